@@ -1,0 +1,136 @@
+/* vdm4cdm_hip.h - C-ABI of libvdm4cdm_hip.so: the MI355X (gfx950) kernels of the vdm4cdm
+ * variational-diffusion denoising hot path.
+ *
+ * The reference (cfpark00/vdm4cdm) has no FFI layer: its hot path is the Python API between its
+ * scripts and the third-party `mltools` package, which bottoms out in ATen ops.  Each entry point
+ * below replaces the ATen op family that one reference call reaches (SURVEY.md section 8a rows
+ * R1-R12); the reference-side call that would bind it is cited per function as
+ * [REF file:line] (files under /root/reference) or [NB ...] (notebook traceback fragment,
+ * SURVEY.md section 3.2).  INTEGRATION.md shows the ctypes stub a maintainer would add.
+ *
+ * Conventions
+ *  - plain pointers and sizes only; every pointer is a DEVICE pointer unless named host_*.
+ *  - the caller owns every buffer (they are torch tensors' data_ptr()s); the library never
+ *    allocates device memory and never synchronises: all work is enqueued on `stream`
+ *    (a hipStream_t passed as void*; NULL = the null stream).
+ *  - activations are NDHWC: x[n][z][y][x][c], dtype VDM_F32 or VDM_BF16 (bf16 = storage only,
+ *    arithmetic and accumulation are fp32).  Channel counts of conv inputs must be a multiple of
+ *    16 bytes (4 fp32 / 8 bf16 elements); the host zero-pads (e.g. conv_in's 2 channels).
+ *  - every function returns VDM_OK (0) or a negative vdm_status; vdm_last_error() returns a
+ *    thread-local message.  No exceptions cross the boundary; HIP errors are translated.
+ */
+#ifndef VDM4CDM_HIP_H
+#define VDM4CDM_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define VDM_ABI_VERSION 1
+
+typedef enum { VDM_OK = 0, VDM_ERR_ARG = -1, VDM_ERR_HIP = -2, VDM_ERR_UNSUPPORTED = -3 } vdm_status;
+typedef enum { VDM_F32 = 0, VDM_BF16 = 1 } vdm_dtype;
+typedef enum { VDM_PAD_ZEROS = 0, VDM_PAD_CIRCULAR = 1 } vdm_pad_mode; /* [REF trainVDM3D128_c_c_from_field_name_thick_lowbatch.py:125] conv_padding_mode */
+typedef enum { VDM_PACK_FWD = 0, VDM_PACK_DGRAD = 1 } vdm_pack_mode;
+
+/* One 3D convolution (k in {1,3}, stride in {1,2}, optional fused nearest x2 up-sampling of the
+ * input).  od/oh/ow are the OUTPUT spatial dims.  Input dims: stride 1: the same; stride 2: 2x
+ * (k=3, pad 1); upsample: the source tensor is (od/2, oh/2, ow/2) and is read at (z>>1,y>>1,x>>1). */
+typedef struct {
+    int32_t n, od, oh, ow;
+    int32_t cin, cout;
+    int32_t ksize;    /* 1 or 3 */
+    int32_t stride;   /* 1 or 2 */
+    int32_t upsample; /* 0 or 1 (only with stride 1, ksize 3) */
+    int32_t pad_mode; /* vdm_pad_mode */
+    int32_t dtype;    /* vdm_dtype of x / residual / out */
+    int32_t out_f32;  /* 1: write `out` as fp32 regardless of dtype (conv_out -> eps_hat) */
+} vdm_conv_desc;
+
+const char* vdm_last_error(void);
+int vdm_abi_version(void);
+/* fills cu_count / lds_bytes_per_cu / gcn arch name (buffer of >= 64 bytes) for `device`. */
+int vdm_device_info(int device, int* cu_count, int* lds_bytes, char* arch_name);
+
+/* ---- K1/K3/K4/K5: convolution (implicit GEMM on MFMA) -------------------------------------
+ * Replaces torch.nn.functional.conv3d as reached from ResNetBlock.net1/net2, ResNetDown and the
+ * up path [NB blocks.py:129-132,166-170; networks.py:259-265].
+ * Master weights are fp32 [taps][cout][cin] (tap = (dz*3+dy)*3+dx).  They are re-packed into the
+ * MFMA fragment order once per optimiser step. */
+size_t vdm_conv_packed_bytes(const vdm_conv_desc* d, int pack_mode);
+int vdm_conv_pack_weights(const vdm_conv_desc* d, int pack_mode, const float* w_master, void* w_packed, void* stream);
+/* out = conv(x, w) + bias[c] + nbias[n][c] + residual   (bias, nbias, residual may be NULL).
+ * nbias is the per-sample conditioning bias table (sum_k Linear_k(cond_k)). */
+int vdm_conv_fwd(const vdm_conv_desc* d, const void* x, const void* w_packed_fwd, const float* bias,
+                 const float* nbias, const void* residual, void* out, void* stream);
+/* dx = conv_transpose(dout, w) for stride-1 convs: the descriptor is the FORWARD conv's; dout has
+ * cout channels, dx gets cin channels (spatial dims od/oh/ow; for an up-sampling conv dx is the
+ * gradient w.r.t. the up-sampled fine tensor - reduce it with vdm_pool2_sum). */
+int vdm_conv_dgrad(const vdm_conv_desc* d, const void* dout, const void* w_packed_dgrad, void* dx, void* stream);
+/* dw[taps][cout][cin] (fp32) = sum over voxels; workspace holds per-workgroup partial slabs. */
+size_t vdm_conv_wgrad_workspace_bytes(const vdm_conv_desc* d);
+int vdm_conv_wgrad(const vdm_conv_desc* d, const void* x, const void* dout, float* dw, int accumulate,
+                   void* workspace, size_t workspace_bytes, void* stream);
+
+/* ---- K2: GroupNorm + SiLU (+ dropout) -----------------------------------------------------
+ * Replaces torch.group_norm / F.silu / F.dropout [NB normalization.py:273 frame under blocks.py:130].
+ * The input may be the channel-concatenation of two tensors (skip connection), never materialised.
+ * stats[n][g] = {sum, sumsq} in fp32 (raw moments; mean/rstd are derived where consumed). */
+int vdm_gn_stats(const void* x1, int c1, const void* x2, int c2, int n, int64_t voxels, int groups,
+                 int dtype, float* stats, void* stream);
+/* y[n][v][c1+c2] = dropout(silu(gn(concat(x1,x2)))) ; keep-mask from Philox(seed, element index). */
+int vdm_gn_silu_fwd(const void* x1, int c1, const void* x2, int c2, int n, int64_t voxels, int groups,
+                    int dtype, const float* stats, const float* gamma, const float* beta, float eps,
+                    float dropout_p, uint64_t seed, void* y, void* stream);
+/* Backward of the above.  dy is the gradient w.r.t. y.  Writes dx1 (and dx2), ADDS into
+ * dgamma/dbeta [c] (caller zeroes), optional `add` (same layout as dy) is added to dx, optional
+ * colsum[n][c1+c2] receives sum_v dx (caller zeroes; used for bias / conditioning-bias grads).
+ * red_ws: >= n*groups*2 floats of scratch. */
+int vdm_gn_silu_bwd(const void* x1, int c1, const void* x2, int c2, int n, int64_t voxels, int groups,
+                    int dtype, const float* stats, const float* gamma, const float* beta, float eps,
+                    float dropout_p, uint64_t seed, const void* dy, const void* add, void* dx1, void* dx2,
+                    float* dgamma, float* dbeta, float* colsum, float* red_ws, void* stream);
+
+/* ---- small tensor ops on the path ------------------------------------------------------------ */
+/* out[n][c] (+)= sum_v x[n][v][c]   (conv bias gradients). */
+int vdm_colsum(const void* x, int n, int64_t voxels, int c, int dtype, float* out, void* stream);
+/* fine[n][2z+a][2y+b][2x+c][ch] = (a|b|c)==0 ? coarse[n][z][y][x][ch] : 0  (stride-2 dgrad helper). */
+int vdm_dilate2(const void* coarse, void* fine, int n, int cd, int ch, int cw, int c, int dtype, void* stream);
+/* coarse = sum of the 2x2x2 children of fine (backward of nearest x2 up-sampling). */
+int vdm_pool2_sum(const void* fine, void* coarse, int n, int cd, int ch, int cw, int c, int dtype, void* stream);
+/* dst = (dst_dtype) src, n elements. */
+int vdm_cast(const void* src, int src_dtype, void* dst, int dst_dtype, int64_t n, void* stream);
+/* out[n][v][cpad] <- channels {a[n][v], b[n][v] (b may be NULL)} zero-padded to cpad; a,b fp32. */
+int vdm_pack_input(const float* a, const float* b, int64_t nvox, int cpad, int dtype, void* out, void* stream);
+
+/* ---- K7/K8: VDM forward diffusion + ELBO pieces [R7; D9/D10] -----------------------------------
+ * z_t = alpha[n] x + sigma[n] eps  (fp32, contiguous per sample of `per` elements). */
+int vdm_diffuse(const float* x, const float* eps, const float* alpha, const float* sigma, int n, int64_t per,
+                float* z_t, void* stream);
+/* sums[n][3] += {sum (eps-eps_hat)^2, sum x^2, sum (x - z0r)^2} with z0r = x + (sigma0/alpha0) eps0;
+ * d_eps_hat = coef[n] * (eps_hat - eps)   (coef folds bpd * gamma'(t) / B).  Caller zeroes sums. */
+int vdm_loss_terms(const float* x, const float* eps, const float* eps_hat, const float* eps0, float sigma0_over_alpha0,
+                   const float* coef, int n, int64_t per, float* sums, float* d_eps_hat, void* stream);
+
+/* ---- K9: ancestral update [NB vdm_model.py:370-378] ----------------------------------------
+ * z <- ratio*(z - c_sigma_t*eps_hat) + scale*noise ; the four scalars are read from the DEVICE table
+ * coef[step][4] = {ratio, c*sigma_t, scale, t_norm} at row *step_ptr (so one captured graph serves
+ * every step).  noise==NULL: Philox normal from (seed, *step_ptr, element index). */
+int vdm_ancestral_step(float* z, const float* eps_hat, const float* noise, const float* coef, const int32_t* step_ptr,
+                       uint64_t seed, int64_t n, void* stream);
+/* standard-normal fill from Philox(seed, stream_id) (z_1 of the sampler; eps in training). */
+int vdm_randn(float* out, int64_t n, uint64_t seed, uint64_t stream_id, void* stream);
+/* *step_ptr += 1 (device-side step counter for the captured sampler graph). */
+int vdm_step_inc(int32_t* step_ptr, void* stream);
+
+/* ---- K10: global gradient norm [REF trainVDM3D128_c_c_from_field_name_thick_lowbatch.py:45] -- */
+/* out[0] += sum x^2 (caller zeroes). */
+int vdm_sumsq(const float* x, int64_t n, float* out, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* VDM4CDM_HIP_H */

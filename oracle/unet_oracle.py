@@ -1,0 +1,116 @@
+"""Oracle: conditional UNet score network (fp32, CPU, plain torch.nn.functional).
+
+TEST INFRASTRUCTURE ONLY (see oracle/__init__.py).  PARITY UNPINNED: the reference delegates
+this network to the un-vendored ``mltools.networks.networks.CUNet``; what follows restates
+spec decisions D1-D8 of SURVEY.md section 8 and matches every observable of the reference:
+
+* constructor kwargs      /root/reference/trainVDM3D128_c_c_from_field_name_thick_lowbatch.py:116-127
+* forward signature       ``forward(x, t, s_conditioning, v_conditionings)`` and the down loop
+                          ``h, h_skip = down(h, conditionings=..., no_down=(i == len(downs)-1))``
+                          (notebook traceback ``networks.py:259-265``)
+* ResNetDown              ``for resnet_block in resnet_blocks: x = resnet_block(x, conditionings)``
+                          (``blocks.py:166-170``)
+* ResNetBlock             ``h = self.net1(x)`` with net1 = Sequential(GroupNorm, ...); one conditioning
+                          projection per entry of ``conditioning_dims`` (``blocks.py:129-132``)
+* ``.shape`` attribute    /root/reference/src/utils.py:287
+
+Tensors are channels-first (N, C, *spatial); conv weights are in torch layout (Cout, Cin, *k).
+Parameter names are the product's (vdm4cdm_amd.networks.CUNet.param_spec); the test helper
+``tests/helpers.py::oracle_params`` converts the product's tap-major conv layout.
+"""
+import math
+
+import torch
+import torch.nn.functional as F
+
+T_EMB_DIM = 64          # D7: sinusoidal embedding width
+V_EMB_DIM = 64          # D7: width of each vector-conditioning embedding
+GN_EPS = 1e-5           # torch.nn.GroupNorm default (reference: normalization.py:273 frame)
+
+
+def _conv(x, w, b, padding_mode, stride=1):
+    """k^dim convolution with 'zeros' or 'circular' padding (D8)."""
+    dim = x.dim() - 2
+    k = w.shape[-1]
+    pad = k // 2
+    f = F.conv3d if dim == 3 else F.conv2d
+    if pad and padding_mode == "circular":
+        x = F.pad(x, (pad, pad) * dim, mode="circular")
+        return f(x, w, b, stride=stride)
+    return f(x, w, b, stride=stride, padding=pad)
+
+
+def sinusoidal_embedding(t, dim=T_EMB_DIM):
+    """t in [0,1] (normalised gamma, vdm_model.py:322) -> (B, dim).  D7."""
+    half = dim // 2
+    freqs = torch.exp(-math.log(10000.0) * torch.arange(half, dtype=torch.float32) / half)
+    args = 1000.0 * t.to(torch.float32)[:, None] * freqs[None, :]
+    return torch.cat([torch.sin(args), torch.cos(args)], dim=1)
+
+
+def _mlp2(p, prefix, x):
+    x = F.gelu(F.linear(x, p[prefix + ".0.weight"], p[prefix + ".0.bias"]))
+    return F.gelu(F.linear(x, p[prefix + ".2.weight"], p[prefix + ".2.bias"]))
+
+
+def resnet_block(p, prefix, x, conds, groups, padding_mode, drop_mask=None):
+    """D4: net1=[GN,SiLU,Conv3] + sum_k Linear_k(cond_k) ; net2=[GN,SiLU,Dropout,Conv3(zero-init)] ; skip."""
+    h = F.group_norm(x, groups, p[prefix + ".norm1.weight"], p[prefix + ".norm1.bias"], GN_EPS)
+    h = _conv(F.silu(h), p[prefix + ".conv1.weight"], p[prefix + ".conv1.bias"], padding_mode)
+    for k, c in enumerate(conds):
+        proj = F.linear(c, p[f"{prefix}.cond.{k}.weight"])          # bias-free, D4
+        h = h + proj.reshape(proj.shape + (1,) * (x.dim() - 2))
+    h = F.group_norm(h, groups, p[prefix + ".norm2.weight"], p[prefix + ".norm2.bias"], GN_EPS)
+    h = F.silu(h)
+    if drop_mask is not None:                                       # pre-scaled keep mask
+        h = h * drop_mask
+    h = _conv(h, p[prefix + ".conv2.weight"], p[prefix + ".conv2.bias"], padding_mode)
+    if prefix + ".skip.weight" in p:
+        x = _conv(x, p[prefix + ".skip.weight"], p[prefix + ".skip.bias"], padding_mode)
+    return x + h
+
+
+def cunet_forward(p, cfg, x, t, s_conditioning=None, v_conditionings=(), drop_masks=None,
+                  taps=None):
+    """eps_hat = CUNet(concat(x, s_conditioning); t, v).  D1-D8.
+
+    cfg: dict(chs, norm_groups, padding_mode).  drop_masks: optional dict block-prefix -> mask.
+    taps: optional dict that receives named intermediates (for per-layer parity tests).
+    """
+    chs = cfg["chs"]
+    G = cfg["norm_groups"]
+    pm = cfg["padding_mode"]
+    L = len(chs)
+    dm = drop_masks or {}
+
+    conds = []
+    if "t_embed.0.weight" in p:
+        conds.append(_mlp2(p, "t_embed", sinusoidal_embedding(t)))
+    for k, v in enumerate(v_conditionings):
+        conds.append(_mlp2(p, f"v_embeds.{k}", v.to(torch.float32)))
+
+    h = x if s_conditioning is None else torch.cat([x, s_conditioning], dim=1)   # D6
+    h = _conv(h, p["conv_in.weight"], p["conv_in.bias"], pm)
+    if taps is not None:
+        taps["conv_in"] = h
+    skips = []
+    for i in range(L):                                                            # D2/D3
+        h = resnet_block(p, f"downs.{i}.block", h, conds, G, pm, dm.get(f"downs.{i}.block"))
+        if taps is not None:
+            taps[f"downs.{i}.block"] = h
+        if i != L - 1:                                                            # no_down on the last
+            skips.append(h)
+            h = _conv(h, p[f"downs.{i}.down.weight"], p[f"downs.{i}.down.bias"], pm, stride=2)  # D5
+    for j in range(2):
+        h = resnet_block(p, f"mid.{j}", h, conds, G, pm, dm.get(f"mid.{j}"))
+    if taps is not None:
+        taps["mid"] = h
+    for i in reversed(range(L - 1)):
+        h = F.interpolate(h, scale_factor=2, mode="nearest")                      # D5
+        h = _conv(h, p[f"ups.{i}.up.weight"], p[f"ups.{i}.up.bias"], pm)
+        h = torch.cat([h, skips[i]], dim=1)
+        h = resnet_block(p, f"ups.{i}.block", h, conds, G, pm, dm.get(f"ups.{i}.block"))
+        if taps is not None:
+            taps[f"ups.{i}.block"] = h
+    h = F.group_norm(h, G, p["norm_out.weight"], p["norm_out.bias"], GN_EPS)      # D6
+    return _conv(F.silu(h), p["conv_out.weight"], p["conv_out.bias"], pm)

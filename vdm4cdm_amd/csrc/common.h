@@ -1,0 +1,132 @@
+// vdm4cdm_amd: common device/host helpers for the gfx950 (MI355X, CDNA4) kernels.
+// Wave = 64 lanes.  All activation tensors are NDHWC ("voxel-major": [n][z][y][x][c]).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/vdm4cdm_hip.h"
+
+namespace vdm {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+
+struct bf16_t {            // storage-only bf16 (arithmetic is always fp32)
+    uint16_t v;
+};
+
+__device__ __forceinline__ float bf16_to_f32(uint16_t h) {
+    return __builtin_bit_cast(float, (uint32_t)h << 16);
+}
+__device__ __forceinline__ uint16_t f32_to_bf16(float f) {      // RNE, NaN-preserving (plain cast)
+    return __builtin_bit_cast(uint16_t, (__bf16)f);
+}
+__device__ __forceinline__ uint32_t pack_bf16x2(float lo, float hi) {
+    return (uint32_t)f32_to_bf16(lo) | ((uint32_t)f32_to_bf16(hi) << 16);
+}
+
+// Per-dtype constants.  A "piece" is 16 bytes of consecutive channels of one voxel
+// (EPL elements); a "K-block" is 4 pieces = 64 bytes = KB channels.
+template <typename T> struct DT;
+template <> struct DT<float> {
+    static constexpr int EPL = 4, KB = 16, ID = VDM_F32;
+    static constexpr int SHIFT = 2;                  // log2(sizeof)
+};
+template <> struct DT<bf16_t> {
+    static constexpr int EPL = 8, KB = 32, ID = VDM_BF16;
+    static constexpr int SHIFT = 1;
+};
+
+// ---- 16-byte piece <-> fp32 lanes -------------------------------------------------------
+template <typename T> struct Piece;                   // EPL floats
+template <> struct Piece<float> {
+    float f[4];
+    __device__ __forceinline__ void load(const uint4& u) {
+        f[0] = __builtin_bit_cast(float, u.x); f[1] = __builtin_bit_cast(float, u.y);
+        f[2] = __builtin_bit_cast(float, u.z); f[3] = __builtin_bit_cast(float, u.w);
+    }
+    __device__ __forceinline__ uint4 store() const {
+        return make_uint4(__builtin_bit_cast(uint32_t, f[0]), __builtin_bit_cast(uint32_t, f[1]),
+                          __builtin_bit_cast(uint32_t, f[2]), __builtin_bit_cast(uint32_t, f[3]));
+    }
+};
+template <> struct Piece<bf16_t> {
+    float f[8];
+    __device__ __forceinline__ void load(const uint4& u) {
+        const uint32_t w[4] = {u.x, u.y, u.z, u.w};
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            f[2 * i] = __builtin_bit_cast(float, w[i] << 16);
+            f[2 * i + 1] = __builtin_bit_cast(float, w[i] & 0xffff0000u);
+        }
+    }
+    __device__ __forceinline__ uint4 store() const {
+        return make_uint4(pack_bf16x2(f[0], f[1]), pack_bf16x2(f[2], f[3]),
+                          pack_bf16x2(f[4], f[5]), pack_bf16x2(f[6], f[7]));
+    }
+};
+
+template <typename T> __device__ __forceinline__ float ld_elem(const T* p);
+template <> __device__ __forceinline__ float ld_elem<float>(const float* p) { return *p; }
+template <> __device__ __forceinline__ float ld_elem<bf16_t>(const bf16_t* p) { return bf16_to_f32(p->v); }
+template <typename T> __device__ __forceinline__ void st_elem(T* p, float v);
+template <> __device__ __forceinline__ void st_elem<float>(float* p, float v) { *p = v; }
+template <> __device__ __forceinline__ void st_elem<bf16_t>(bf16_t* p, float v) { p->v = f32_to_bf16(v); }
+
+// ---- wave / block reductions (wave64) -------------------------------------------------------
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+__device__ __forceinline__ float silu_f(float y) { return y / (1.0f + __expf(-y)); }
+__device__ __forceinline__ float sigmoid_f(float y) { return 1.0f / (1.0f + __expf(-y)); }
+
+// ---- Philox4x32-10 counter RNG (dropout masks, sampler noise) ---------------------------------
+struct Philox {
+    static constexpr uint32_t M0 = 0xD2511F53u, M1 = 0xCD9E8D57u, W0 = 0x9E3779B9u, W1 = 0xBB67AE85u;
+    __host__ __device__ static inline void mulhilo(uint32_t a, uint32_t b, uint32_t& hi, uint32_t& lo) {
+        const uint64_t p = (uint64_t)a * b;
+        hi = (uint32_t)(p >> 32);
+        lo = (uint32_t)p;
+    }
+    // counter = (c0,c1,c2,c3), key = (k0,k1) -> 4 x u32
+    __host__ __device__ static inline void gen(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3,
+                                               uint32_t k0, uint32_t k1, uint32_t out[4]) {
+#pragma unroll
+        for (int r = 0; r < 10; ++r) {
+            uint32_t h0, l0, h1, l1;
+            mulhilo(M0, c0, h0, l0);
+            mulhilo(M1, c2, h1, l1);
+            const uint32_t n0 = h1 ^ c1 ^ k0, n1 = l1, n2 = h0 ^ c3 ^ k1, n3 = l0;
+            c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+            k0 += W0; k1 += W1;
+        }
+        out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
+    }
+};
+__host__ __device__ inline float u32_to_unit(uint32_t u) {          // (0,1]
+    return ((float)(u >> 8) + 1.0f) * (1.0f / 16777216.0f);
+}
+
+// ---- host-side error plumbing ------------------------------------------------------------
+void set_error(const char* fmt, ...);
+int check_hip(hipError_t e, const char* what);
+
+#define VDM_REQUIRE(cond, ...)                      \
+    do {                                            \
+        if (!(cond)) {                              \
+            vdm::set_error(__VA_ARGS__);            \
+            return VDM_ERR_ARG;                     \
+        }                                           \
+    } while (0)
+
+#define VDM_LAUNCH_CHECK(what)                                   \
+    do {                                                         \
+        int _e = vdm::check_hip(hipGetLastError(), what);        \
+        if (_e) return _e;                                       \
+    } while (0)
+
+}  // namespace vdm

@@ -1,0 +1,722 @@
+// conv.hip - 3D convolution as implicit GEMM on the gfx950 matrix cores (K1/K3/K4/K5 of DESIGN.md).
+//
+// Replaces torch.nn.functional.conv3d as reached from mltools' ResNetBlock / ResNetDown / up path
+// (reference call chain: SURVEY.md section 3.2; notebook frames blocks.py:129-132,166-170).
+//
+// Mapping (same for fp32 and bf16 storage; accumulation always fp32):
+//   D[cout][voxel] += W[cout][k] * X[k][voxel],   k = (tap, cin)
+//   MFMA 16x16x32 bf16 (or 16x16x4 f32): A = packed weights (global -> VGPR, fragment order),
+//   B = activations read from an LDS halo tile, D: lane (v = lane&15, q = lane>>4) owns voxel v and
+//   4*NC consecutive output channels -> 16-byte NDHWC stores.
+//   One workgroup = 4 waves = TZ x TY x 16 output voxels x (NC*16) output channels.
+//   LDS halo image is "piece-major": [piece 0..3][halo voxel][16 B], plane stride a multiple of
+//   256 B, so the 64-lane ds_read_b128 of 16 x-consecutive voxels is bank-conflict-free.
+// wgrad: D[cout][cin] += dOut^T[cout][voxel] * X[voxel][cin]; both operands are voxel-major in LDS
+//   and are read transposed with ds_read_b64_tr_b16 (bf16) / ds_read_b32 (fp32); workgroups are
+//   persistent over spatial tiles and write partial slabs that a second kernel reduces
+//   (deterministic, no float atomics).
+#include <stdarg.h>
+#include <stdio.h>
+
+#include "common.h"
+
+namespace vdm {
+
+static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
+
+// ---------------------------------------------------------------------------------------------
+// geometry
+// ---------------------------------------------------------------------------------------------
+template <int KS_, int STRIDE_, int TZ_, int TY_>
+struct Geo {
+    static constexpr int KS = KS_, STRIDE = STRIDE_, TZ = TZ_, TY = TY_, TX = 16;
+    static constexpr int PAD = KS / 2;
+    static constexpr int TAPS = KS * KS * KS;
+    static constexpr int HZ = (TZ - 1) * STRIDE + KS, HY = (TY - 1) * STRIDE + KS, HX = (TX - 1) * STRIDE + KS;
+    static constexpr int HVOX = HZ * HY * HX;
+    static constexpr int HVOX_PAD = (HVOX + 15) / 16 * 16;
+    static constexpr int PLANE = HVOX_PAD * 16;          // bytes, multiple of 256
+    static constexpr int ROWS = TZ * TY;                 // 16-voxel MFMA columns-tiles per workgroup
+    static constexpr int NV = ROWS / 4;                  // per wave
+    static constexpr int OVOX = ROWS * 16;
+    static constexpr int OPLANE = OVOX * 16;             // dOut tile plane (wgrad)
+    static_assert(ROWS % 4 == 0, "rows must split over 4 waves");
+};
+
+struct ConvArgs {
+    const void* x;       // staged operand (input for fwd/wgrad, dOut for dgrad)
+    const void* w;       // packed weights
+    const float* bias;
+    const float* nbias;
+    const void* res;
+    void* out;
+    int N, Dz, Dy, Dx;   // output spatial dims
+    int Iz, Iy, Ix;      // logical input grid the taps index
+    int Sz, Sy, Sx;      // source tensor dims (== I, or I/2 when up-sampling)
+    int Cin, CinStride;  // reduction channels, channel stride of x
+    int Cout;            // output channels (exact stride of out / res)
+    int circular;
+    int ntz, nty, ntx, nchunks, nkb;
+};
+
+// halo voxel index -> LDS byte offset of piece pc
+template <int PLANE, int ODD_OFF>
+__device__ __forceinline__ int lds_off(int pc, int hv) {
+    return pc * PLANE + (pc & 1) * ODD_OFF + hv * 16;
+}
+
+__device__ __forceinline__ int wrap(int i, int n) {
+    i %= n;
+    return i < 0 ? i + n : i;
+}
+
+// Stage one K-block (64 B of channels per voxel) of the halo tile into LDS.
+template <typename T, typename G, int UPS, int ODD_OFF>
+__device__ __forceinline__ void stage_halo(char* lds, const T* __restrict__ x, const ConvArgs& a, int n,
+                                           int oz0, int oy0, int ox0, int kb, int tid) {
+    constexpr int EPL = DT<T>::EPL, KB = DT<T>::KB;
+    constexpr int NP = (G::HVOX + 7) / 8 * 32;
+    const int iz0 = oz0 * G::STRIDE - G::PAD, iy0 = oy0 * G::STRIDE - G::PAD, ix0 = ox0 * G::STRIDE - G::PAD;
+#pragma unroll 4
+    for (int p = tid; p < NP; p += 256) {
+        const int pc = (p >> 3) & 3;
+        const int hv = ((p >> 5) << 3) + (p & 7);
+        if (hv < G::HVOX) {
+            const int hx = hv % G::HX;
+            const int t = hv / G::HX;
+            const int hy = t % G::HY;
+            const int hz = t / G::HY;
+            int iz = iz0 + hz, iy = iy0 + hy, ix = ix0 + hx;
+            const int ci = kb * KB + pc * EPL;
+            bool ok = ci < a.Cin;
+            if (a.circular) {
+                iz = wrap(iz, a.Iz); iy = wrap(iy, a.Iy); ix = wrap(ix, a.Ix);
+            } else {
+                ok = ok && (unsigned)iz < (unsigned)a.Iz && (unsigned)iy < (unsigned)a.Iy && (unsigned)ix < (unsigned)a.Ix;
+            }
+            if (UPS) { iz >>= 1; iy >>= 1; ix >>= 1; }
+            uint4 v = make_uint4(0, 0, 0, 0);
+            if (ok) {
+                const size_t off = ((((size_t)n * a.Sz + iz) * a.Sy + iy) * a.Sx + ix) * a.CinStride + ci;
+                v = *reinterpret_cast<const uint4*>(x + off);
+            }
+            *reinterpret_cast<uint4*>(lds + lds_off<G::PLANE, ODD_OFF>(pc, hv)) = v;
+        }
+    }
+}
+
+// Stage the (halo-free) dOut tile of a wgrad workgroup: OVOX voxels x 64 B (one channel block).
+template <typename T, typename G>
+__device__ __forceinline__ void stage_dout(char* lds, const T* __restrict__ g, const ConvArgs& a, int n, int oz0,
+                                           int oy0, int ox0, int cb, int cstride, int tid) {
+    constexpr int EPL = DT<T>::EPL, KB = DT<T>::KB;
+    constexpr int NP = G::OVOX * 4;
+#pragma unroll 4
+    for (int p = tid; p < NP; p += 256) {
+        const int pc = (p >> 3) & 3;
+        const int ov = ((p >> 5) << 3) + (p & 7);
+        const int lx = ov & 15, r = ov >> 4;
+        const int oz = oz0 + r / G::TY, oy = oy0 + r % G::TY, ox = ox0 + lx;
+        const int co = cb * KB + pc * EPL;
+        uint4 v = make_uint4(0, 0, 0, 0);
+        if (co < a.Cout && oz < a.Dz && oy < a.Dy && ox < a.Dx) {
+            const size_t off = ((((size_t)n * a.Dz + oz) * a.Dy + oy) * a.Dx + ox) * cstride + co;
+            v = *reinterpret_cast<const uint4*>(g + off);
+        }
+        *reinterpret_cast<uint4*>(lds + lds_off<G::OPLANE, 128>(pc, ov)) = v;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// MFMA wrappers: acc[16 cout x 16 voxel] += A(16 cout x 64 B of k) * B(64 B of k x 16 voxel)
+// ---------------------------------------------------------------------------------------------
+template <typename T> __device__ __forceinline__ void mma16(f32x4& acc, const uint4& a, const uint4& b);
+template <> __device__ __forceinline__ void mma16<bf16_t>(f32x4& acc, const uint4& a, const uint4& b) {
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), acc, 0, 0, 0);
+}
+template <> __device__ __forceinline__ void mma16<float>(f32x4& acc, const uint4& a, const uint4& b) {
+    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(__builtin_bit_cast(float, a.x), __builtin_bit_cast(float, b.x), acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(__builtin_bit_cast(float, a.y), __builtin_bit_cast(float, b.y), acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(__builtin_bit_cast(float, a.z), __builtin_bit_cast(float, b.z), acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(__builtin_bit_cast(float, a.w), __builtin_bit_cast(float, b.w), acc, 0, 0, 0);
+}
+
+// XCD-aware, bijective block remap: blocks b and b+8 share an XCD (observed round-robin), so give
+// each XCD a contiguous run of spatial tiles (their halos overlap -> hits in that XCD's L2).
+__device__ __forceinline__ int xcd_remap(int bid, int nwg) {
+    const int xcd = bid & 7, q = nwg >> 3, r = nwg & 7;
+    return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+}
+
+// ---------------------------------------------------------------------------------------------
+// forward / dgrad kernel
+// ---------------------------------------------------------------------------------------------
+template <typename T, typename TO, int KS, int STRIDE, int UPS, int NC, int TZ, int TY>
+__global__ void __launch_bounds__(256, 2) conv_fwd_kernel(const ConvArgs a) {
+    using G = Geo<KS, STRIDE, TZ, TY>;
+    constexpr int EPL = DT<T>::EPL;
+    constexpr int NV = G::NV, TAPS = G::TAPS;
+    extern __shared__ __attribute__((aligned(16))) char lds[];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lx = lane & 15, q = lane >> 4;
+
+    int b = xcd_remap(blockIdx.x, gridDim.x);
+    const int tx = b % a.ntx; b /= a.ntx;
+    const int ty = b % a.nty; b /= a.nty;
+    const int tz = b % a.ntz; b /= a.ntz;
+    const int n = b % a.N;
+    const int chunk = b / a.N;
+    const int oz0 = tz * TZ, oy0 = ty * TY, ox0 = tx * 16;
+
+    f32x4 acc[NV][NC];
+#pragma unroll
+    for (int v = 0; v < NV; ++v)
+#pragma unroll
+        for (int c = 0; c < NC; ++c) acc[v][c] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    // per-row LDS base (tap 0) of this lane: piece q, halo voxel ((rz*S)*HY + ry*S)*HX + lx*S
+    int rowbase[NV];
+#pragma unroll
+    for (int v = 0; v < NV; ++v) {
+        const int r = wave * NV + v;
+        const int rz = r / TY, ry = r % TY;
+        rowbase[v] = q * G::PLANE + (((rz * STRIDE) * G::HY + ry * STRIDE) * G::HX + lx * STRIDE) * 16;
+    }
+
+    const uint4* wbase = reinterpret_cast<const uint4*>(a.w) + (size_t)chunk * a.nkb * TAPS * NC * 64 + lane;
+    const T* x = reinterpret_cast<const T*>(a.x);
+
+    for (int kb = 0; kb < a.nkb; ++kb) {
+        if (kb) __syncthreads();
+        stage_halo<T, G, UPS, 0>(lds, x, a, n, oz0, oy0, ox0, kb, tid);
+        __syncthreads();
+        const uint4* wk = wbase + (size_t)kb * TAPS * NC * 64;
+        // bf16: all taps unrolled (tap offsets become immediates).  fp32: rolled - the 4x longer MFMA
+        // chain otherwise makes the scheduler hoist LDS reads until it spills.
+        constexpr int TAP_UNROLL = sizeof(T) == 2 ? TAPS : 1;
+#pragma clang loop unroll_count(TAP_UNROLL)
+        for (int tap = 0; tap < TAPS; ++tap) {
+            const int dz = tap / (KS * KS), dy = (tap / KS) % KS, dx = tap % KS;
+            const int toff = ((dz * G::HY + dy) * G::HX + dx) * 16;
+            uint4 wf[NC];
+#pragma unroll
+            for (int c = 0; c < NC; ++c) wf[c] = wk[(tap * NC + c) * 64];
+#pragma unroll
+            for (int v = 0; v < NV; ++v) {
+                const uint4 af = *reinterpret_cast<const uint4*>(lds + rowbase[v] + toff);
+#pragma unroll
+                for (int c = 0; c < NC; ++c) mma16<T>(acc[v][c], wf[c], af);
+            }
+        }
+    }
+
+    // ---- epilogue: + bias + per-sample conditioning bias + residual, cast, store ----------------
+    const int cbase = chunk * NC * 16 + q * NC * 4;     // first of this lane's NC*4 consecutive couts
+    float badd[NC * 4];
+#pragma unroll
+    for (int j = 0; j < NC * 4; ++j) {
+        float bv = 0.f;
+        if (cbase + j < a.Cout) {
+            if (a.bias) bv += a.bias[cbase + j];
+            if (a.nbias) bv += a.nbias[(size_t)n * a.Cout + cbase + j];
+        }
+        badd[j] = bv;
+    }
+    const bool vec_ok = (a.Cout % (NC * 4) == 0) && (cbase + NC * 4 <= a.Cout);
+    TO* out = reinterpret_cast<TO*>(a.out);
+    const T* res = reinterpret_cast<const T*>(a.res);
+#pragma unroll
+    for (int v = 0; v < NV; ++v) {
+        const int r = wave * NV + v;
+        const int oz = oz0 + r / TY, oy = oy0 + r % TY, ox = ox0 + lx;
+        if (oz >= a.Dz || oy >= a.Dy || ox >= a.Dx) continue;
+        const size_t vo = ((((size_t)n * a.Dz + oz) * a.Dy + oy) * a.Dx + ox) * a.Cout + cbase;
+        float val[NC * 4];
+#pragma unroll
+        for (int c = 0; c < NC; ++c)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) val[c * 4 + j] = acc[v][c][j] + badd[c * 4 + j];
+        if (vec_ok) {
+            if (res) {
+                constexpr int RP = NC * 4 / EPL > 0 ? NC * 4 / EPL : 1;    // 16-B pieces (bf16 NC=1: half piece)
+                if (NC * 4 >= EPL) {
+#pragma unroll
+                    for (int i = 0; i < RP; ++i) {
+                        Piece<T> pr;
+                        pr.load(*reinterpret_cast<const uint4*>(res + vo + i * EPL));
+#pragma unroll
+                        for (int j = 0; j < EPL; ++j) val[i * EPL + j] += pr.f[j];
+                    }
+                } else {
+#pragma unroll
+                    for (int j = 0; j < NC * 4; ++j) val[j] += ld_elem<T>(res + vo + j);
+                }
+            }
+            if (sizeof(TO) == 4) {
+#pragma unroll
+                for (int c = 0; c < NC; ++c)
+                    *reinterpret_cast<float4*>(reinterpret_cast<float*>(out) + vo + c * 4) =
+                        make_float4(val[c * 4], val[c * 4 + 1], val[c * 4 + 2], val[c * 4 + 3]);
+            } else {
+                uint16_t* o16 = reinterpret_cast<uint16_t*>(out) + vo;
+                if (NC == 1) {
+                    *reinterpret_cast<uint2*>(o16) = make_uint2(pack_bf16x2(val[0], val[1]), pack_bf16x2(val[2], val[3]));
+                } else {
+#pragma unroll
+                    for (int i = 0; i < NC / 2; ++i)
+                        *reinterpret_cast<uint4*>(o16 + i * 8) =
+                            make_uint4(pack_bf16x2(val[i * 8], val[i * 8 + 1]), pack_bf16x2(val[i * 8 + 2], val[i * 8 + 3]),
+                                       pack_bf16x2(val[i * 8 + 4], val[i * 8 + 5]), pack_bf16x2(val[i * 8 + 6], val[i * 8 + 7]));
+                }
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < NC * 4; ++j) {
+                if (cbase + j < a.Cout) {
+                    float o = val[j];
+                    if (res) o += ld_elem<T>(res + vo + j);
+                    st_elem<TO>(out + vo + j, o);
+                }
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// wgrad kernel
+// ---------------------------------------------------------------------------------------------
+struct WgradArgs {
+    ConvArgs c;          // c.x = input, c.Cin/CinStride = input channels, c.Cout = dOut channels
+    const void* dout;
+    int dout_stride;
+    float* slabs;        // [pair][P][slot]... see wgrad_reduce
+    int P;               // persistent workgroups per (cout block, cin block) pair
+    int ntiles;          // N * ntz * nty * ntx
+    int ncb, nkb;        // cout blocks, cin blocks (64 B each)
+};
+
+template <typename T> struct WG;     // 16x16 tiles per 64-byte channel block
+template <> struct WG<bf16_t> { static constexpr int NT = 2; };
+template <> struct WG<float> { static constexpr int NT = 1; };
+
+// transposed operand fetch: 16 channels (tile ct of the 64 B block) x the k-step's voxels.
+// bf16: two ds_read_b64_tr_b16 (rows r0 and r0+1 of 16 voxels);  fp32: four ds_read_b32.
+// `vox0`/`vox1`: LDS voxel index (already including tap shift) of x==0 in row r0 / r0+1, `xs` = x stride.
+template <typename T, int PLANE>
+struct TrFetch;
+template <int PLANE>
+struct TrFetch<bf16_t, PLANE> {
+    // lane: g = lane>>4 (voxels 4g..4g+3), li = lane&15: row-in-block q' = li>>2, column quad p = li&3
+    static __device__ __forceinline__ uint4 get(const char* lds, int ct, int vox0, int vox1, int xs, int lane) {
+        const int g = lane >> 4, li = lane & 15, qp = li >> 2, p = li & 3;
+        const int pc = 2 * ct + (p >> 1);
+        const int xo = (4 * g + qp) * xs;
+        const int base = pc * PLANE + (pc & 1) * 128 + (p & 1) * 8;
+        typedef __attribute__((address_space(3))) s16x4* lptr;
+        const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lptr)(lds + base + (vox0 + xo) * 16));
+        const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lptr)(lds + base + (vox1 + xo) * 16));
+        const uint2 l2 = __builtin_bit_cast(uint2, lo), h2 = __builtin_bit_cast(uint2, hi);
+        return make_uint4(l2.x, l2.y, h2.x, h2.y);
+    }
+};
+template <int PLANE>
+struct TrFetch<float, PLANE> {
+    // lane: channel m = lane&15, k-slot kq = lane>>4; MFMA step s reads voxel x = 4*s + kq of row r0.
+    static __device__ __forceinline__ uint4 get(const char* lds, int ct, int vox0, int vox1, int xs, int lane) {
+        (void)ct; (void)vox1;
+        const int m = lane & 15, kq = lane >> 4;
+        const int pc = m >> 2;
+        const int base = pc * PLANE + (pc & 1) * 128 + (m & 3) * 4;
+        uint4 r;
+        r.x = *reinterpret_cast<const uint32_t*>(lds + base + (vox0 + (0 + kq) * xs) * 16);
+        r.y = *reinterpret_cast<const uint32_t*>(lds + base + (vox0 + (4 + kq) * xs) * 16);
+        r.z = *reinterpret_cast<const uint32_t*>(lds + base + (vox0 + (8 + kq) * xs) * 16);
+        r.w = *reinterpret_cast<const uint32_t*>(lds + base + (vox0 + (12 + kq) * xs) * 16);
+        return r;
+    }
+};
+
+template <typename T, int KS, int STRIDE, int UPS, int TZ, int TY>
+__global__ void __launch_bounds__(256, 1) conv_wgrad_kernel(const WgradArgs w) {
+    using G = Geo<KS, STRIDE, TZ, TY>;
+    constexpr int NT = WG<T>::NT;
+    constexpr int TAPS = G::TAPS;
+    constexpr int TPW = (TAPS + 3) / 4;                    // taps per wave (KS=3: 7; KS=1: 1)
+    constexpr int RSTEP = (sizeof(T) == 2) ? 2 : 1;        // rows consumed per k-step
+    constexpr int IN_BYTES = 4 * G::PLANE + 128;
+    extern __shared__ __attribute__((aligned(16))) char lds[];
+    char* lds_in = lds;
+    char* lds_do = lds + IN_BYTES;
+    const ConvArgs& a = w.c;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+
+    const int pair = blockIdx.x / w.P, pidx = blockIdx.x % w.P;
+    const int cb = pair / w.nkb, kb = pair % w.nkb;        // cout block, cin block
+
+    f32x4 acc[TPW][NT][NT];
+#pragma unroll
+    for (int t = 0; t < TPW; ++t)
+#pragma unroll
+        for (int i = 0; i < NT; ++i)
+#pragma unroll
+            for (int j = 0; j < NT; ++j) acc[t][i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    // KS=3: wave owns taps wave, wave+4, ... over all rows.  KS=1: all waves own tap 0, rows split.
+    int tapoff[TPW];
+#pragma unroll
+    for (int t = 0; t < TPW; ++t) {
+        int tap = (TAPS > 1) ? wave + 4 * t : 0;
+        if (tap >= TAPS) tap = TAPS - 1;                   // dummy (result discarded)
+        const int dz = tap / (KS * KS), dy = (tap / KS) % KS, dx = tap % KS;
+        tapoff[t] = (dz * G::HY + dy) * G::HX + dx;
+    }
+    const int row0 = (TAPS > 1) ? 0 : wave * RSTEP;
+    const int rowinc = (TAPS > 1) ? RSTEP : 4 * RSTEP;
+
+    const T* x = reinterpret_cast<const T*>(a.x);
+    const T* g = reinterpret_cast<const T*>(w.dout);
+
+    for (int tile = pidx; tile < w.ntiles; tile += w.P) {
+        int b = tile;
+        const int tx = b % a.ntx; b /= a.ntx;
+        const int ty = b % a.nty; b /= a.nty;
+        const int tz = b % a.ntz; b /= a.ntz;
+        const int n = b;
+        const int oz0 = tz * TZ, oy0 = ty * TY, ox0 = tx * 16;
+        __syncthreads();
+        stage_halo<T, G, UPS, 128>(lds_in, x, a, n, oz0, oy0, ox0, kb, tid);
+        stage_dout<T, G>(lds_do, g, a, n, oz0, oy0, ox0, cb, w.dout_stride, tid);
+        __syncthreads();
+        for (int r = row0; r < G::ROWS; r += rowinc) {
+            const int r1 = r + RSTEP - 1;
+            const int o0 = r * 16, o1 = r1 * 16;
+            const int i0 = ((r / TY) * STRIDE * G::HY + (r % TY) * STRIDE) * G::HX;
+            const int i1 = ((r1 / TY) * STRIDE * G::HY + (r1 % TY) * STRIDE) * G::HX;
+            uint4 af[NT];
+#pragma unroll
+            for (int i = 0; i < NT; ++i) af[i] = TrFetch<T, G::OPLANE>::get(lds_do, i, o0, o1, 1, lane);
+#pragma unroll
+            for (int t = 0; t < TPW; ++t) {
+                uint4 bf[NT];
+#pragma unroll
+                for (int j = 0; j < NT; ++j)
+                    bf[j] = TrFetch<T, G::PLANE>::get(lds_in, j, i0 + tapoff[t], i1 + tapoff[t], STRIDE, lane);
+#pragma unroll
+                for (int i = 0; i < NT; ++i)
+#pragma unroll
+                    for (int j = 0; j < NT; ++j) mma16<T>(acc[t][i][j], af[i], bf[j]);
+            }
+        }
+    }
+
+    // ---- write this wave's partial tiles: slab[tap][co_local][ci_local] ------------------------
+    constexpr int CL = NT * 16;                               // channels per 64-B block
+    constexpr int SLAB = TAPS * CL * CL;
+    const int nslab_per_wg = (TAPS > 1) ? 1 : 4;
+    float* slab = w.slabs + ((size_t)(pair * w.P + pidx) * nslab_per_wg + ((TAPS > 1) ? 0 : wave)) * SLAB;
+    const int gq = lane >> 4, col = lane & 15;
+#pragma unroll
+    for (int t = 0; t < TPW; ++t) {
+        const int tap = (TAPS > 1) ? wave + 4 * t : 0;
+        if (tap >= TAPS) continue;
+#pragma unroll
+        for (int i = 0; i < NT; ++i)
+#pragma unroll
+            for (int j = 0; j < NT; ++j)
+#pragma unroll
+                for (int rg = 0; rg < 4; ++rg)
+                    slab[(tap * CL + i * 16 + gq * 4 + rg) * CL + j * 16 + col] = acc[t][i][j][rg];
+    }
+}
+
+// dw[tap][co][ci] (+)= sum over slabs
+__global__ void wgrad_reduce_kernel(const float* __restrict__ slabs, float* __restrict__ dw, int taps, int cout, int cin,
+                                    int ncb, int nkb, int CL, int nslabs, int accumulate) {
+    const int total = taps * cout * cin;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+        const int ci = i % cin, co = (i / cin) % cout, tap = i / (cin * cout);
+        const int cb = co / CL, kb = ci / CL;
+        const int pair = cb * nkb + kb;
+        const size_t slab_elems = (size_t)taps * CL * CL;
+        const float* s = slabs + (size_t)pair * nslabs * slab_elems + ((size_t)tap * CL + co % CL) * CL + ci % CL;
+        float sum = 0.f;
+        for (int k = 0; k < nslabs; ++k) sum += s[(size_t)k * slab_elems];
+        dw[i] = accumulate ? dw[i] + sum : sum;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// weight packing: master fp32 [taps][cout][cin] -> MFMA A-fragment order
+//   packed[chunk][kb][tap][ct][lane][EPL]: lane (m = lane&15, q = lane>>4), element j:
+//     out channel o = chunk*NC*16 + NC*4*(m>>2) + 4*ct + (m&3) ; reduction channel k = kb*KB + q*EPL + j
+//   fwd  : W[tap][o][k]                       dgrad: W[flip(tap)][k][o]  (o indexes cin, k indexes cout)
+// ---------------------------------------------------------------------------------------------
+template <typename T>
+__global__ void pack_weights_kernel(const float* __restrict__ w, T* __restrict__ p, int taps, int cout_m, int cin_m,
+                                    int nc, int nchunks, int nkb, int dgrad) {
+    constexpr int EPL = DT<T>::EPL, KB = DT<T>::KB;
+    const size_t total = (size_t)nchunks * nkb * taps * nc * 64 * EPL;
+    const int O = dgrad ? cin_m : cout_m, K = dgrad ? cout_m : cin_m;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        size_t r = i;
+        const int j = r % EPL; r /= EPL;
+        const int lane = r % 64; r /= 64;
+        const int ct = r % nc; r /= nc;
+        const int tap = r % taps; r /= taps;
+        const int kb = r % nkb; r /= nkb;
+        const int chunk = (int)r;
+        const int m = lane & 15, q = lane >> 4;
+        const int o = chunk * nc * 16 + nc * 4 * (m >> 2) + 4 * ct + (m & 3);
+        const int k = kb * KB + q * EPL + j;
+        float v = 0.f;
+        if (o < O && k < K) {
+            if (dgrad)
+                v = w[((size_t)(taps - 1 - tap) * cout_m + k) * cin_m + o];
+            else
+                v = w[((size_t)tap * cout_m + o) * cin_m + k];
+        }
+        st_elem<T>(p + i, v);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// host side
+// ---------------------------------------------------------------------------------------------
+static int nc_for(int cout) { return cout <= 16 ? 1 : (cout <= 32 ? 2 : 4); }
+static int epl_of(int dtype) { return dtype == VDM_F32 ? 4 : 8; }
+static int kb_of(int dtype) { return dtype == VDM_F32 ? 16 : 32; }
+static int cpad(int c, int dtype) { const int e = epl_of(dtype); return (c + e - 1) / e * e; }
+
+static int validate(const vdm_conv_desc* d) {
+    VDM_REQUIRE(d != nullptr, "conv desc is NULL");
+    VDM_REQUIRE(d->n > 0 && d->od > 0 && d->oh > 0 && d->ow > 0, "conv: bad output dims %d %d %d %d", d->n, d->od, d->oh, d->ow);
+    VDM_REQUIRE(d->cin > 0 && d->cout > 0, "conv: bad channels cin=%d cout=%d", d->cin, d->cout);
+    VDM_REQUIRE(d->ksize == 1 || d->ksize == 3, "conv: ksize must be 1 or 3 (got %d)", d->ksize);
+    VDM_REQUIRE(d->stride == 1 || d->stride == 2, "conv: stride must be 1 or 2 (got %d)", d->stride);
+    VDM_REQUIRE(!(d->stride == 2 && d->ksize != 3), "conv: stride 2 needs ksize 3");
+    VDM_REQUIRE(!(d->upsample && (d->stride != 1 || d->ksize != 3)), "conv: upsample needs stride 1, ksize 3");
+    VDM_REQUIRE(!(d->upsample && ((d->od | d->oh | d->ow) & 1)), "conv: upsample needs even output dims");
+    VDM_REQUIRE(d->dtype == VDM_F32 || d->dtype == VDM_BF16, "conv: bad dtype %d", d->dtype);
+    VDM_REQUIRE(d->pad_mode == VDM_PAD_ZEROS || d->pad_mode == VDM_PAD_CIRCULAR, "conv: bad pad_mode %d", d->pad_mode);
+    return VDM_OK;
+}
+
+struct Plan {           // derived launch parameters of one conv in one direction
+    int taps, nc, nchunks, nkb, O, K;
+};
+static Plan plan_of(const vdm_conv_desc* d, int dgrad) {
+    Plan p;
+    p.taps = d->ksize * d->ksize * d->ksize;
+    p.O = dgrad ? d->cin : d->cout;
+    p.K = dgrad ? d->cout : d->cin;
+    p.nc = nc_for(p.O);
+    p.nchunks = cdiv(p.O, p.nc * 16);
+    p.nkb = cdiv(p.K, kb_of(d->dtype));
+    return p;
+}
+
+template <typename K>
+static int set_lds(K kernel, size_t bytes) {
+    return check_hip(hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes),
+                     "hipFuncSetAttribute(MaxDynamicSharedMemorySize)");
+}
+
+template <typename T, typename TO, int KS, int STRIDE, int UPS, int NC, int TZ, int TY>
+static int launch_fwd_cfg(const ConvArgs& a0, hipStream_t s) {
+    using G = Geo<KS, STRIDE, TZ, TY>;
+    ConvArgs a = a0;
+    a.ntz = cdiv(a.Dz, TZ); a.nty = cdiv(a.Dy, TY); a.ntx = cdiv(a.Dx, 16);
+    const size_t lds = 4 * (size_t)G::PLANE;
+    auto kern = conv_fwd_kernel<T, TO, KS, STRIDE, UPS, NC, TZ, TY>;
+    static bool attr_done = false;
+    if (!attr_done) {
+        int e = set_lds(kern, lds);
+        if (e) return e;
+        attr_done = true;
+    }
+    const long long nwg = (long long)a.N * a.ntz * a.nty * a.ntx * a.nchunks;
+    if (nwg > 0x7fffffffLL) { set_error("conv: grid too large"); return VDM_ERR_ARG; }
+    hipLaunchKernelGGL(kern, dim3((unsigned)nwg), dim3(256), lds, s, a);
+    VDM_LAUNCH_CHECK("conv_fwd_kernel");
+    return VDM_OK;
+}
+
+template <typename T, typename TO, int KS, int STRIDE, int UPS, int NC>
+static int launch_fwd_geo(const ConvArgs& a, hipStream_t s) {
+    if constexpr (STRIDE == 2)
+        return launch_fwd_cfg<T, TO, KS, STRIDE, UPS, NC, 2, 4>(a, s);
+    else
+        return launch_fwd_cfg<T, TO, KS, STRIDE, UPS, NC, 4, 8>(a, s);
+}
+
+template <typename T, typename TO, int KS, int STRIDE, int UPS>
+static int launch_fwd_nc(const ConvArgs& a, int nc, hipStream_t s) {
+    switch (nc) {
+        case 1: return launch_fwd_geo<T, TO, KS, STRIDE, UPS, 1>(a, s);
+        case 2: return launch_fwd_geo<T, TO, KS, STRIDE, UPS, 2>(a, s);
+        default: return launch_fwd_geo<T, TO, KS, STRIDE, UPS, 4>(a, s);
+    }
+}
+
+template <typename T, typename TO>
+static int launch_fwd_variant(const ConvArgs& a, int ks, int stride, int ups, int nc, hipStream_t s) {
+    if (ks == 1) return launch_fwd_nc<T, TO, 1, 1, 0>(a, nc, s);
+    if (stride == 2) return launch_fwd_nc<T, TO, 3, 2, 0>(a, nc, s);
+    if (ups) return launch_fwd_nc<T, TO, 3, 1, 1>(a, nc, s);
+    return launch_fwd_nc<T, TO, 3, 1, 0>(a, nc, s);
+}
+
+static int launch_fwd(const ConvArgs& a, int dtype, int out_f32, int ks, int stride, int ups, int nc, hipStream_t s) {
+    if (dtype == VDM_F32) return launch_fwd_variant<float, float>(a, ks, stride, ups, nc, s);
+    if (out_f32) {
+        if (!(ks == 3 && stride == 1 && !ups && nc == 1)) {
+            set_error("conv: out_f32 with bf16 input is only built for ksize 3, stride 1, cout <= 16");
+            return VDM_ERR_UNSUPPORTED;
+        }
+        return launch_fwd_geo<bf16_t, float, 3, 1, 0, 1>(a, s);
+    }
+    return launch_fwd_variant<bf16_t, bf16_t>(a, ks, stride, ups, nc, s);
+}
+
+template <typename T, int KS, int STRIDE, int UPS, int TZ, int TY>
+static int launch_wgrad_cfg(WgradArgs w, float* dw, int accumulate, int cout, int cin, size_t ws_bytes, hipStream_t s) {
+    using G = Geo<KS, STRIDE, TZ, TY>;
+    constexpr int CL = WG<T>::NT * 16;
+    ConvArgs& a = w.c;
+    a.ntz = cdiv(a.Dz, TZ); a.nty = cdiv(a.Dy, TY); a.ntx = cdiv(a.Dx, 16);
+    w.ntiles = a.N * a.ntz * a.nty * a.ntx;
+    const int npairs = w.ncb * w.nkb;
+    int P = 256 / npairs;
+    if (P < 1) P = 1;
+    if (P > w.ntiles) P = w.ntiles;
+    w.P = P;
+    const int per_wg = (G::TAPS > 1) ? 1 : 4;
+    const size_t need = (size_t)npairs * P * per_wg * G::TAPS * CL * CL * sizeof(float);
+    if (need > ws_bytes) { set_error("conv_wgrad: workspace too small (%zu < %zu)", ws_bytes, need); return VDM_ERR_ARG; }
+    const size_t lds = 4 * (size_t)G::PLANE + 128 + 4 * (size_t)G::OPLANE + 128;
+    auto kern = conv_wgrad_kernel<T, KS, STRIDE, UPS, TZ, TY>;
+    static bool attr_done = false;
+    if (!attr_done) {
+        int e = set_lds(kern, lds);
+        if (e) return e;
+        attr_done = true;
+    }
+    hipLaunchKernelGGL(kern, dim3(npairs * P), dim3(256), lds, s, w);
+    VDM_LAUNCH_CHECK("conv_wgrad_kernel");
+    const int total = G::TAPS * cout * cin;
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(cdiv(total, 256) < 1024 ? cdiv(total, 256) : 1024), dim3(256), 0, s,
+                       (const float*)w.slabs, dw, G::TAPS, cout, cin, w.ncb, w.nkb, CL, P * per_wg, accumulate);
+    VDM_LAUNCH_CHECK("wgrad_reduce_kernel");
+    return VDM_OK;
+}
+
+template <typename T>
+static int launch_wgrad(const WgradArgs& w, float* dw, int acc, int cout, int cin, int ks, int stride, int ups, size_t ws,
+                        hipStream_t s) {
+    if (ks == 1) return launch_wgrad_cfg<T, 1, 1, 0, 4, 8>(w, dw, acc, cout, cin, ws, s);
+    if (stride == 2) return launch_wgrad_cfg<T, 3, 2, 0, 2, 4>(w, dw, acc, cout, cin, ws, s);
+    if (ups) return launch_wgrad_cfg<T, 3, 1, 1, 4, 8>(w, dw, acc, cout, cin, ws, s);
+    return launch_wgrad_cfg<T, 3, 1, 0, 4, 8>(w, dw, acc, cout, cin, ws, s);
+}
+
+static void fill_dims(ConvArgs& a, const vdm_conv_desc* d) {
+    a.N = d->n; a.Dz = d->od; a.Dy = d->oh; a.Dx = d->ow;
+    a.Iz = d->od * d->stride; a.Iy = d->oh * d->stride; a.Ix = d->ow * d->stride;
+    a.Sz = d->upsample ? a.Iz / 2 : a.Iz; a.Sy = d->upsample ? a.Iy / 2 : a.Iy; a.Sx = d->upsample ? a.Ix / 2 : a.Ix;
+    a.circular = d->pad_mode == VDM_PAD_CIRCULAR;
+}
+
+}  // namespace vdm
+
+using namespace vdm;
+
+extern "C" size_t vdm_conv_packed_bytes(const vdm_conv_desc* d, int pack_mode) {
+    if (validate(d) != VDM_OK) return 0;
+    const Plan p = plan_of(d, pack_mode == VDM_PACK_DGRAD);
+    return (size_t)p.nchunks * p.nkb * p.taps * p.nc * 64 * 16;
+}
+
+extern "C" int vdm_conv_pack_weights(const vdm_conv_desc* d, int pack_mode, const float* w_master, void* w_packed, void* stream) {
+    int e = validate(d);
+    if (e) return e;
+    VDM_REQUIRE(w_master && w_packed, "conv_pack_weights: NULL pointer");
+    VDM_REQUIRE(pack_mode == VDM_PACK_FWD || pack_mode == VDM_PACK_DGRAD, "conv_pack_weights: bad mode %d", pack_mode);
+    const int dg = pack_mode == VDM_PACK_DGRAD;
+    const Plan p = plan_of(d, dg);
+    const size_t elems = vdm_conv_packed_bytes(d, pack_mode) / (d->dtype == VDM_F32 ? 4 : 2);
+    const unsigned grid = (unsigned)((elems + 255) / 256 < 2048 ? (elems + 255) / 256 : 2048);
+    hipStream_t s = (hipStream_t)stream;
+    if (d->dtype == VDM_F32)
+        hipLaunchKernelGGL(pack_weights_kernel<float>, dim3(grid), dim3(256), 0, s, w_master, (float*)w_packed, p.taps, d->cout, d->cin,
+                           p.nc, p.nchunks, p.nkb, dg);
+    else
+        hipLaunchKernelGGL(pack_weights_kernel<bf16_t>, dim3(grid), dim3(256), 0, s, w_master, (bf16_t*)w_packed, p.taps, d->cout,
+                           d->cin, p.nc, p.nchunks, p.nkb, dg);
+    VDM_LAUNCH_CHECK("pack_weights_kernel");
+    return VDM_OK;
+}
+
+extern "C" int vdm_conv_fwd(const vdm_conv_desc* d, const void* x, const void* w_packed, const float* bias, const float* nbias,
+                            const void* residual, void* out, void* stream) {
+    int e = validate(d);
+    if (e) return e;
+    VDM_REQUIRE(x && w_packed && out, "conv_fwd: NULL pointer");
+    const Plan p = plan_of(d, 0);
+    ConvArgs a{};
+    a.x = x; a.w = w_packed; a.bias = bias; a.nbias = nbias; a.res = residual; a.out = out;
+    fill_dims(a, d);
+    a.Cin = d->cin; a.CinStride = cpad(d->cin, d->dtype); a.Cout = d->cout;
+    a.nchunks = p.nchunks; a.nkb = p.nkb;
+    return launch_fwd(a, d->dtype, d->out_f32, d->ksize, d->stride, d->upsample, p.nc, (hipStream_t)stream);
+}
+
+extern "C" int vdm_conv_dgrad(const vdm_conv_desc* d, const void* dout, const void* w_packed_dgrad, void* dx, void* stream) {
+    int e = validate(d);
+    if (e) return e;
+    VDM_REQUIRE(dout && w_packed_dgrad && dx, "conv_dgrad: NULL pointer");
+    VDM_REQUIRE(d->stride == 1, "conv_dgrad: stride-2 convs are differentiated via vdm_dilate2 + a stride-1 dgrad");
+    const Plan p = plan_of(d, 1);
+    ConvArgs a{};
+    a.x = dout; a.w = w_packed_dgrad; a.out = dx;
+    a.N = d->n; a.Dz = d->od; a.Dy = d->oh; a.Dx = d->ow;
+    a.Iz = a.Sz = d->od; a.Iy = a.Sy = d->oh; a.Ix = a.Sx = d->ow;       // dgrad runs on the output grid
+    a.circular = d->pad_mode == VDM_PAD_CIRCULAR;
+    a.Cin = d->cout; a.CinStride = cpad(d->cout, d->dtype); a.Cout = d->cin;
+    a.nchunks = p.nchunks; a.nkb = p.nkb;
+    return launch_fwd(a, d->dtype, 0, d->ksize, 1, 0, p.nc, (hipStream_t)stream);
+}
+
+extern "C" size_t vdm_conv_wgrad_workspace_bytes(const vdm_conv_desc* d) {
+    if (validate(d) != VDM_OK) return 0;
+    const int CL = d->dtype == VDM_F32 ? 16 : 32;
+    const int taps = d->ksize * d->ksize * d->ksize;
+    const int npairs = cdiv(d->cout, CL) * cdiv(d->cin, CL);
+    int P = 256 / npairs;
+    if (P < 1) P = 1;
+    return (size_t)npairs * P * (taps > 1 ? 1 : 4) * taps * CL * CL * sizeof(float);
+}
+
+extern "C" int vdm_conv_wgrad(const vdm_conv_desc* d, const void* x, const void* dout, float* dw, int accumulate, void* workspace,
+                              size_t workspace_bytes, void* stream) {
+    int e = validate(d);
+    if (e) return e;
+    VDM_REQUIRE(x && dout && dw && workspace, "conv_wgrad: NULL pointer");
+    const int CL = d->dtype == VDM_F32 ? 16 : 32;
+    WgradArgs w{};
+    fill_dims(w.c, d);
+    w.c.x = x;
+    w.c.Cin = d->cin; w.c.CinStride = cpad(d->cin, d->dtype); w.c.Cout = d->cout;
+    w.dout = dout; w.dout_stride = cpad(d->cout, d->dtype);
+    w.slabs = (float*)workspace;
+    w.ncb = cdiv(d->cout, CL); w.nkb = cdiv(d->cin, CL);
+    hipStream_t s = (hipStream_t)stream;
+    if (d->dtype == VDM_F32)
+        return launch_wgrad<float>(w, dw, accumulate, d->cout, d->cin, d->ksize, d->stride, d->upsample, workspace_bytes, s);
+    return launch_wgrad<bf16_t>(w, dw, accumulate, d->cout, d->cin, d->ksize, d->stride, d->upsample, workspace_bytes, s);
+}

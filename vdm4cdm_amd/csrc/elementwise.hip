@@ -1,0 +1,754 @@
+// elementwise.hip - HBM-bound kernels of the VDM denoising path (K2, K7-K10 of DESIGN.md):
+// GroupNorm statistics, fused GroupNorm-apply+SiLU(+dropout) forward/backward, VDM forward
+// diffusion, ELBO reductions, ancestral update with Philox normals, gradient-norm reduction and
+// the small layout helpers.  All are 16-byte-vectorised NDHWC streams with wave64 shuffle
+// reductions and one float atomic per workgroup per output.
+#include "common.h"
+
+namespace vdm {
+
+static inline unsigned grid_for(int64_t work_items, int per_block) {
+    int64_t g = (work_items + per_block - 1) / per_block;
+    if (g < 1) g = 1;
+    if (g > 2048) g = 2048;          // ~8 blocks/CU; grid-stride the rest
+    return (unsigned)g;
+}
+
+// block-wide sum of NVAL values; result valid in thread 0.  256 threads = 4 waves.
+template <int NVAL>
+__device__ __forceinline__ void block_sum(float (&v)[NVAL], float* smem /* >= 4*NVAL floats */) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int i = 0; i < NVAL; ++i) v[i] = wave_sum(v[i]);
+    __syncthreads();
+    if (lane == 0) {
+#pragma unroll
+        for (int i = 0; i < NVAL; ++i) smem[wave * NVAL + i] = v[i];
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+#pragma unroll
+        for (int i = 0; i < NVAL; ++i) v[i] = smem[i] + smem[NVAL + i] + smem[2 * NVAL + i] + smem[3 * NVAL + i];
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// GroupNorm statistics: stats[n][g] = {sum, sumsq}.  One source tensor [n][V][C] whose groups
+// occupy [g0, g0 + C/gs) of the `G`-group concatenated tensor.
+// Work split: thread t owns piece column pc = t % PPV (16 B of channels), rows t / PPV + k*RPB.
+// ---------------------------------------------------------------------------------------------
+template <typename T>
+__global__ void __launch_bounds__(256) gn_stats_kernel(const T* __restrict__ x, int C, int64_t V, int gs, int G, int g0,
+                                                      float* __restrict__ stats, int blocks_per_n) {
+    constexpr int EPL = DT<T>::EPL;
+    const int n = blockIdx.x / blocks_per_n, bn = blockIdx.x % blocks_per_n;
+    const int PPV = C / EPL;                       // pieces per voxel
+    const int64_t npieces = V * PPV;
+    const uint4* xp = reinterpret_cast<const uint4*>(x + (size_t)n * V * C);
+    // a thread's channel piece is fixed when the stride is a multiple of PPV
+    const int64_t stride = (int64_t)blocks_per_n * 256;
+    // fast path: stride % PPV == 0 -> the piece column of a thread never changes
+    float s[EPL], ss[EPL];
+#pragma unroll
+    for (int j = 0; j < EPL; ++j) s[j] = ss[j] = 0.f;
+    const int64_t start = (int64_t)bn * 256 + threadIdx.x;
+    const int pc = (int)(start % PPV);
+    for (int64_t i = start; i < npieces; i += stride) {
+        Piece<T> p;
+        p.load(xp[i]);
+#pragma unroll
+        for (int j = 0; j < EPL; ++j) { s[j] += p.f[j]; ss[j] += p.f[j] * p.f[j]; }
+    }
+    // fold the EPL channels of the piece into groups; groups of a piece: (pc*EPL + j) / gs
+    __shared__ float sh[2 * 64];                   // up to 64 groups
+    for (int i = threadIdx.x; i < 2 * G; i += 256) sh[i] = 0.f;
+    __syncthreads();
+    if (gs >= EPL) {                               // whole piece in one group
+        float a = 0.f, b = 0.f;
+#pragma unroll
+        for (int j = 0; j < EPL; ++j) { a += s[j]; b += ss[j]; }
+        const int g = g0 + (pc * EPL) / gs;
+        atomicAdd(&sh[2 * g], a);
+        atomicAdd(&sh[2 * g + 1], b);
+    } else {
+#pragma unroll
+        for (int j = 0; j < EPL; ++j) {
+            const int g = g0 + (pc * EPL + j) / gs;
+            atomicAdd(&sh[2 * g], s[j]);
+            atomicAdd(&sh[2 * g + 1], ss[j]);
+        }
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < 2 * G; i += 256)
+        if (sh[i] != 0.f) atomicAdd(&stats[(size_t)n * 2 * G + i], sh[i]);
+}
+
+// per-(n, channel) affine of GN: y = x * A + B with A = rstd*gamma, B = beta - mean*rstd*gamma
+__device__ __forceinline__ void gn_affine(const float* __restrict__ stats, int n, int G, int g, float cnt, float eps, float gamma,
+                                          float beta, float& A, float& B, float& mean, float& rstd) {
+    const float sum = stats[((size_t)n * G + g) * 2], sq = stats[((size_t)n * G + g) * 2 + 1];
+    mean = sum / cnt;
+    const float var = fmaxf(sq / cnt - mean * mean, 0.f);
+    rstd = rsqrtf(var + eps);
+    A = rstd * gamma;
+    B = beta - mean * A;
+}
+
+// ---------------------------------------------------------------------------------------------
+// y[n][v][c1+c2] = dropout(silu(gn(concat(x1,x2))))
+// ---------------------------------------------------------------------------------------------
+struct GnArgs {
+    const void* x1; const void* x2;
+    int c1, c2, n, G;
+    int64_t V;
+    const float* stats; const float* gamma; const float* beta;
+    float eps, p;
+    uint64_t seed;
+    void* y;                 // fwd out
+    const void* dy; const void* add; void* dx1; void* dx2;       // bwd
+    float* dgamma; float* dbeta; float* colsum; float* red;
+    int blocks_per_n;
+};
+
+template <typename T>
+__global__ void __launch_bounds__(256) gn_silu_fwd_kernel(const GnArgs a) {
+    constexpr int EPL = DT<T>::EPL;
+    const int C = a.c1 + a.c2, gs = C / a.G, PPV = C / EPL, P1 = a.c1 / EPL;
+    const int n = blockIdx.x / a.blocks_per_n, bn = blockIdx.x % a.blocks_per_n;
+    const int64_t npieces = a.V * PPV;
+    const int64_t stride = (int64_t)a.blocks_per_n * 256;       // multiple of PPV (blocks_per_sample)
+    const float cnt = (float)a.V * gs;
+    const T* x1 = reinterpret_cast<const T*>(a.x1) + (size_t)n * a.V * a.c1;
+    const T* x2 = a.x2 ? reinterpret_cast<const T*>(a.x2) + (size_t)n * a.V * a.c2 : nullptr;
+    T* y = reinterpret_cast<T*>(a.y) + (size_t)n * a.V * C;
+    const bool drop = a.p > 0.f;
+    const float inv_keep = drop ? 1.f / (1.f - a.p) : 1.f;
+    const int64_t start = (int64_t)bn * 256 + threadIdx.x;
+    const int pc = (int)(start % PPV);                          // fixed piece column of this thread
+    float A[EPL], B[EPL];
+#pragma unroll
+    for (int j = 0; j < EPL; ++j) {
+        const int c = pc * EPL + j;
+        float mean, rstd;
+        gn_affine(a.stats, n, a.G, c / gs, cnt, a.eps, a.gamma[c], a.beta[c], A[j], B[j], mean, rstd);
+    }
+    for (int64_t i = start; i < npieces; i += stride) {
+        const int64_t v = i / PPV;
+        const uint4 raw = pc < P1 ? *reinterpret_cast<const uint4*>(x1 + v * a.c1 + pc * EPL)
+                                  : *reinterpret_cast<const uint4*>(x2 + v * a.c2 + (pc - P1) * EPL);
+        Piece<T> p;
+        p.load(raw);
+        uint32_t rnd[4];
+#pragma unroll
+        for (int j = 0; j < EPL; ++j) {
+            float o = silu_f(p.f[j] * A[j] + B[j]);
+            if (drop) {
+                if ((j & 3) == 0) {
+                    const uint64_t e4 = ((uint64_t)n * a.V * C + (uint64_t)i * EPL + j) >> 2;
+                    Philox::gen((uint32_t)e4, (uint32_t)(e4 >> 32), 0x5eedu, 0u, (uint32_t)a.seed, (uint32_t)(a.seed >> 32), rnd);
+                }
+                o *= u32_to_unit(rnd[j & 3]) > a.p ? inv_keep : 0.f;
+            }
+            p.f[j] = o;
+        }
+        *reinterpret_cast<uint4*>(y + i * EPL) = p.store();
+    }
+}
+
+// d(silu(y))/dy
+__device__ __forceinline__ float dsilu(float y) {
+    const float s = sigmoid_f(y);
+    return s * (1.f + y * (1.f - s));
+}
+
+// pass 1: red[n][g] = {sum gamma*dyh, sum gamma*dyh*xhat};  dgamma[c] += sum dyh*xhat; dbeta[c] += sum dyh
+// where dyh = dy * keep * silu'(yhat).  Thread owns a fixed piece column (stride % PPV == 0 by construction).
+template <typename T>
+__global__ void __launch_bounds__(256) gn_silu_bwd_reduce_kernel(const GnArgs a) {
+    constexpr int EPL = DT<T>::EPL;
+    const int C = a.c1 + a.c2, gs = C / a.G, PPV = C / EPL, P1 = a.c1 / EPL;
+    const int n = blockIdx.x / a.blocks_per_n, bn = blockIdx.x % a.blocks_per_n;
+    const int64_t npieces = a.V * PPV;
+    const int64_t stride = (int64_t)a.blocks_per_n * 256;
+    const float cnt = (float)a.V * gs;
+    const T* x1 = reinterpret_cast<const T*>(a.x1) + (size_t)n * a.V * a.c1;
+    const T* x2 = a.x2 ? reinterpret_cast<const T*>(a.x2) + (size_t)n * a.V * a.c2 : nullptr;
+    const T* dy = reinterpret_cast<const T*>(a.dy) + (size_t)n * a.V * C;
+    const bool drop = a.p > 0.f;
+    const float inv_keep = drop ? 1.f / (1.f - a.p) : 1.f;
+    const int64_t start = (int64_t)bn * 256 + threadIdx.x;
+    const int pc = (int)(start % PPV);
+    float A[EPL], B[EPL], mean[EPL], rstd[EPL], gam[EPL];
+#pragma unroll
+    for (int j = 0; j < EPL; ++j) {
+        const int c = pc * EPL + j;
+        gam[j] = a.gamma[c];
+        gn_affine(a.stats, n, a.G, c / gs, cnt, a.eps, gam[j], a.beta[c], A[j], B[j], mean[j], rstd[j]);
+    }
+    float sdy[EPL], sdyx[EPL];
+#pragma unroll
+    for (int j = 0; j < EPL; ++j) sdy[j] = sdyx[j] = 0.f;
+    for (int64_t i = start; i < npieces; i += stride) {
+        const int64_t v = i / PPV;
+        const uint4 raw = pc < P1 ? *reinterpret_cast<const uint4*>(x1 + v * a.c1 + pc * EPL)
+                                  : *reinterpret_cast<const uint4*>(x2 + v * a.c2 + (pc - P1) * EPL);
+        Piece<T> px, pd;
+        px.load(raw);
+        pd.load(*reinterpret_cast<const uint4*>(dy + i * EPL));
+        uint32_t rnd[4];
+#pragma unroll
+        for (int j = 0; j < EPL; ++j) {
+            float d = pd.f[j] * dsilu(px.f[j] * A[j] + B[j]);
+            if (drop) {
+                if ((j & 3) == 0) {
+                    const uint64_t e4 = ((uint64_t)n * a.V * C + (uint64_t)i * EPL + j) >> 2;
+                    Philox::gen((uint32_t)e4, (uint32_t)(e4 >> 32), 0x5eedu, 0u, (uint32_t)a.seed, (uint32_t)(a.seed >> 32), rnd);
+                }
+                d *= u32_to_unit(rnd[j & 3]) > a.p ? inv_keep : 0.f;
+            }
+            sdy[j] += d;
+            sdyx[j] += d * (px.f[j] - mean[j]) * rstd[j];
+        }
+    }
+    // block-level accumulation in LDS: per channel (C <= 512) and per group
+    __shared__ float shc[2 * 512];
+    __shared__ float shg[2 * 64];
+    for (int i = threadIdx.x; i < 2 * C; i += 256) shc[i] = 0.f;
+    for (int i = threadIdx.x; i < 2 * a.G; i += 256) shg[i] = 0.f;
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < EPL; ++j) {
+        const int c = pc * EPL + j;
+        atomicAdd(&shc[2 * c], sdy[j]);
+        atomicAdd(&shc[2 * c + 1], sdyx[j]);
+        atomicAdd(&shg[2 * (c / gs)], gam[j] * sdy[j]);
+        atomicAdd(&shg[2 * (c / gs) + 1], gam[j] * sdyx[j]);
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < C; i += 256) {
+        atomicAdd(&a.dbeta[i], shc[2 * i]);
+        atomicAdd(&a.dgamma[i], shc[2 * i + 1]);
+    }
+    for (int i = threadIdx.x; i < 2 * a.G; i += 256) atomicAdd(&a.red[(size_t)n * 2 * a.G + i], shg[i]);
+}
+
+// pass 2: dx = rstd * (gamma*dyh - m1 - xhat*m2) (+ add), m1 = red0/cnt, m2 = red1/cnt ; colsum[n][c] += sum_v dx
+template <typename T>
+__global__ void __launch_bounds__(256) gn_silu_bwd_apply_kernel(const GnArgs a) {
+    constexpr int EPL = DT<T>::EPL;
+    const int C = a.c1 + a.c2, gs = C / a.G, PPV = C / EPL, P1 = a.c1 / EPL;
+    const int n = blockIdx.x / a.blocks_per_n, bn = blockIdx.x % a.blocks_per_n;
+    const int64_t npieces = a.V * PPV;
+    const int64_t stride = (int64_t)a.blocks_per_n * 256;
+    const float cnt = (float)a.V * gs;
+    const T* x1 = reinterpret_cast<const T*>(a.x1) + (size_t)n * a.V * a.c1;
+    const T* x2 = a.x2 ? reinterpret_cast<const T*>(a.x2) + (size_t)n * a.V * a.c2 : nullptr;
+    const T* dy = reinterpret_cast<const T*>(a.dy) + (size_t)n * a.V * C;
+    const T* add = a.add ? reinterpret_cast<const T*>(a.add) + (size_t)n * a.V * C : nullptr;
+    T* dx1 = reinterpret_cast<T*>(a.dx1) + (size_t)n * a.V * a.c1;
+    T* dx2 = a.dx2 ? reinterpret_cast<T*>(a.dx2) + (size_t)n * a.V * a.c2 : nullptr;
+    const bool drop = a.p > 0.f;
+    const float inv_keep = drop ? 1.f / (1.f - a.p) : 1.f;
+    const int64_t start = (int64_t)bn * 256 + threadIdx.x;
+    const int pc = (int)(start % PPV);
+    float A[EPL], B[EPL], mean[EPL], rstd[EPL], gam[EPL], m1[EPL], m2[EPL], cs[EPL];
+#pragma unroll
+    for (int j = 0; j < EPL; ++j) {
+        const int c = pc * EPL + j, g = c / gs;
+        gam[j] = a.gamma[c];
+        gn_affine(a.stats, n, a.G, g, cnt, a.eps, gam[j], a.beta[c], A[j], B[j], mean[j], rstd[j]);
+        m1[j] = a.red[((size_t)n * a.G + g) * 2] / cnt;
+        m2[j] = a.red[((size_t)n * a.G + g) * 2 + 1] / cnt;
+        cs[j] = 0.f;
+    }
+    for (int64_t i = start; i < npieces; i += stride) {
+        const int64_t v = i / PPV;
+        const uint4 raw = pc < P1 ? *reinterpret_cast<const uint4*>(x1 + v * a.c1 + pc * EPL)
+                                  : *reinterpret_cast<const uint4*>(x2 + v * a.c2 + (pc - P1) * EPL);
+        Piece<T> px, pd, pa;
+        px.load(raw);
+        pd.load(*reinterpret_cast<const uint4*>(dy + i * EPL));
+        if (add) pa.load(*reinterpret_cast<const uint4*>(add + i * EPL));
+        uint32_t rnd[4];
+#pragma unroll
+        for (int j = 0; j < EPL; ++j) {
+            float d = pd.f[j] * dsilu(px.f[j] * A[j] + B[j]);
+            if (drop) {
+                if ((j & 3) == 0) {
+                    const uint64_t e4 = ((uint64_t)n * a.V * C + (uint64_t)i * EPL + j) >> 2;
+                    Philox::gen((uint32_t)e4, (uint32_t)(e4 >> 32), 0x5eedu, 0u, (uint32_t)a.seed, (uint32_t)(a.seed >> 32), rnd);
+                }
+                d *= u32_to_unit(rnd[j & 3]) > a.p ? inv_keep : 0.f;
+            }
+            const float xh = (px.f[j] - mean[j]) * rstd[j];
+            float o = rstd[j] * (gam[j] * d - m1[j] - xh * m2[j]);
+            if (add) o += pa.f[j];
+            px.f[j] = o;
+            cs[j] += o;
+        }
+        if (pc < P1)
+            *reinterpret_cast<uint4*>(dx1 + v * a.c1 + pc * EPL) = px.store();
+        else
+            *reinterpret_cast<uint4*>(dx2 + v * a.c2 + (pc - P1) * EPL) = px.store();
+    }
+    if (a.colsum) {
+        __shared__ float shc[512];
+        for (int i = threadIdx.x; i < C; i += 256) shc[i] = 0.f;
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < EPL; ++j) atomicAdd(&shc[pc * EPL + j], cs[j]);
+        __syncthreads();
+        for (int i = threadIdx.x; i < C; i += 256) atomicAdd(&a.colsum[(size_t)n * C + i], shc[i]);
+    }
+}
+
+// out[n][c] += sum_v x[n][v][c]
+template <typename T>
+__global__ void __launch_bounds__(256) colsum_kernel(const T* __restrict__ x, int C, int64_t V, float* __restrict__ out,
+                                                    int blocks_per_n) {
+    constexpr int EPL = DT<T>::EPL;
+    const int PPV = C / EPL;
+    const int n = blockIdx.x / blocks_per_n, bn = blockIdx.x % blocks_per_n;
+    const int64_t npieces = V * PPV, stride = (int64_t)blocks_per_n * 256;
+    const uint4* xp = reinterpret_cast<const uint4*>(x + (size_t)n * V * C);
+    const int64_t start = (int64_t)bn * 256 + threadIdx.x;
+    const int pc = (int)(start % PPV);
+    float s[EPL];
+#pragma unroll
+    for (int j = 0; j < EPL; ++j) s[j] = 0.f;
+    for (int64_t i = start; i < npieces; i += stride) {
+        Piece<T> p;
+        p.load(xp[i]);
+#pragma unroll
+        for (int j = 0; j < EPL; ++j) s[j] += p.f[j];
+    }
+    __shared__ float shc[512];
+    for (int i = threadIdx.x; i < C; i += 256) shc[i] = 0.f;
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < EPL; ++j) atomicAdd(&shc[pc * EPL + j], s[j]);
+    __syncthreads();
+    for (int i = threadIdx.x; i < C; i += 256) atomicAdd(&out[(size_t)n * C + i], shc[i]);
+}
+
+// ---------------------------------------------------------------------------------------------
+// dilate2 / pool2_sum (piece granularity)
+// ---------------------------------------------------------------------------------------------
+template <typename T>
+__global__ void __launch_bounds__(256) dilate2_kernel(const T* __restrict__ coarse, T* __restrict__ fine, int N, int cd, int ch,
+                                                     int cw, int C) {
+    constexpr int EPL = DT<T>::EPL;
+    const int PPV = C / EPL;
+    const int fd = 2 * cd, fh = 2 * ch, fw = 2 * cw;
+    const int64_t total = (int64_t)N * fd * fh * fw * PPV;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        int64_t r = i;
+        const int pc = r % PPV; r /= PPV;
+        const int x = r % fw; r /= fw;
+        const int y = r % fh; r /= fh;
+        const int z = r % fd; r /= fd;
+        const int n = (int)r;
+        uint4 v = make_uint4(0, 0, 0, 0);
+        if (((x | y | z) & 1) == 0)
+            v = *reinterpret_cast<const uint4*>(coarse + ((((int64_t)n * cd + (z >> 1)) * ch + (y >> 1)) * cw + (x >> 1)) * C + pc * EPL);
+        *reinterpret_cast<uint4*>(fine + i * EPL) = v;
+    }
+}
+
+template <typename T>
+__global__ void __launch_bounds__(256) pool2_sum_kernel(const T* __restrict__ fine, T* __restrict__ coarse, int N, int cd, int ch,
+                                                       int cw, int C) {
+    constexpr int EPL = DT<T>::EPL;
+    const int PPV = C / EPL;
+    const int fh = 2 * ch, fw = 2 * cw, fd = 2 * cd;
+    const int64_t total = (int64_t)N * cd * ch * cw * PPV;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        int64_t r = i;
+        const int pc = r % PPV; r /= PPV;
+        const int x = r % cw; r /= cw;
+        const int y = r % ch; r /= ch;
+        const int z = r % cd; r /= cd;
+        const int n = (int)r;
+        float s[EPL];
+#pragma unroll
+        for (int j = 0; j < EPL; ++j) s[j] = 0.f;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const int fz = 2 * z + (k >> 2), fy = 2 * y + ((k >> 1) & 1), fx = 2 * x + (k & 1);
+            Piece<T> p;
+            p.load(*reinterpret_cast<const uint4*>(fine + ((((int64_t)n * fd + fz) * fh + fy) * fw + fx) * C + pc * EPL));
+#pragma unroll
+            for (int j = 0; j < EPL; ++j) s[j] += p.f[j];
+        }
+        Piece<T> o;
+#pragma unroll
+        for (int j = 0; j < EPL; ++j) o.f[j] = s[j];
+        *reinterpret_cast<uint4*>(coarse + i * EPL) = o.store();
+    }
+}
+
+template <typename TS, typename TD>
+__global__ void __launch_bounds__(256) cast_kernel(const TS* __restrict__ s, TD* __restrict__ d, int64_t n) {
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) st_elem<TD>(d + i, ld_elem<TS>(s + i));
+}
+
+template <typename T>
+__global__ void __launch_bounds__(256) pack_input_kernel(const float* __restrict__ a, const float* __restrict__ b, int64_t nvox,
+                                                        int cpad, T* __restrict__ out) {
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < nvox; i += (int64_t)gridDim.x * 256) {
+        T* o = out + i * cpad;
+        st_elem<T>(o, a[i]);
+        st_elem<T>(o + 1, b ? b[i] : 0.f);
+        for (int j = 2; j < cpad; ++j) st_elem<T>(o + j, 0.f);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// VDM kernels
+// ---------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) diffuse_kernel(const float* __restrict__ x, const float* __restrict__ eps,
+                                                     const float* __restrict__ alpha, const float* __restrict__ sigma, int64_t per,
+                                                     float* __restrict__ z, int blocks_per_n) {
+    const int n = blockIdx.x / blocks_per_n, bn = blockIdx.x % blocks_per_n;
+    const float al = alpha[n], si = sigma[n];
+    const int64_t n4 = per >> 2;
+    const float4* x4 = reinterpret_cast<const float4*>(x + (size_t)n * per);
+    const float4* e4 = reinterpret_cast<const float4*>(eps + (size_t)n * per);
+    float4* z4 = reinterpret_cast<float4*>(z + (size_t)n * per);
+    for (int64_t i = (int64_t)bn * 256 + threadIdx.x; i < n4; i += (int64_t)blocks_per_n * 256) {
+        const float4 a = x4[i], b = e4[i];
+        z4[i] = make_float4(al * a.x + si * b.x, al * a.y + si * b.y, al * a.z + si * b.z, al * a.w + si * b.w);
+    }
+    if (bn == 0)
+        for (int64_t i = (n4 << 2) + threadIdx.x; i < per; i += 256)
+            z[(size_t)n * per + i] = al * x[(size_t)n * per + i] + si * eps[(size_t)n * per + i];
+}
+
+__global__ void __launch_bounds__(256) loss_terms_kernel(const float* __restrict__ x, const float* __restrict__ eps,
+                                                        const float* __restrict__ eh, const float* __restrict__ eps0, float s0a0,
+                                                        const float* __restrict__ coef, int64_t per, float* __restrict__ sums,
+                                                        float* __restrict__ deh, int blocks_per_n) {
+    const int n = blockIdx.x / blocks_per_n, bn = blockIdx.x % blocks_per_n;
+    const float cf = coef[n];
+    const size_t base = (size_t)n * per;
+    float acc[3] = {0.f, 0.f, 0.f};
+    for (int64_t i = (int64_t)bn * 256 + threadIdx.x; i < per; i += (int64_t)blocks_per_n * 256) {
+        const float xv = x[base + i], e = eps[base + i], h = eh[base + i];
+        const float d = h - e;
+        acc[0] += d * d;
+        acc[1] += xv * xv;
+        const float r = s0a0 * eps0[base + i];       // z0/alpha0 - x
+        acc[2] += r * r;
+        deh[base + i] = cf * d;
+    }
+    __shared__ float sm[12];
+    block_sum<3>(acc, sm);
+    if (threadIdx.x == 0) {
+        atomicAdd(&sums[n * 3 + 0], acc[0]);
+        atomicAdd(&sums[n * 3 + 1], acc[1]);
+        atomicAdd(&sums[n * 3 + 2], acc[2]);
+    }
+}
+
+__device__ __forceinline__ void box_muller(uint32_t u0, uint32_t u1, float& n0, float& n1) {
+    const float r = sqrtf(-2.0f * __logf(u32_to_unit(u0)));
+    const float th = 6.28318530717958647692f * u32_to_unit(u1);
+    float s, c;
+    __sincosf(th, &s, &c);
+    n0 = r * c;
+    n1 = r * s;
+}
+
+// 4 normals for element group idx4 of stream (seed, sid)
+__device__ __forceinline__ float4 randn4(uint64_t seed, uint64_t sid, uint64_t idx4) {
+    uint32_t r[4];
+    Philox::gen((uint32_t)idx4, (uint32_t)(idx4 >> 32), (uint32_t)sid, (uint32_t)(sid >> 32), (uint32_t)seed, (uint32_t)(seed >> 32), r);
+    float4 o;
+    box_muller(r[0], r[1], o.x, o.y);
+    box_muller(r[2], r[3], o.z, o.w);
+    return o;
+}
+
+__global__ void __launch_bounds__(256) randn_kernel(float* __restrict__ out, int64_t n, uint64_t seed, uint64_t sid) {
+    const int64_t n4 = (n + 3) >> 2;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) {
+        const float4 r = randn4(seed, sid, (uint64_t)i);
+        const float v[4] = {r.x, r.y, r.z, r.w};
+        for (int j = 0; j < 4; ++j)
+            if (i * 4 + j < n) out[i * 4 + j] = v[j];
+    }
+}
+
+__global__ void __launch_bounds__(256) ancestral_kernel(float* __restrict__ z, const float* __restrict__ eh,
+                                                       const float* __restrict__ noise, const float* __restrict__ coef,
+                                                       const int32_t* __restrict__ step_ptr, uint64_t seed, int64_t n) {
+    const int step = *step_ptr;
+    const float ratio = coef[step * 4 + 0], cs = coef[step * 4 + 1], scale = coef[step * 4 + 2];
+    const int64_t n4 = (n + 3) >> 2;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) {
+        float nz[4];
+        if (noise) {
+            for (int j = 0; j < 4; ++j) nz[j] = (i * 4 + j < n) ? noise[i * 4 + j] : 0.f;
+        } else {
+            const float4 r = randn4(seed, (uint64_t)(step + 1), (uint64_t)i);
+            nz[0] = r.x; nz[1] = r.y; nz[2] = r.z; nz[3] = r.w;
+        }
+        for (int j = 0; j < 4; ++j) {
+            const int64_t k = i * 4 + j;
+            if (k < n) z[k] = ratio * (z[k] - cs * eh[k]) + scale * nz[j];
+        }
+    }
+}
+
+__global__ void step_inc_kernel(int32_t* p) { *p += 1; }
+
+__global__ void __launch_bounds__(256) sumsq_kernel(const float* __restrict__ x, int64_t n, float* __restrict__ out) {
+    float acc[1] = {0.f};
+    const int64_t n4 = n >> 2;
+    const float4* x4 = reinterpret_cast<const float4*>(x);
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) {
+        const float4 v = x4[i];
+        acc[0] += v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w;
+    }
+    if (blockIdx.x == 0)
+        for (int64_t i = (n4 << 2) + threadIdx.x; i < n; i += 256) acc[0] += x[i] * x[i];
+    __shared__ float sm[4];
+    block_sum<1>(acc, sm);
+    if (threadIdx.x == 0) atomicAdd(out, acc[0]);
+}
+
+// blocks per sample such that blocks*256 is a multiple of pieces-per-voxel (fixed piece column per thread)
+static int blocks_per_sample(int64_t npieces, int ppv, int n) {
+    int64_t want = (npieces + 256 * 8 - 1) / (256 * 8);          // ~8 pieces per thread
+    int64_t cap = 2048 / (n > 0 ? n : 1);
+    if (cap < 1) cap = 1;
+    if (want > cap) want = cap;
+    if (want < 1) want = 1;
+    // need (want*256) % ppv == 0 ; ppv = C/EPL is a power of two times {1,3}: round up to a multiple of m = ppv/gcd(ppv,256)
+    int g = ppv, b = 256;
+    while (b) { const int t = g % b; g = b; b = t; }
+    const int m = ppv / g;
+    want = (want + m - 1) / m * m;
+    return (int)want;
+}
+
+}  // namespace vdm
+
+using namespace vdm;
+
+static int gn_common_check(int c1, int c2, int n, int64_t voxels, int groups, int dtype, const char* who) {
+    const int epl = dtype == VDM_F32 ? 4 : 8;
+    VDM_REQUIRE(dtype == VDM_F32 || dtype == VDM_BF16, "%s: bad dtype %d", who, dtype);
+    VDM_REQUIRE(n > 0 && voxels > 0 && groups > 0 && groups <= 64, "%s: bad n/voxels/groups", who);
+    VDM_REQUIRE(c1 > 0 && c2 >= 0 && (c1 % epl) == 0 && (c2 % epl) == 0, "%s: channel counts must be multiples of %d (got %d,%d)", who, epl, c1, c2);
+    const int C = c1 + c2;
+    VDM_REQUIRE(C % groups == 0 && C <= 512, "%s: channels %d not divisible by groups %d or > 512", who, C, groups);
+    VDM_REQUIRE(c1 % (C / groups) == 0, "%s: group straddles the concat boundary", who);
+    return VDM_OK;
+}
+
+extern "C" int vdm_gn_stats(const void* x1, int c1, const void* x2, int c2, int n, int64_t voxels, int groups, int dtype, float* stats,
+                            void* stream) {
+    int e = gn_common_check(c1, c2, n, voxels, groups, dtype, "gn_stats");
+    if (e) return e;
+    VDM_REQUIRE(x1 && stats && (c2 == 0 || x2), "gn_stats: NULL pointer");
+    hipStream_t s = (hipStream_t)stream;
+    e = check_hip(hipMemsetAsync(stats, 0, sizeof(float) * 2 * groups * n, s), "hipMemsetAsync(stats)");
+    if (e) return e;
+    const int epl = dtype == VDM_F32 ? 4 : 8;
+    const int gs = (c1 + c2) / groups;
+    const void* xs[2] = {x1, x2};
+    const int cs[2] = {c1, c2};
+    int g0 = 0;
+    for (int k = 0; k < 2; ++k) {
+        if (cs[k] == 0) continue;
+        const int ppv = cs[k] / epl;
+        const int bpn = blocks_per_sample(voxels * ppv, ppv, n);
+        if (dtype == VDM_F32)
+            hipLaunchKernelGGL(gn_stats_kernel<float>, dim3(bpn * n), dim3(256), 0, s, (const float*)xs[k], cs[k], voxels, gs, groups, g0, stats, bpn);
+        else
+            hipLaunchKernelGGL(gn_stats_kernel<bf16_t>, dim3(bpn * n), dim3(256), 0, s, (const bf16_t*)xs[k], cs[k], voxels, gs, groups, g0, stats, bpn);
+        VDM_LAUNCH_CHECK("gn_stats_kernel");
+        g0 += cs[k] / gs;
+    }
+    return VDM_OK;
+}
+
+static GnArgs gn_args(const void* x1, int c1, const void* x2, int c2, int n, int64_t voxels, int groups, int dtype, const float* stats,
+                      const float* gamma, const float* beta, float eps, float p, uint64_t seed) {
+    GnArgs a{};
+    a.x1 = x1; a.x2 = x2; a.c1 = c1; a.c2 = c2; a.n = n; a.G = groups; a.V = voxels;
+    a.stats = stats; a.gamma = gamma; a.beta = beta; a.eps = eps; a.p = p; a.seed = seed;
+    const int epl = dtype == VDM_F32 ? 4 : 8;
+    const int ppv = (c1 + c2) / epl;
+    a.blocks_per_n = blocks_per_sample(voxels * ppv, ppv, n);
+    return a;
+}
+
+extern "C" int vdm_gn_silu_fwd(const void* x1, int c1, const void* x2, int c2, int n, int64_t voxels, int groups, int dtype,
+                               const float* stats, const float* gamma, const float* beta, float eps, float dropout_p, uint64_t seed,
+                               void* y, void* stream) {
+    int e = gn_common_check(c1, c2, n, voxels, groups, dtype, "gn_silu_fwd");
+    if (e) return e;
+    VDM_REQUIRE(x1 && stats && gamma && beta && y && (c2 == 0 || x2), "gn_silu_fwd: NULL pointer");
+    VDM_REQUIRE(dropout_p >= 0.f && dropout_p < 1.f, "gn_silu_fwd: dropout_p out of range");
+    GnArgs a = gn_args(x1, c1, x2, c2, n, voxels, groups, dtype, stats, gamma, beta, eps, dropout_p, seed);
+    a.y = y;
+    hipStream_t s = (hipStream_t)stream;
+    if (dtype == VDM_F32)
+        hipLaunchKernelGGL(gn_silu_fwd_kernel<float>, dim3(a.blocks_per_n * n), dim3(256), 0, s, a);
+    else
+        hipLaunchKernelGGL(gn_silu_fwd_kernel<bf16_t>, dim3(a.blocks_per_n * n), dim3(256), 0, s, a);
+    VDM_LAUNCH_CHECK("gn_silu_fwd_kernel");
+    return VDM_OK;
+}
+
+extern "C" int vdm_gn_silu_bwd(const void* x1, int c1, const void* x2, int c2, int n, int64_t voxels, int groups, int dtype,
+                               const float* stats, const float* gamma, const float* beta, float eps, float dropout_p, uint64_t seed,
+                               const void* dy, const void* add, void* dx1, void* dx2, float* dgamma, float* dbeta, float* colsum,
+                               float* red_ws, void* stream) {
+    int e = gn_common_check(c1, c2, n, voxels, groups, dtype, "gn_silu_bwd");
+    if (e) return e;
+    VDM_REQUIRE(x1 && stats && gamma && beta && dy && dx1 && dgamma && dbeta && red_ws && (c2 == 0 || (x2 && dx2)), "gn_silu_bwd: NULL pointer");
+    GnArgs a = gn_args(x1, c1, x2, c2, n, voxels, groups, dtype, stats, gamma, beta, eps, dropout_p, seed);
+    a.dy = dy; a.add = add; a.dx1 = dx1; a.dx2 = dx2; a.dgamma = dgamma; a.dbeta = dbeta; a.colsum = colsum; a.red = red_ws;
+    hipStream_t s = (hipStream_t)stream;
+    e = check_hip(hipMemsetAsync(red_ws, 0, sizeof(float) * 2 * groups * n, s), "hipMemsetAsync(red_ws)");
+    if (e) return e;
+    if (dtype == VDM_F32) {
+        hipLaunchKernelGGL(gn_silu_bwd_reduce_kernel<float>, dim3(a.blocks_per_n * n), dim3(256), 0, s, a);
+        hipLaunchKernelGGL(gn_silu_bwd_apply_kernel<float>, dim3(a.blocks_per_n * n), dim3(256), 0, s, a);
+    } else {
+        hipLaunchKernelGGL(gn_silu_bwd_reduce_kernel<bf16_t>, dim3(a.blocks_per_n * n), dim3(256), 0, s, a);
+        hipLaunchKernelGGL(gn_silu_bwd_apply_kernel<bf16_t>, dim3(a.blocks_per_n * n), dim3(256), 0, s, a);
+    }
+    VDM_LAUNCH_CHECK("gn_silu_bwd kernels");
+    return VDM_OK;
+}
+
+extern "C" int vdm_colsum(const void* x, int n, int64_t voxels, int c, int dtype, float* out, void* stream) {
+    const int epl = dtype == VDM_F32 ? 4 : 8;
+    VDM_REQUIRE(x && out && n > 0 && voxels > 0 && c > 0 && c <= 512 && c % epl == 0, "colsum: bad arguments (c=%d)", c);
+    const int ppv = c / epl;
+    const int bpn = blocks_per_sample(voxels * ppv, ppv, n);
+    hipStream_t s = (hipStream_t)stream;
+    if (dtype == VDM_F32)
+        hipLaunchKernelGGL(colsum_kernel<float>, dim3(bpn * n), dim3(256), 0, s, (const float*)x, c, voxels, out, bpn);
+    else
+        hipLaunchKernelGGL(colsum_kernel<bf16_t>, dim3(bpn * n), dim3(256), 0, s, (const bf16_t*)x, c, voxels, out, bpn);
+    VDM_LAUNCH_CHECK("colsum_kernel");
+    return VDM_OK;
+}
+
+extern "C" int vdm_dilate2(const void* coarse, void* fine, int n, int cd, int ch, int cw, int c, int dtype, void* stream) {
+    const int epl = dtype == VDM_F32 ? 4 : 8;
+    VDM_REQUIRE(coarse && fine && n > 0 && cd > 0 && ch > 0 && cw > 0 && c % epl == 0, "dilate2: bad arguments");
+    const int64_t total = (int64_t)n * cd * ch * cw * 8 * (c / epl);
+    hipStream_t s = (hipStream_t)stream;
+    if (dtype == VDM_F32)
+        hipLaunchKernelGGL(dilate2_kernel<float>, dim3(grid_for(total, 256 * 4)), dim3(256), 0, s, (const float*)coarse, (float*)fine, n, cd, ch, cw, c);
+    else
+        hipLaunchKernelGGL(dilate2_kernel<bf16_t>, dim3(grid_for(total, 256 * 4)), dim3(256), 0, s, (const bf16_t*)coarse, (bf16_t*)fine, n, cd, ch, cw, c);
+    VDM_LAUNCH_CHECK("dilate2_kernel");
+    return VDM_OK;
+}
+
+extern "C" int vdm_pool2_sum(const void* fine, void* coarse, int n, int cd, int ch, int cw, int c, int dtype, void* stream) {
+    const int epl = dtype == VDM_F32 ? 4 : 8;
+    VDM_REQUIRE(coarse && fine && n > 0 && cd > 0 && ch > 0 && cw > 0 && c % epl == 0, "pool2_sum: bad arguments");
+    const int64_t total = (int64_t)n * cd * ch * cw * (c / epl);
+    hipStream_t s = (hipStream_t)stream;
+    if (dtype == VDM_F32)
+        hipLaunchKernelGGL(pool2_sum_kernel<float>, dim3(grid_for(total, 256 * 2)), dim3(256), 0, s, (const float*)fine, (float*)coarse, n, cd, ch, cw, c);
+    else
+        hipLaunchKernelGGL(pool2_sum_kernel<bf16_t>, dim3(grid_for(total, 256 * 2)), dim3(256), 0, s, (const bf16_t*)fine, (bf16_t*)coarse, n, cd, ch, cw, c);
+    VDM_LAUNCH_CHECK("pool2_sum_kernel");
+    return VDM_OK;
+}
+
+extern "C" int vdm_cast(const void* src, int sd, void* dst, int dd, int64_t n, void* stream) {
+    VDM_REQUIRE(src && dst && n >= 0, "cast: bad arguments");
+    hipStream_t s = (hipStream_t)stream;
+    const unsigned g = grid_for(n, 256 * 4);
+    if (sd == VDM_F32 && dd == VDM_BF16)
+        hipLaunchKernelGGL((cast_kernel<float, bf16_t>), dim3(g), dim3(256), 0, s, (const float*)src, (bf16_t*)dst, n);
+    else if (sd == VDM_BF16 && dd == VDM_F32)
+        hipLaunchKernelGGL((cast_kernel<bf16_t, float>), dim3(g), dim3(256), 0, s, (const bf16_t*)src, (float*)dst, n);
+    else if (sd == VDM_F32 && dd == VDM_F32)
+        hipLaunchKernelGGL((cast_kernel<float, float>), dim3(g), dim3(256), 0, s, (const float*)src, (float*)dst, n);
+    else {
+        set_error("cast: unsupported dtype pair %d -> %d", sd, dd);
+        return VDM_ERR_UNSUPPORTED;
+    }
+    VDM_LAUNCH_CHECK("cast_kernel");
+    return VDM_OK;
+}
+
+extern "C" int vdm_pack_input(const float* a, const float* b, int64_t nvox, int cpad, int dtype, void* out, void* stream) {
+    VDM_REQUIRE(a && out && nvox > 0 && cpad >= 2, "pack_input: bad arguments");
+    hipStream_t s = (hipStream_t)stream;
+    if (dtype == VDM_F32)
+        hipLaunchKernelGGL(pack_input_kernel<float>, dim3(grid_for(nvox, 256)), dim3(256), 0, s, a, b, nvox, cpad, (float*)out);
+    else
+        hipLaunchKernelGGL(pack_input_kernel<bf16_t>, dim3(grid_for(nvox, 256)), dim3(256), 0, s, a, b, nvox, cpad, (bf16_t*)out);
+    VDM_LAUNCH_CHECK("pack_input_kernel");
+    return VDM_OK;
+}
+
+static int bpn_for(int64_t per, int n) {
+    int64_t b = (per + 256 * 16 - 1) / (256 * 16);
+    int64_t cap = 2048 / (n > 0 ? n : 1);
+    if (cap < 1) cap = 1;
+    if (b > cap) b = cap;
+    if (b < 1) b = 1;
+    return (int)b;
+}
+
+extern "C" int vdm_diffuse(const float* x, const float* eps, const float* alpha, const float* sigma, int n, int64_t per, float* z_t,
+                           void* stream) {
+    VDM_REQUIRE(x && eps && alpha && sigma && z_t && n > 0 && per > 0 && per % 4 == 0, "diffuse: bad arguments (per must be a multiple of 4)");
+    const int bpn = bpn_for(per / 4, n);
+    hipLaunchKernelGGL(diffuse_kernel, dim3(bpn * n), dim3(256), 0, (hipStream_t)stream, x, eps, alpha, sigma, per, z_t, bpn);
+    VDM_LAUNCH_CHECK("diffuse_kernel");
+    return VDM_OK;
+}
+
+extern "C" int vdm_loss_terms(const float* x, const float* eps, const float* eps_hat, const float* eps0, float s0a0, const float* coef,
+                              int n, int64_t per, float* sums, float* d_eps_hat, void* stream) {
+    VDM_REQUIRE(x && eps && eps_hat && eps0 && coef && sums && d_eps_hat && n > 0 && per > 0, "loss_terms: bad arguments");
+    const int bpn = bpn_for(per, n);
+    hipLaunchKernelGGL(loss_terms_kernel, dim3(bpn * n), dim3(256), 0, (hipStream_t)stream, x, eps, eps_hat, eps0, s0a0, coef, per, sums,
+                       d_eps_hat, bpn);
+    VDM_LAUNCH_CHECK("loss_terms_kernel");
+    return VDM_OK;
+}
+
+extern "C" int vdm_ancestral_step(float* z, const float* eps_hat, const float* noise, const float* coef, const int32_t* step_ptr,
+                                  uint64_t seed, int64_t n, void* stream) {
+    VDM_REQUIRE(z && eps_hat && coef && step_ptr && n > 0, "ancestral_step: bad arguments");
+    hipLaunchKernelGGL(ancestral_kernel, dim3(grid_for(n, 256 * 8)), dim3(256), 0, (hipStream_t)stream, z, eps_hat, noise, coef, step_ptr, seed, n);
+    VDM_LAUNCH_CHECK("ancestral_kernel");
+    return VDM_OK;
+}
+
+extern "C" int vdm_randn(float* out, int64_t n, uint64_t seed, uint64_t stream_id, void* stream) {
+    VDM_REQUIRE(out && n > 0, "randn: bad arguments");
+    hipLaunchKernelGGL(randn_kernel, dim3(grid_for(n, 256 * 8)), dim3(256), 0, (hipStream_t)stream, out, n, seed, stream_id);
+    VDM_LAUNCH_CHECK("randn_kernel");
+    return VDM_OK;
+}
+
+extern "C" int vdm_step_inc(int32_t* step_ptr, void* stream) {
+    VDM_REQUIRE(step_ptr, "step_inc: NULL pointer");
+    hipLaunchKernelGGL(step_inc_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, step_ptr);
+    VDM_LAUNCH_CHECK("step_inc_kernel");
+    return VDM_OK;
+}
+
+extern "C" int vdm_sumsq(const float* x, int64_t n, float* out, void* stream) {
+    VDM_REQUIRE(x && out && n > 0, "sumsq: bad arguments");
+    VDM_REQUIRE(((uintptr_t)x & 15) == 0, "sumsq: x must be 16-byte aligned");
+    hipLaunchKernelGGL(sumsq_kernel, dim3(grid_for(n, 256 * 16)), dim3(256), 0, (hipStream_t)stream, x, n, out);
+    VDM_LAUNCH_CHECK("sumsq_kernel");
+    return VDM_OK;
+}
