@@ -62,14 +62,16 @@ int vdm_device_info(int device, int* cu_count, int* lds_bytes, char* arch_name);
  * MFMA fragment order once per optimiser step. */
 size_t vdm_conv_packed_bytes(const vdm_conv_desc* d, int pack_mode);
 int vdm_conv_pack_weights(const vdm_conv_desc* d, int pack_mode, const float* w_master, void* w_packed, void* stream);
-/* out = conv(x, w) + bias[c] + nbias[n][c] + residual   (bias, nbias, residual may be NULL).
- * nbias is the per-sample conditioning bias table (sum_k Linear_k(cond_k)). */
+/* out = conv(x, w) + bias[c] + nbias[n*nbias_stride + c] + residual   (bias, nbias, residual may be NULL).
+ * nbias is the per-sample conditioning bias table (sum_k Linear_k(cond_k)); nbias_stride is the
+ * element distance between samples (the table of all blocks is one [n][sum cout] matrix). */
 int vdm_conv_fwd(const vdm_conv_desc* d, const void* x, const void* w_packed_fwd, const float* bias,
-                 const float* nbias, const void* residual, void* out, void* stream);
+                 const float* nbias, int64_t nbias_stride, const void* residual, void* out, void* stream);
 /* dx = conv_transpose(dout, w) for stride-1 convs: the descriptor is the FORWARD conv's; dout has
  * cout channels, dx gets cin channels (spatial dims od/oh/ow; for an up-sampling conv dx is the
  * gradient w.r.t. the up-sampled fine tensor - reduce it with vdm_pool2_sum). */
-int vdm_conv_dgrad(const vdm_conv_desc* d, const void* dout, const void* w_packed_dgrad, void* dx, void* stream);
+int vdm_conv_dgrad(const vdm_conv_desc* d, const void* dout, const void* w_packed_dgrad, const void* residual, void* dx,
+                   void* stream); /* dx = dgrad (+ residual, same shape as dx, may be NULL) */
 /* dw[taps][cout][cin] (fp32) = sum over voxels; workspace holds per-workgroup partial slabs. */
 size_t vdm_conv_wgrad_workspace_bytes(const vdm_conv_desc* d);
 int vdm_conv_wgrad(const vdm_conv_desc* d, const void* x, const void* dout, float* dw, int accumulate,
@@ -78,25 +80,29 @@ int vdm_conv_wgrad(const vdm_conv_desc* d, const void* x, const void* dout, floa
 /* ---- K2: GroupNorm + SiLU (+ dropout) -----------------------------------------------------
  * Replaces torch.group_norm / F.silu / F.dropout [NB normalization.py:273 frame under blocks.py:130].
  * The input may be the channel-concatenation of two tensors (skip connection), never materialised.
- * stats[n][g] = {sum, sumsq} in fp32 (raw moments; mean/rstd are derived where consumed). */
+ * stats[n][g] = {sum, sumsq} in fp32 (raw moments; mean/rstd are derived where consumed).
+ * workspace: VDM_GN_STATS_WS_BYTES of scratch for the per-workgroup partials (two-stage, fixed-order
+ * reduction: the forward pass is bit-reproducible). */
+#define VDM_GN_STATS_WS_BYTES (2048 * 2 * 64 * 4)
 int vdm_gn_stats(const void* x1, int c1, const void* x2, int c2, int n, int64_t voxels, int groups,
-                 int dtype, float* stats, void* stream);
+                 int dtype, float* stats, float* workspace, void* stream);
 /* y[n][v][c1+c2] = dropout(silu(gn(concat(x1,x2)))) ; keep-mask from Philox(seed, element index). */
 int vdm_gn_silu_fwd(const void* x1, int c1, const void* x2, int c2, int n, int64_t voxels, int groups,
                     int dtype, const float* stats, const float* gamma, const float* beta, float eps,
                     float dropout_p, uint64_t seed, void* y, void* stream);
 /* Backward of the above.  dy is the gradient w.r.t. y.  Writes dx1 (and dx2), ADDS into
- * dgamma/dbeta [c] (caller zeroes), optional `add` (same layout as dy) is added to dx, optional
- * colsum[n][c1+c2] receives sum_v dx (caller zeroes; used for bias / conditioning-bias grads).
- * red_ws: >= n*groups*2 floats of scratch. */
+ * dgamma/dbeta [c] (caller zeroes); optional add1 / add2 (shaped like x1 / x2) are added to dx1 / dx2
+ * (residual-path gradients); optional colsum[n*colsum_stride + c] += sum_v dx (caller zeroes; bias and
+ * conditioning-bias gradients).  red_ws: >= n*groups*2 floats of scratch. */
 int vdm_gn_silu_bwd(const void* x1, int c1, const void* x2, int c2, int n, int64_t voxels, int groups,
                     int dtype, const float* stats, const float* gamma, const float* beta, float eps,
-                    float dropout_p, uint64_t seed, const void* dy, const void* add, void* dx1, void* dx2,
-                    float* dgamma, float* dbeta, float* colsum, float* red_ws, void* stream);
+                    float dropout_p, uint64_t seed, const void* dy, const void* add1, const void* add2, void* dx1,
+                    void* dx2, float* dgamma, float* dbeta, float* colsum, int64_t colsum_stride, float* red_ws,
+                    void* stream);
 
 /* ---- small tensor ops on the path ------------------------------------------------------------ */
-/* out[n][c] (+)= sum_v x[n][v][c]   (conv bias gradients). */
-int vdm_colsum(const void* x, int n, int64_t voxels, int c, int dtype, float* out, void* stream);
+/* out[n*out_stride + c] += sum_v x[n][v][c]   (conv bias gradients; caller zeroes). */
+int vdm_colsum(const void* x, int n, int64_t voxels, int c, int dtype, float* out, int64_t out_stride, void* stream);
 /* fine[n][2z+a][2y+b][2x+c][ch] = (a|b|c)==0 ? coarse[n][z][y][x][ch] : 0  (stride-2 dgrad helper). */
 int vdm_dilate2(const void* coarse, void* fine, int n, int cd, int ch, int cw, int c, int dtype, void* stream);
 /* coarse = sum of the 2x2x2 children of fine (backward of nearest x2 up-sampling). */

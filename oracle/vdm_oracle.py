@@ -66,9 +66,9 @@ def vdm_loss(score_fn, sched, x, times, eps, eps0):
     eps_hat = score_fn(z_t, t_norm)
     diff = 0.5 * sched.dgamma_dt(times).to(x.dtype) * ((eps - eps_hat) ** 2).sum(red)
     g1 = sched.gamma(1.0)
-    var1 = torch.sigmoid(g1).to(x.dtype)
-    mean1_sq = (1.0 - var1) * x ** 2
-    latent = 0.5 * (var1 + mean1_sq - torch.log(var1) - 1.0).sum(red)
+    var1 = torch.sigmoid(g1)                       # fp64: var1 - log(var1) - 1 ~ 1e-12 cancels in fp32
+    numel = x[0].numel()
+    latent = (0.5 * (numel * (var1 - torch.log(var1) - 1.0) + (1.0 - var1) * (x.double() ** 2).sum(red))).to(x.dtype)
     g0 = sched.gamma(0.0)
     a0, s0 = sched.alpha(g0).to(x.dtype), sched.sigma(g0).to(x.dtype)
     z0_rescaled = (a0 * x + s0 * eps0) / a0

@@ -1,0 +1,360 @@
+"""GPU parity tests: every HIP kernel (through the C-ABI) against the same torch.nn.functional primitive on
+the CPU in fp32 (T1 of SURVEY.md section 8c).  Tolerances (stated per test):
+  fp32 storage : |d| <= 1e-5 + 1e-5|ref| for GroupNorm / elementwise, <= 1e-4 * max|ref| for convolutions
+  bf16 storage : inputs are rounded to bf16 first; outputs within 2^-7 * max|ref| (one bf16 rounding + fp32 accumulate)
+"""
+import math
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+DEV = "cuda:0"
+DTYPES = [torch.float32, torch.bfloat16]
+
+
+def _ops():
+    from vdm4cdm_amd import hip_ops
+    return hip_ops
+
+
+def rnd(shape, seed, dtype=torch.float32, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    x = torch.randn(shape, generator=g) * scale
+    return x.to(dtype).float()          # value representable in `dtype`, held as fp32 on the CPU
+
+
+def to_dev(x, dtype):
+    return x.to(dtype).to(DEV).contiguous()
+
+
+def conv_tol(dtype, ref):
+    return (1e-4 if dtype == torch.float32 else 2.0 ** -7) * max(ref.abs().max().item(), 1e-6)
+
+
+def ref_conv(x, w, bias, nbias, res, ks, stride, ups, circular):
+    """x: [N,D,H,W,Cin] fp32 ; w: [T,Cout,Cin] ; returns NDHWC fp32."""
+    xc = x.permute(0, 4, 1, 2, 3)
+    if ups:
+        xc = F.interpolate(xc, scale_factor=2, mode="nearest")
+    cout, cin = w.shape[1], w.shape[2]
+    wt = w.view(ks, ks, ks, cout, cin).permute(3, 4, 0, 1, 2)
+    pad = ks // 2
+    if pad and circular:
+        y = F.conv3d(F.pad(xc, (pad,) * 6, mode="circular"), wt, bias, stride=stride)
+    else:
+        y = F.conv3d(xc, wt, bias, stride=stride, padding=pad)
+    y = y.permute(0, 2, 3, 4, 1)
+    if nbias is not None:
+        y = y + nbias[:, None, None, None, :]
+    if res is not None:
+        y = y + res
+    return y
+
+
+CONV_CASES = [
+    # name, N, (D,H,W) of the OUTPUT, cin, cout, ks, stride, ups, circular
+    ("k3_32_32", 2, (8, 8, 16), 32, 32, 3, 1, 0, False),
+    ("k3_32_32_ragged", 1, (6, 9, 20), 32, 32, 3, 1, 0, False),
+    ("k3_64_32", 1, (4, 8, 16), 64, 32, 3, 1, 0, False),
+    ("k3_32_64", 1, (4, 8, 16), 32, 64, 3, 1, 0, False),
+    ("k3_128_256", 1, (4, 4, 16), 128, 256, 3, 1, 0, False),
+    ("k3_cin2pad", 2, (8, 8, 16), 2, 32, 3, 1, 0, False),
+    ("k3_cout1", 2, (8, 8, 16), 32, 1, 3, 1, 0, False),
+    ("k3_circ", 1, (8, 8, 16), 32, 32, 3, 1, 0, True),
+    ("k3_circ_small", 1, (2, 4, 6), 32, 32, 3, 1, 0, True),
+    ("k3_s2", 2, (4, 4, 8), 32, 32, 3, 2, 0, False),
+    ("k3_s2_circ", 1, (4, 6, 8), 64, 64, 3, 2, 0, True),
+    ("k3_ups", 1, (8, 8, 16), 64, 32, 3, 1, 1, False),
+    ("k3_ups_circ", 1, (4, 8, 12), 32, 16, 3, 1, 1, True),
+    ("k1_64_32", 2, (8, 8, 16), 64, 32, 1, 1, 0, False),
+    ("k1_32_128", 1, (4, 8, 12), 32, 128, 1, 1, 0, False),
+    ("k3_16_16", 1, (8, 8, 16), 16, 16, 3, 1, 0, False),
+    ("k3_48_96", 1, (4, 8, 16), 48, 96, 3, 1, 0, False),
+]
+
+
+def _conv_setup(case, dtype, seed=0):
+    ops = _ops()
+    name, N, (D, H, W), cin, cout, ks, stride, ups, circ = case
+    if stride == 2:
+        ishape = (N, 2 * D, 2 * H, 2 * W, cin)
+    elif ups:
+        ishape = (N, D // 2, H // 2, W // 2, cin)
+    else:
+        ishape = (N, D, H, W, cin)
+    x = rnd(ishape, seed + 1, dtype)
+    w = rnd((ks ** 3, cout, cin), seed + 2, dtype, scale=1.0 / math.sqrt(ks ** 3 * cin))
+    conv = ops.Conv(cin, cout, ks, stride=stride, upsample=ups, circular=circ)
+    conv.pack(w.to(DEV), dtype, need_dgrad=(stride == 1))
+    cp = ops.cpad(cin, dtype)
+    xd = torch.zeros(ishape[:-1] + (cp,), dtype=dtype, device=DEV)
+    xd[..., :cin] = x.to(dtype).to(DEV)
+    return ops, conv, x, w, xd
+
+
+@pytest.mark.parametrize("dtype", DTYPES, ids=["f32", "bf16"])
+@pytest.mark.parametrize("case", CONV_CASES, ids=[c[0] for c in CONV_CASES])
+def test_conv_fwd(case, dtype):
+    ops, conv, x, w, xd = _conv_setup(case, dtype)
+    name, N, (D, H, W), cin, cout, ks, stride, ups, circ = case
+    bias = rnd((cout,), 5)
+    nbias_full = rnd((N, cout + 7), 6)                     # strided view: row stride cout+7
+    res = rnd((N, D, H, W, cout), 7, dtype)
+    nb_dev = nbias_full.to(DEV)[:, 3:3 + cout]
+    out = conv.fwd(xd, bias.to(DEV), nb_dev, to_dev(res, dtype))
+    ref = ref_conv(x, w, bias, nbias_full[:, 3:3 + cout], res, ks, stride, ups, circ)
+    err = (out.float().cpu() - ref).abs().max().item()
+    assert out.shape == ref.shape
+    assert err <= conv_tol(dtype, ref), f"{name}: max err {err} > {conv_tol(dtype, ref)}"
+    # plain variant without epilogue terms
+    out2 = conv.fwd(xd)
+    ref2 = ref_conv(x, w, None, None, None, ks, stride, ups, circ)
+    err2 = (out2.float().cpu() - ref2).abs().max().item()
+    assert err2 <= conv_tol(dtype, ref2), f"{name} (no epilogue): max err {err2}"
+
+
+def test_conv_out_f32():
+    """conv_out writes fp32 eps_hat from bf16 activations (cout = 1)."""
+    case = ("k3_cout1", 2, (8, 8, 16), 32, 1, 3, 1, 0, False)
+    dtype = torch.bfloat16
+    ops = _ops()
+    x = rnd((2, 8, 8, 16, 32), 1, dtype)
+    w = rnd((27, 1, 32), 2, dtype, scale=0.05)
+    conv = ops.Conv(32, 1, 3, out_f32=True)
+    conv.pack(w.to(DEV), dtype, need_dgrad=False)
+    out = conv.fwd(to_dev(x, dtype), rnd((1,), 3).to(DEV))
+    assert out.dtype == torch.float32
+    ref = ref_conv(x, w, rnd((1,), 3), None, None, 3, 1, 0, False)
+    assert (out.cpu() - ref).abs().max().item() <= 1e-4 * ref.abs().max().item() + 1e-5
+
+
+GRAD_CASES = [c for c in CONV_CASES if c[0] in ("k3_32_32", "k3_32_32_ragged", "k3_64_32", "k3_32_64", "k3_128_256", "k3_cin2pad",
+                                                  "k3_cout1", "k3_circ", "k3_s2", "k3_s2_circ", "k3_ups", "k3_ups_circ", "k1_64_32",
+                                                  "k1_32_128", "k3_48_96")]
+
+
+@pytest.mark.parametrize("dtype", DTYPES, ids=["f32", "bf16"])
+@pytest.mark.parametrize("case", GRAD_CASES, ids=[c[0] for c in GRAD_CASES])
+def test_conv_grads(case, dtype):
+    """dgrad and wgrad against torch.autograd of the reference conv."""
+    ops, conv, x, w, xd = _conv_setup(case, dtype, seed=10)
+    name, N, (D, H, W), cin, cout, ks, stride, ups, circ = case
+    dout = rnd((N, D, H, W, cout), 11, dtype)
+    xr = x.clone().requires_grad_(True)
+    wr = w.clone().requires_grad_(True)
+    ref = ref_conv(xr, wr, None, None, None, ks, stride, ups, circ)
+    ref.backward(dout)
+    cpo = ops.cpad(cout, dtype)
+    dd = torch.zeros((N, D, H, W, cpo), dtype=dtype, device=DEV)
+    dd[..., :cout] = dout.to(dtype).to(DEV)
+    # wgrad
+    dw = torch.full((ks ** 3, cout, cin), float("nan"), device=DEV)
+    conv.wgrad(xd, dd, dw)
+    tol_w = (2e-4 if dtype == torch.float32 else 2.0 ** -7) * max(wr.grad.abs().max().item(), 1e-6)
+    err_w = (dw.cpu() - wr.grad).abs().max().item()
+    assert err_w <= tol_w, f"{name}: wgrad err {err_w} > {tol_w}"
+    # accumulate flag
+    conv.wgrad(xd, dd, dw, accumulate=True)
+    assert (dw.cpu() - 2 * wr.grad).abs().max().item() <= 2 * tol_w
+    # dgrad
+    if stride == 2:
+        conv.pack(w.to(DEV), dtype, need_dgrad=True)
+        dx = conv.dgrad(ops.dilate2(dd))
+    else:
+        dx = conv.dgrad(dd)
+        if ups:
+            dx = ops.pool2_sum(dx)
+    gref = xr.grad
+    err_x = (dx.float().cpu()[..., :cin] - gref).abs().max().item()
+    assert dx.shape[:-1] == gref.shape[:-1]
+    assert err_x <= conv_tol(dtype, gref) * (4 if ups else 1), f"{name}: dgrad err {err_x}"
+
+
+def test_dgrad_residual():
+    ops, conv, x, w, xd = _conv_setup(("k3_32_32", 2, (8, 8, 16), 32, 32, 3, 1, 0, False), torch.float32, seed=20)
+    dout = rnd((2, 8, 8, 16, 32), 21)
+    res = rnd((2, 8, 8, 16, 32), 22)
+    a = conv.dgrad(dout.to(DEV))
+    b = conv.dgrad(dout.to(DEV), residual=res.to(DEV))
+    assert (b.cpu() - a.cpu() - res).abs().max().item() <= 1e-5
+
+
+# ------------------------------------------------------------------------------------------ GroupNorm + SiLU
+GN_CASES = [  # N, voxels-shape, c1, c2, groups
+    (2, (4, 6, 10), 32, 0, 8),
+    (2, (4, 6, 10), 32, 32, 8),
+    (1, (3, 5, 7), 64, 64, 8),
+    (2, (4, 4, 4), 256, 0, 8),
+    (1, (8, 8, 8), 16, 0, 8),      # group size 2 < piece width
+    (1, (4, 4, 6), 48, 48, 8),
+    (3, (2, 2, 2), 8, 0, 4),
+]
+
+
+def ew_tol(dtype, ref):
+    return 1e-5 + 1e-5 * ref.abs().max().item() if dtype == torch.float32 else 2.0 ** -7 * max(ref.abs().max().item(), 1e-6)
+
+
+@pytest.mark.parametrize("dtype", DTYPES, ids=["f32", "bf16"])
+@pytest.mark.parametrize("case", GN_CASES, ids=[f"gn{i}" for i in range(len(GN_CASES))])
+def test_gn_silu_fwd_bwd(case, dtype):
+    ops = _ops()
+    N, sp, c1, c2, G = case
+    C = c1 + c2
+    x1 = (rnd((N,) + sp + (c1,), 1) * 1.5 + 0.3).to(dtype).float()
+    x2 = rnd((N,) + sp + (c2,), 2, dtype) if c2 else None
+    gamma = 1.0 + 0.3 * rnd((C,), 3)
+    beta = 0.2 * rnd((C,), 4)
+    dy = rnd((N,) + sp + (C,), 5, dtype)
+    add1 = rnd((N,) + sp + (c1,), 6, dtype)
+    add2 = rnd((N,) + sp + (c2,), 7, dtype) if c2 else None
+    xc = (x1 if x2 is None else torch.cat([x1, x2], -1)).clone().requires_grad_(True)
+    gr, br = gamma.clone().requires_grad_(True), beta.clone().requires_grad_(True)
+    y_ref = F.silu(F.group_norm(xc.permute(0, 4, 1, 2, 3), G, gr, br, 1e-5)).permute(0, 2, 3, 4, 1)
+    y_ref.backward(dy)
+
+    d1, d2 = to_dev(x1, dtype), (to_dev(x2, dtype) if c2 else None)
+    st = ops.gn_stats(d1, d2, G)
+    # statistics
+    V = math.prod(sp)
+    xg = xc.detach().reshape(N, V, G, C // G)
+    assert torch.allclose(st[..., 0].cpu(), xg.sum((1, 3)), rtol=1e-4, atol=1e-3)
+    assert torch.allclose(st[..., 1].cpu(), (xg ** 2).sum((1, 3)), rtol=1e-4, atol=1e-3)
+    y = ops.gn_silu_fwd(d1, d2, G, st, gamma.to(DEV), beta.to(DEV))
+    err = (y.float().cpu() - y_ref.detach()).abs().max().item()
+    assert err <= ew_tol(dtype, y_ref.detach()) * 4, f"gn fwd err {err}"
+
+    dgam = torch.zeros(C, device=DEV)
+    dbet = torch.zeros(C, device=DEV)
+    cs = torch.zeros(N, C + 5, device=DEV)
+    dx1, dx2 = ops.gn_silu_bwd(d1, d2, G, st, gamma.to(DEV), beta.to(DEV), to_dev(dy, dtype), dgam, dbet,
+                               add1=to_dev(add1, dtype), add2=(to_dev(add2, dtype) if c2 else None), colsum=cs[:, 2:2 + C])
+    gx = xc.grad
+    ref1 = gx[..., :c1] + add1
+    tol = ew_tol(dtype, ref1) * 8
+    e1 = (dx1.float().cpu() - ref1).abs().max().item()
+    assert e1 <= tol, f"gn bwd dx1 err {e1} > {tol}"
+    full = ref1
+    if c2:
+        ref2 = gx[..., c1:] + add2
+        e2 = (dx2.float().cpu() - ref2).abs().max().item()
+        assert e2 <= tol, f"gn bwd dx2 err {e2}"
+        full = torch.cat([ref1, ref2], -1)
+    rt = 1e-3 if dtype == torch.float32 else 2e-2
+    assert torch.allclose(dgam.cpu(), gr.grad, rtol=rt, atol=rt * gr.grad.abs().max().item())
+    assert torch.allclose(dbet.cpu(), br.grad, rtol=rt, atol=rt * br.grad.abs().max().item())
+    cref = full.reshape(N, V, C).sum(1)
+    assert torch.allclose(cs[:, 2:2 + C].cpu(), cref, rtol=rt, atol=rt * cref.abs().max().item() + 1e-3)
+    assert cs[:, :2].abs().max().item() == 0 and cs[:, 2 + C:].abs().max().item() == 0
+
+
+def test_gn_dropout_consistency():
+    """Dropout mask: fwd and bwd regenerate the same Philox keep-mask; keep rate ~ 1-p; kept values scaled 1/(1-p)."""
+    ops = _ops()
+    dtype = torch.float32
+    N, sp, C, G, p = 2, (8, 8, 8), 32, 8, 0.1
+    x = rnd((N,) + sp + (C,), 1)
+    gamma, beta = torch.ones(C), torch.zeros(C)
+    d = x.to(DEV)
+    st = ops.gn_stats(d, None, G)
+    y0 = ops.gn_silu_fwd(d, None, G, st, gamma.to(DEV), beta.to(DEV))
+    y1 = ops.gn_silu_fwd(d, None, G, st, gamma.to(DEV), beta.to(DEV), p, 1234)
+    y1b = ops.gn_silu_fwd(d, None, G, st, gamma.to(DEV), beta.to(DEV), p, 1234)
+    y2 = ops.gn_silu_fwd(d, None, G, st, gamma.to(DEV), beta.to(DEV), p, 99)
+    assert torch.equal(y1, y1b) and not torch.equal(y1, y2)
+    kept = y1 != 0
+    rate = kept.float().mean().item()
+    assert abs(rate - (1 - p)) < 0.01, rate
+    assert torch.allclose(y1[kept], y0[kept] / (1 - p), rtol=1e-6, atol=1e-7)
+    # backward uses the same mask: dx == 0 contribution where dropped -> compare with autograd using the mask
+    dy = rnd((N,) + sp + (C,), 5)
+    mask = (kept.float() / (1 - p)).cpu()
+    xr = x.clone().requires_grad_(True)
+    yr = F.silu(F.group_norm(xr.permute(0, 4, 1, 2, 3), G, gamma, beta, 1e-5)).permute(0, 2, 3, 4, 1) * mask
+    yr.backward(dy)
+    dg, db = torch.zeros(C, device=DEV), torch.zeros(C, device=DEV)
+    dx, _ = ops.gn_silu_bwd(d, None, G, st, gamma.to(DEV), beta.to(DEV), dy.to(DEV), dg, db, dropout_p=p, seed=1234)
+    assert (dx.cpu() - xr.grad).abs().max().item() <= 1e-4
+
+
+# ------------------------------------------------------------------------------------------ small ops
+@pytest.mark.parametrize("dtype", DTYPES, ids=["f32", "bf16"])
+def test_small_ops(dtype):
+    ops = _ops()
+    x = rnd((2, 4, 6, 8, 32), 1, dtype)
+    d = to_dev(x, dtype)
+    out = torch.zeros(32, device=DEV)
+    ops.colsum(d, out, 0)
+    assert torch.allclose(out.cpu(), x.sum((0, 1, 2, 3)), rtol=1e-4, atol=1e-3)
+    out2 = torch.zeros(2, 40, device=DEV)
+    ops.colsum(d, out2[:, 4:36])
+    assert torch.allclose(out2[:, 4:36].cpu(), x.sum((1, 2, 3)), rtol=1e-4, atol=1e-3)
+    fine = ops.dilate2(d).float().cpu()
+    assert fine.shape == (2, 8, 12, 16, 32)
+    assert torch.equal(fine[:, ::2, ::2, ::2], x) and fine.abs().sum().item() == pytest.approx(x.abs().sum().item(), rel=1e-5)
+    pooled = ops.pool2_sum(to_dev(fine, dtype)).float().cpu()
+    assert torch.allclose(pooled, x, atol=1e-6)
+    y = rnd((2, 4, 4, 8, 16), 2, dtype)
+    pr = ops.pool2_sum(to_dev(y, dtype)).float().cpu()
+    ref = y.reshape(2, 2, 2, 2, 2, 4, 2, 16).sum((2, 4, 6))
+    assert (pr - ref).abs().max().item() <= ew_tol(dtype, ref) * 2
+    a, b = rnd((2, 4, 4, 4), 3), rnd((2, 4, 4, 4), 4)
+    pk = ops.pack_input(a.to(DEV), b.to(DEV), dtype).float().cpu()
+    assert pk.shape[-1] == ops.cpad(2, dtype)
+    assert (pk[..., 0] - a.to(dtype).float()).abs().max() == 0 and (pk[..., 1] - b.to(dtype).float()).abs().max() == 0
+    assert pk[..., 2:].abs().max() == 0
+    pk1 = ops.pack_input(a.to(DEV), None, dtype).float().cpu()
+    assert pk1[..., 1:].abs().max() == 0
+
+
+def test_vdm_elementwise():
+    ops = _ops()
+    B, per = 3, 4 * 5 * 6 * 4
+    x, eps, eh, e0 = rnd((B, per), 1), rnd((B, per), 2), rnd((B, per), 3), rnd((B, per), 4)
+    al, si = torch.tensor([0.9, 0.5, 0.1]), torch.tensor([0.3, 0.8, 0.99])
+    z = ops.diffuse(x.to(DEV), eps.to(DEV), al.to(DEV), si.to(DEV)).cpu()
+    assert torch.allclose(z, al[:, None] * x + si[:, None] * eps, atol=1e-6)
+    coef = torch.tensor([0.5, 1.5, 2.0])
+    sums = torch.zeros(B, 3, device=DEV)
+    d = torch.empty(B, per, device=DEV)
+    ops.loss_terms(x.to(DEV), eps.to(DEV), eh.to(DEV), e0.to(DEV), 0.01, coef.to(DEV), sums, d)
+    ref = torch.stack([((eh - eps) ** 2).sum(1), (x ** 2).sum(1), ((0.01 * e0) ** 2).sum(1)], 1)
+    assert torch.allclose(sums.cpu(), ref, rtol=1e-5)
+    assert torch.allclose(d.cpu(), coef[:, None] * (eh - eps), atol=1e-6)
+    # ancestral update with supplied noise, scalars from the device table
+    coefs = torch.tensor([[0.9, 0.1, 0.2, 0.7], [1.1, 0.3, 0.05, 0.4]])
+    step = torch.tensor([1], dtype=torch.int32, device=DEV)
+    zz = x.clone().to(DEV)
+    ops.ancestral_step(zz, eh.to(DEV), e0.to(DEV), coefs.to(DEV), step, 0)
+    assert torch.allclose(zz.cpu(), 1.1 * (x - 0.3 * eh) + 0.05 * e0, atol=1e-6)
+    ops.step_inc(step)
+    assert step.item() == 2
+    s = torch.zeros(1, device=DEV)
+    big = rnd((1_000_003,), 9)
+    bd = torch.zeros(1_000_004, device=DEV)[:1_000_003]
+    bd.copy_(big)
+    ops.sumsq(bd, s)
+    assert s.item() == pytest.approx((big.double() ** 2).sum().item(), rel=1e-5)
+
+
+def test_philox_normals():
+    """K9/K7 noise source: N(0,1) moments, stream independence, reproducibility."""
+    ops = _ops()
+    n = 1 << 22
+    a = ops.randn(torch.empty(n, device=DEV), 42, 1)
+    b = ops.randn(torch.empty(n, device=DEV), 42, 1)
+    c = ops.randn(torch.empty(n, device=DEV), 42, 2)
+    assert torch.equal(a, b) and not torch.equal(a, c)
+    assert abs(a.mean().item()) < 3e-3 and abs(a.var().item() - 1) < 5e-3
+    assert abs((a ** 4).mean().item() - 3.0) < 0.05
+    assert abs((a * c).mean().item()) < 3e-3
+    assert abs((a[:-1] * a[1:]).mean().item()) < 3e-3
+    # ancestral step with in-kernel noise: z' - ratio*(z - cs*eh) is N(0, scale^2)
+    z = torch.zeros(n, device=DEV)
+    coefs = torch.tensor([[1.0, 0.0, 2.0, 0.0]], device=DEV)
+    step = torch.zeros(1, dtype=torch.int32, device=DEV)
+    ops.ancestral_step(z, torch.zeros(n, device=DEV), None, coefs, step, 7)
+    assert abs(z.std().item() - 2.0) < 0.01

@@ -1,0 +1,97 @@
+"""ctypes binding of libvdm4cdm_hip.so (C-ABI: include/vdm4cdm_hip.h).
+
+The library is the product's only compute path on the GPU.  There is NO fallback: if the shared
+object is missing or a symbol is absent, ``lib()`` raises.  ``build()`` compiles it in-tree with
+hipcc for gfx950 (vdm4cdm_amd/csrc/Makefile).
+"""
+import ctypes as C
+import os
+import subprocess
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libvdm4cdm_hip.so")
+CSRC = os.path.join(_HERE, "csrc")
+
+VDM_F32, VDM_BF16 = 0, 1
+PAD_ZEROS, PAD_CIRCULAR = 0, 1
+PACK_FWD, PACK_DGRAD = 0, 1
+GN_STATS_WS_BYTES = 2048 * 2 * 64 * 4
+
+
+class ConvDesc(C.Structure):
+    """vdm_conv_desc (include/vdm4cdm_hip.h)."""
+    _fields_ = [(k, C.c_int32) for k in
+                ("n", "od", "oh", "ow", "cin", "cout", "ksize", "stride", "upsample", "pad_mode", "dtype", "out_f32")]
+
+
+_p, _i, _i64, _u64, _f, _sz = C.c_void_p, C.c_int, C.c_int64, C.c_uint64, C.c_float, C.c_size_t
+_D = C.POINTER(ConvDesc)
+
+# name -> (restype, argtypes); mirrors include/vdm4cdm_hip.h one to one
+SIGNATURES = {
+    "vdm_last_error": (C.c_char_p, []),
+    "vdm_abi_version": (_i, []),
+    "vdm_device_info": (_i, [_i, C.POINTER(_i), C.POINTER(_i), C.c_char_p]),
+    "vdm_conv_packed_bytes": (_sz, [_D, _i]),
+    "vdm_conv_pack_weights": (_i, [_D, _i, _p, _p, _p]),
+    "vdm_conv_fwd": (_i, [_D, _p, _p, _p, _p, _i64, _p, _p, _p]),
+    "vdm_conv_dgrad": (_i, [_D, _p, _p, _p, _p, _p]),
+    "vdm_conv_wgrad_workspace_bytes": (_sz, [_D]),
+    "vdm_conv_wgrad": (_i, [_D, _p, _p, _p, _i, _p, _sz, _p]),
+    "vdm_gn_stats": (_i, [_p, _i, _p, _i, _i, _i64, _i, _i, _p, _p, _p]),
+    "vdm_gn_silu_fwd": (_i, [_p, _i, _p, _i, _i, _i64, _i, _i, _p, _p, _p, _f, _f, _u64, _p, _p]),
+    "vdm_gn_silu_bwd": (_i, [_p, _i, _p, _i, _i, _i64, _i, _i, _p, _p, _p, _f, _f, _u64, _p, _p, _p, _p, _p, _p, _p, _p, _i64, _p, _p]),
+    "vdm_colsum": (_i, [_p, _i, _i64, _i, _i, _p, _i64, _p]),
+    "vdm_dilate2": (_i, [_p, _p, _i, _i, _i, _i, _i, _i, _p]),
+    "vdm_pool2_sum": (_i, [_p, _p, _i, _i, _i, _i, _i, _i, _p]),
+    "vdm_cast": (_i, [_p, _i, _p, _i, _i64, _p]),
+    "vdm_pack_input": (_i, [_p, _p, _i64, _i, _i, _p, _p]),
+    "vdm_diffuse": (_i, [_p, _p, _p, _p, _i, _i64, _p, _p]),
+    "vdm_loss_terms": (_i, [_p, _p, _p, _p, _f, _p, _i, _i64, _p, _p, _p]),
+    "vdm_ancestral_step": (_i, [_p, _p, _p, _p, _p, _u64, _i64, _p]),
+    "vdm_randn": (_i, [_p, _i64, _u64, _u64, _p]),
+    "vdm_step_inc": (_i, [_p, _p]),
+    "vdm_sumsq": (_i, [_p, _i64, _p, _p]),
+}
+
+
+class VdmError(RuntimeError):
+    pass
+
+
+_lib = None
+
+
+def build(force=False):
+    """Compile libvdm4cdm_hip.so in-tree with hipcc --offload-arch=gfx950."""
+    if force:
+        subprocess.check_call(["make", "-C", CSRC, "clean"])
+    subprocess.check_call(["make", "-C", CSRC, "-j4"])
+    return LIB_PATH
+
+
+def lib():
+    """Load the shared object (once) and type its entry points.  Raises if it is not built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise VdmError(
+            f"{LIB_PATH} is missing: the HIP extension is not built. Run `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(or `make -C vdm4cdm_amd/csrc`). There is no CPU fallback for the HIP backend.")
+    handle = C.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(handle, name)          # AttributeError if the library lacks a declared symbol
+        fn.restype = res
+        fn.argtypes = args
+    ver = handle.vdm_abi_version()
+    if ver != 1:
+        raise VdmError(f"libvdm4cdm_hip.so ABI version {ver} != 1")
+    _lib = handle
+    return _lib
+
+
+def check(status, what=""):
+    if status != 0:
+        msg = lib().vdm_last_error().decode("utf-8", "replace")
+        raise VdmError(f"{what} failed with status {status}: {msg}")

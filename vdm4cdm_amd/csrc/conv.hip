@@ -48,6 +48,7 @@ struct ConvArgs {
     const void* w;       // packed weights
     const float* bias;
     const float* nbias;
+    long long nbias_stride;
     const void* res;
     void* out;
     int N, Dz, Dy, Dx;   // output spatial dims
@@ -62,7 +63,9 @@ struct ConvArgs {
 // halo voxel index -> LDS byte offset of piece pc
 template <int PLANE, int ODD_OFF>
 __device__ __forceinline__ int lds_off(int pc, int hv) {
-    return pc * PLANE + (pc & 1) * ODD_OFF + hv * 16;
+    // ODD_OFF = 128 shifts odd pieces by half a 256-B bank row (conflict-free transposed reads in wgrad);
+    // the shift is folded into the plane stride so that planes never overlap.
+    return pc * (PLANE + ODD_OFF) + hv * 16;
 }
 
 __device__ __forceinline__ int wrap(int i, int n) {
@@ -221,7 +224,7 @@ __global__ void __launch_bounds__(256, 2) conv_fwd_kernel(const ConvArgs a) {
         float bv = 0.f;
         if (cbase + j < a.Cout) {
             if (a.bias) bv += a.bias[cbase + j];
-            if (a.nbias) bv += a.nbias[(size_t)n * a.Cout + cbase + j];
+            if (a.nbias) bv += a.nbias[(size_t)n * a.nbias_stride + cbase + j];
         }
         badd[j] = bv;
     }
@@ -314,7 +317,7 @@ struct TrFetch<bf16_t, PLANE> {
         const int g = lane >> 4, li = lane & 15, qp = li >> 2, p = li & 3;
         const int pc = 2 * ct + (p >> 1);
         const int xo = (4 * g + qp) * xs;
-        const int base = pc * PLANE + (pc & 1) * 128 + (p & 1) * 8;
+        const int base = pc * (PLANE + 128) + (p & 1) * 8;
         typedef __attribute__((address_space(3))) s16x4* lptr;
         const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lptr)(lds + base + (vox0 + xo) * 16));
         const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lptr)(lds + base + (vox1 + xo) * 16));
@@ -329,7 +332,7 @@ struct TrFetch<float, PLANE> {
         (void)ct; (void)vox1;
         const int m = lane & 15, kq = lane >> 4;
         const int pc = m >> 2;
-        const int base = pc * PLANE + (pc & 1) * 128 + (m & 3) * 4;
+        const int base = pc * (PLANE + 128) + (m & 3) * 4;
         uint4 r;
         r.x = *reinterpret_cast<const uint32_t*>(lds + base + (vox0 + (0 + kq) * xs) * 16);
         r.y = *reinterpret_cast<const uint32_t*>(lds + base + (vox0 + (4 + kq) * xs) * 16);
@@ -346,7 +349,7 @@ __global__ void __launch_bounds__(256, 1) conv_wgrad_kernel(const WgradArgs w) {
     constexpr int TAPS = G::TAPS;
     constexpr int TPW = (TAPS + 3) / 4;                    // taps per wave (KS=3: 7; KS=1: 1)
     constexpr int RSTEP = (sizeof(T) == 2) ? 2 : 1;        // rows consumed per k-step
-    constexpr int IN_BYTES = 4 * G::PLANE + 128;
+    constexpr int IN_BYTES = 4 * (G::PLANE + 128);
     extern __shared__ __attribute__((aligned(16))) char lds[];
     char* lds_in = lds;
     char* lds_do = lds + IN_BYTES;
@@ -599,7 +602,7 @@ static int launch_wgrad_cfg(WgradArgs w, float* dw, int accumulate, int cout, in
     const int per_wg = (G::TAPS > 1) ? 1 : 4;
     const size_t need = (size_t)npairs * P * per_wg * G::TAPS * CL * CL * sizeof(float);
     if (need > ws_bytes) { set_error("conv_wgrad: workspace too small (%zu < %zu)", ws_bytes, need); return VDM_ERR_ARG; }
-    const size_t lds = 4 * (size_t)G::PLANE + 128 + 4 * (size_t)G::OPLANE + 128;
+    const size_t lds = 4 * ((size_t)G::PLANE + 128) + 4 * ((size_t)G::OPLANE + 128);
     auto kern = conv_wgrad_kernel<T, KS, STRIDE, UPS, TZ, TY>;
     static bool attr_done = false;
     if (!attr_done) {
@@ -663,27 +666,28 @@ extern "C" int vdm_conv_pack_weights(const vdm_conv_desc* d, int pack_mode, cons
 }
 
 extern "C" int vdm_conv_fwd(const vdm_conv_desc* d, const void* x, const void* w_packed, const float* bias, const float* nbias,
-                            const void* residual, void* out, void* stream) {
+                            int64_t nbias_stride, const void* residual, void* out, void* stream) {
     int e = validate(d);
     if (e) return e;
     VDM_REQUIRE(x && w_packed && out, "conv_fwd: NULL pointer");
     const Plan p = plan_of(d, 0);
     ConvArgs a{};
-    a.x = x; a.w = w_packed; a.bias = bias; a.nbias = nbias; a.res = residual; a.out = out;
+    a.x = x; a.w = w_packed; a.bias = bias; a.nbias = nbias; a.nbias_stride = nbias_stride; a.res = residual; a.out = out;
     fill_dims(a, d);
     a.Cin = d->cin; a.CinStride = cpad(d->cin, d->dtype); a.Cout = d->cout;
     a.nchunks = p.nchunks; a.nkb = p.nkb;
     return launch_fwd(a, d->dtype, d->out_f32, d->ksize, d->stride, d->upsample, p.nc, (hipStream_t)stream);
 }
 
-extern "C" int vdm_conv_dgrad(const vdm_conv_desc* d, const void* dout, const void* w_packed_dgrad, void* dx, void* stream) {
+extern "C" int vdm_conv_dgrad(const vdm_conv_desc* d, const void* dout, const void* w_packed_dgrad, const void* residual, void* dx,
+                              void* stream) {
     int e = validate(d);
     if (e) return e;
     VDM_REQUIRE(dout && w_packed_dgrad && dx, "conv_dgrad: NULL pointer");
     VDM_REQUIRE(d->stride == 1, "conv_dgrad: stride-2 convs are differentiated via vdm_dilate2 + a stride-1 dgrad");
     const Plan p = plan_of(d, 1);
     ConvArgs a{};
-    a.x = dout; a.w = w_packed_dgrad; a.out = dx;
+    a.x = dout; a.w = w_packed_dgrad; a.res = residual; a.out = dx;
     a.N = d->n; a.Dz = d->od; a.Dy = d->oh; a.Dx = d->ow;
     a.Iz = a.Sz = d->od; a.Iy = a.Sy = d->oh; a.Ix = a.Sx = d->ow;       // dgrad runs on the output grid
     a.circular = d->pad_mode == VDM_PAD_CIRCULAR;

@@ -39,7 +39,7 @@ __device__ __forceinline__ void block_sum(float (&v)[NVAL], float* smem /* >= 4*
 // ---------------------------------------------------------------------------------------------
 template <typename T>
 __global__ void __launch_bounds__(256) gn_stats_kernel(const T* __restrict__ x, int C, int64_t V, int gs, int G, int g0,
-                                                      float* __restrict__ stats, int blocks_per_n) {
+                                                      float* __restrict__ partial, int blocks_per_n) {
     constexpr int EPL = DT<T>::EPL;
     const int n = blockIdx.x / blocks_per_n, bn = blockIdx.x % blocks_per_n;
     const int PPV = C / EPL;                       // pieces per voxel
@@ -59,28 +59,51 @@ __global__ void __launch_bounds__(256) gn_stats_kernel(const T* __restrict__ x, 
 #pragma unroll
         for (int j = 0; j < EPL; ++j) { s[j] += p.f[j]; ss[j] += p.f[j] * p.f[j]; }
     }
-    // fold the EPL channels of the piece into groups; groups of a piece: (pc*EPL + j) / gs
-    __shared__ float sh[2 * 64];                   // up to 64 groups
-    for (int i = threadIdx.x; i < 2 * G; i += 256) sh[i] = 0.f;
-    __syncthreads();
-    if (gs >= EPL) {                               // whole piece in one group
-        float a = 0.f, b = 0.f;
+    // Fixed-order block reduction (no float atomics: the forward pass must be bit-reproducible).
+    // Every thread parks its per-channel sums in LDS; thread e < 2G then walks the 256 entries in order.
+    __shared__ float sm[256 * EPL * 2];
+    __shared__ float sh[2 * 64];
 #pragma unroll
-        for (int j = 0; j < EPL; ++j) { a += s[j]; b += ss[j]; }
-        const int g = g0 + (pc * EPL) / gs;
-        atomicAdd(&sh[2 * g], a);
-        atomicAdd(&sh[2 * g + 1], b);
-    } else {
-#pragma unroll
-        for (int j = 0; j < EPL; ++j) {
-            const int g = g0 + (pc * EPL + j) / gs;
-            atomicAdd(&sh[2 * g], s[j]);
-            atomicAdd(&sh[2 * g + 1], ss[j]);
-        }
+    for (int j = 0; j < EPL; ++j) {
+        sm[(threadIdx.x * EPL + j) * 2] = s[j];
+        sm[(threadIdx.x * EPL + j) * 2 + 1] = ss[j];
     }
     __syncthreads();
-    for (int i = threadIdx.x; i < 2 * G; i += 256)
-        if (sh[i] != 0.f) atomicAdd(&stats[(size_t)n * 2 * G + i], sh[i]);
+    if ((int)threadIdx.x < 2 * G) {
+        const int g = (int)threadIdx.x >> 1, which = threadIdx.x & 1;
+        float acc = 0.f;
+        for (int t = 0; t < 256; ++t) {
+            const int pct = (int)(((int64_t)bn * 256 + t) % PPV);
+            const int c0 = pct * EPL;
+            if (g0 + c0 / gs > g || g0 + (c0 + EPL - 1) / gs < g) continue;
+#pragma unroll
+            for (int j = 0; j < EPL; ++j)
+                if (g0 + (c0 + j) / gs == g) acc += sm[(t * EPL + j) * 2 + which];
+        }
+        sh[threadIdx.x] = acc;
+    }
+    __syncthreads();
+    // per-block partials; gn_stats_finalize_kernel sums them in a fixed order (bit-reproducible forward)
+    for (int i = threadIdx.x; i < 2 * G; i += 256) partial[((size_t)n * blocks_per_n + bn) * 2 * G + i] = sh[i];
+}
+
+// stats[n][g][0..1] = sum over blocks of partial, groups [g0, g0+gc) only.  One block per sample.
+__global__ void __launch_bounds__(256) gn_stats_finalize_kernel(const float* __restrict__ partial, int G, int g0, int gc,
+                                                               int blocks_per_n, float* __restrict__ stats) {
+    const int n = blockIdx.x;
+    __shared__ float sm[256];
+    for (int e = 2 * g0; e < 2 * (g0 + gc); ++e) {
+        float s = 0.f;
+        for (int b = threadIdx.x; b < blocks_per_n; b += 256) s += partial[((size_t)n * blocks_per_n + b) * 2 * G + e];
+        sm[threadIdx.x] = s;
+        __syncthreads();
+        for (int o = 128; o > 0; o >>= 1) {
+            if ((int)threadIdx.x < o) sm[threadIdx.x] += sm[threadIdx.x + o];
+            __syncthreads();
+        }
+        if (threadIdx.x == 0) stats[(size_t)n * 2 * G + e] = sm[0];
+        __syncthreads();
+    }
 }
 
 // per-(n, channel) affine of GN: y = x * A + B with A = rstd*gamma, B = beta - mean*rstd*gamma
@@ -105,7 +128,8 @@ struct GnArgs {
     float eps, p;
     uint64_t seed;
     void* y;                 // fwd out
-    const void* dy; const void* add; void* dx1; void* dx2;       // bwd
+    const void* dy; const void* add1; const void* add2; void* dx1; void* dx2;       // bwd
+    long long colsum_stride;
     float* dgamma; float* dbeta; float* colsum; float* red;
     int blocks_per_n;
 };
@@ -232,6 +256,12 @@ __global__ void __launch_bounds__(256) gn_silu_bwd_reduce_kernel(const GnArgs a)
     for (int i = threadIdx.x; i < 2 * a.G; i += 256) atomicAdd(&a.red[(size_t)n * 2 * a.G + i], shg[i]);
 }
 
+__device__ __forceinline__ bool pc_is_first(const GnArgs& a, int epl, int bid, int tid) {
+    const int ppv = (a.c1 + a.c2) / epl;
+    const long long start = (long long)(bid % a.blocks_per_n) * 256 + tid;
+    return (int)(start % ppv) < a.c1 / epl;
+}
+
 // pass 2: dx = rstd * (gamma*dyh - m1 - xhat*m2) (+ add), m1 = red0/cnt, m2 = red1/cnt ; colsum[n][c] += sum_v dx
 template <typename T>
 __global__ void __launch_bounds__(256) gn_silu_bwd_apply_kernel(const GnArgs a) {
@@ -244,7 +274,9 @@ __global__ void __launch_bounds__(256) gn_silu_bwd_apply_kernel(const GnArgs a) 
     const T* x1 = reinterpret_cast<const T*>(a.x1) + (size_t)n * a.V * a.c1;
     const T* x2 = a.x2 ? reinterpret_cast<const T*>(a.x2) + (size_t)n * a.V * a.c2 : nullptr;
     const T* dy = reinterpret_cast<const T*>(a.dy) + (size_t)n * a.V * C;
-    const T* add = a.add ? reinterpret_cast<const T*>(a.add) + (size_t)n * a.V * C : nullptr;
+    const T* add1 = a.add1 ? reinterpret_cast<const T*>(a.add1) + (size_t)n * a.V * a.c1 : nullptr;
+    const T* add2 = a.add2 ? reinterpret_cast<const T*>(a.add2) + (size_t)n * a.V * a.c2 : nullptr;
+    const T* addp = pc_is_first(a, DT<T>::EPL, blockIdx.x, threadIdx.x) ? add1 : add2;
     T* dx1 = reinterpret_cast<T*>(a.dx1) + (size_t)n * a.V * a.c1;
     T* dx2 = a.dx2 ? reinterpret_cast<T*>(a.dx2) + (size_t)n * a.V * a.c2 : nullptr;
     const bool drop = a.p > 0.f;
@@ -268,7 +300,8 @@ __global__ void __launch_bounds__(256) gn_silu_bwd_apply_kernel(const GnArgs a) 
         Piece<T> px, pd, pa;
         px.load(raw);
         pd.load(*reinterpret_cast<const uint4*>(dy + i * EPL));
-        if (add) pa.load(*reinterpret_cast<const uint4*>(add + i * EPL));
+        if (addp) pa.load(pc < P1 ? *reinterpret_cast<const uint4*>(addp + v * a.c1 + pc * EPL)
+                                  : *reinterpret_cast<const uint4*>(addp + v * a.c2 + (pc - P1) * EPL));
         uint32_t rnd[4];
 #pragma unroll
         for (int j = 0; j < EPL; ++j) {
@@ -282,7 +315,7 @@ __global__ void __launch_bounds__(256) gn_silu_bwd_apply_kernel(const GnArgs a) 
             }
             const float xh = (px.f[j] - mean[j]) * rstd[j];
             float o = rstd[j] * (gam[j] * d - m1[j] - xh * m2[j]);
-            if (add) o += pa.f[j];
+            if (addp) o += pa.f[j];
             px.f[j] = o;
             cs[j] += o;
         }
@@ -298,14 +331,14 @@ __global__ void __launch_bounds__(256) gn_silu_bwd_apply_kernel(const GnArgs a) 
 #pragma unroll
         for (int j = 0; j < EPL; ++j) atomicAdd(&shc[pc * EPL + j], cs[j]);
         __syncthreads();
-        for (int i = threadIdx.x; i < C; i += 256) atomicAdd(&a.colsum[(size_t)n * C + i], shc[i]);
+        for (int i = threadIdx.x; i < C; i += 256) atomicAdd(&a.colsum[(size_t)n * a.colsum_stride + i], shc[i]);
     }
 }
 
 // out[n][c] += sum_v x[n][v][c]
 template <typename T>
 __global__ void __launch_bounds__(256) colsum_kernel(const T* __restrict__ x, int C, int64_t V, float* __restrict__ out,
-                                                    int blocks_per_n) {
+                                                    long long out_stride, int blocks_per_n) {
     constexpr int EPL = DT<T>::EPL;
     const int PPV = C / EPL;
     const int n = blockIdx.x / blocks_per_n, bn = blockIdx.x % blocks_per_n;
@@ -328,7 +361,7 @@ __global__ void __launch_bounds__(256) colsum_kernel(const T* __restrict__ x, in
 #pragma unroll
     for (int j = 0; j < EPL; ++j) atomicAdd(&shc[pc * EPL + j], s[j]);
     __syncthreads();
-    for (int i = threadIdx.x; i < C; i += 256) atomicAdd(&out[(size_t)n * C + i], shc[i]);
+    for (int i = threadIdx.x; i < C; i += 256) atomicAdd(&out[(size_t)n * out_stride + i], shc[i]);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -548,13 +581,11 @@ static int gn_common_check(int c1, int c2, int n, int64_t voxels, int groups, in
 }
 
 extern "C" int vdm_gn_stats(const void* x1, int c1, const void* x2, int c2, int n, int64_t voxels, int groups, int dtype, float* stats,
-                            void* stream) {
+                            float* workspace, void* stream) {
     int e = gn_common_check(c1, c2, n, voxels, groups, dtype, "gn_stats");
     if (e) return e;
-    VDM_REQUIRE(x1 && stats && (c2 == 0 || x2), "gn_stats: NULL pointer");
+    VDM_REQUIRE(x1 && stats && workspace && (c2 == 0 || x2), "gn_stats: NULL pointer");
     hipStream_t s = (hipStream_t)stream;
-    e = check_hip(hipMemsetAsync(stats, 0, sizeof(float) * 2 * groups * n, s), "hipMemsetAsync(stats)");
-    if (e) return e;
     const int epl = dtype == VDM_F32 ? 4 : 8;
     const int gs = (c1 + c2) / groups;
     const void* xs[2] = {x1, x2};
@@ -565,9 +596,10 @@ extern "C" int vdm_gn_stats(const void* x1, int c1, const void* x2, int c2, int 
         const int ppv = cs[k] / epl;
         const int bpn = blocks_per_sample(voxels * ppv, ppv, n);
         if (dtype == VDM_F32)
-            hipLaunchKernelGGL(gn_stats_kernel<float>, dim3(bpn * n), dim3(256), 0, s, (const float*)xs[k], cs[k], voxels, gs, groups, g0, stats, bpn);
+            hipLaunchKernelGGL(gn_stats_kernel<float>, dim3(bpn * n), dim3(256), 0, s, (const float*)xs[k], cs[k], voxels, gs, groups, g0, workspace, bpn);
         else
-            hipLaunchKernelGGL(gn_stats_kernel<bf16_t>, dim3(bpn * n), dim3(256), 0, s, (const bf16_t*)xs[k], cs[k], voxels, gs, groups, g0, stats, bpn);
+            hipLaunchKernelGGL(gn_stats_kernel<bf16_t>, dim3(bpn * n), dim3(256), 0, s, (const bf16_t*)xs[k], cs[k], voxels, gs, groups, g0, workspace, bpn);
+        hipLaunchKernelGGL(gn_stats_finalize_kernel, dim3(n), dim3(256), 0, s, (const float*)workspace, groups, g0, cs[k] / gs, bpn, stats);
         VDM_LAUNCH_CHECK("gn_stats_kernel");
         g0 += cs[k] / gs;
     }
@@ -605,13 +637,13 @@ extern "C" int vdm_gn_silu_fwd(const void* x1, int c1, const void* x2, int c2, i
 
 extern "C" int vdm_gn_silu_bwd(const void* x1, int c1, const void* x2, int c2, int n, int64_t voxels, int groups, int dtype,
                                const float* stats, const float* gamma, const float* beta, float eps, float dropout_p, uint64_t seed,
-                               const void* dy, const void* add, void* dx1, void* dx2, float* dgamma, float* dbeta, float* colsum,
-                               float* red_ws, void* stream) {
+                               const void* dy, const void* add1, const void* add2, void* dx1, void* dx2, float* dgamma, float* dbeta,
+                               float* colsum, int64_t colsum_stride, float* red_ws, void* stream) {
     int e = gn_common_check(c1, c2, n, voxels, groups, dtype, "gn_silu_bwd");
     if (e) return e;
     VDM_REQUIRE(x1 && stats && gamma && beta && dy && dx1 && dgamma && dbeta && red_ws && (c2 == 0 || (x2 && dx2)), "gn_silu_bwd: NULL pointer");
     GnArgs a = gn_args(x1, c1, x2, c2, n, voxels, groups, dtype, stats, gamma, beta, eps, dropout_p, seed);
-    a.dy = dy; a.add = add; a.dx1 = dx1; a.dx2 = dx2; a.dgamma = dgamma; a.dbeta = dbeta; a.colsum = colsum; a.red = red_ws;
+    a.dy = dy; a.add1 = add1; a.add2 = add2; a.colsum_stride = colsum_stride; a.dx1 = dx1; a.dx2 = dx2; a.dgamma = dgamma; a.dbeta = dbeta; a.colsum = colsum; a.red = red_ws;
     hipStream_t s = (hipStream_t)stream;
     e = check_hip(hipMemsetAsync(red_ws, 0, sizeof(float) * 2 * groups * n, s), "hipMemsetAsync(red_ws)");
     if (e) return e;
@@ -626,16 +658,16 @@ extern "C" int vdm_gn_silu_bwd(const void* x1, int c1, const void* x2, int c2, i
     return VDM_OK;
 }
 
-extern "C" int vdm_colsum(const void* x, int n, int64_t voxels, int c, int dtype, float* out, void* stream) {
+extern "C" int vdm_colsum(const void* x, int n, int64_t voxels, int c, int dtype, float* out, int64_t out_stride, void* stream) {
     const int epl = dtype == VDM_F32 ? 4 : 8;
     VDM_REQUIRE(x && out && n > 0 && voxels > 0 && c > 0 && c <= 512 && c % epl == 0, "colsum: bad arguments (c=%d)", c);
     const int ppv = c / epl;
     const int bpn = blocks_per_sample(voxels * ppv, ppv, n);
     hipStream_t s = (hipStream_t)stream;
     if (dtype == VDM_F32)
-        hipLaunchKernelGGL(colsum_kernel<float>, dim3(bpn * n), dim3(256), 0, s, (const float*)x, c, voxels, out, bpn);
+        hipLaunchKernelGGL(colsum_kernel<float>, dim3(bpn * n), dim3(256), 0, s, (const float*)x, c, voxels, out, (long long)out_stride, bpn);
     else
-        hipLaunchKernelGGL(colsum_kernel<bf16_t>, dim3(bpn * n), dim3(256), 0, s, (const bf16_t*)x, c, voxels, out, bpn);
+        hipLaunchKernelGGL(colsum_kernel<bf16_t>, dim3(bpn * n), dim3(256), 0, s, (const bf16_t*)x, c, voxels, out, (long long)out_stride, bpn);
     VDM_LAUNCH_CHECK("colsum_kernel");
     return VDM_OK;
 }

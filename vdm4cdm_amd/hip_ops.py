@@ -1,0 +1,290 @@
+"""Typed wrappers over the C-ABI: torch tensors in, kernels enqueued on torch's current HIP stream.
+
+torch is used here only for device memory and streams (``Tensor.data_ptr()``,
+``torch.cuda.current_stream()``); no torch compute op runs on activations in this module.
+Activations are NDHWC tensors ``[N, D, H, W, C]`` (fp32 or bf16).
+"""
+import ctypes as C
+
+import torch
+
+from . import _lib
+from ._lib import ConvDesc, PACK_DGRAD, PACK_FWD, VDM_BF16, VDM_F32, check
+
+GN_EPS = 1e-5
+
+
+def dt_id(dtype):
+    if dtype == torch.float32:
+        return VDM_F32
+    if dtype == torch.bfloat16:
+        return VDM_BF16
+    raise ValueError(f"unsupported activation dtype {dtype}")
+
+
+def epl(dtype):
+    """elements per 16-byte piece"""
+    return 4 if dtype == torch.float32 else 8
+
+
+def cpad(c, dtype):
+    e = epl(dtype)
+    return (c + e - 1) // e * e
+
+
+def _s():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _p(t):
+    if t is None:
+        return None
+    assert t.is_cuda, "HIP ops need device tensors"
+    return t.data_ptr()
+
+
+def _contig(*ts):
+    for t in ts:
+        if t is not None:
+            assert t.is_contiguous(), "HIP ops need contiguous tensors"
+
+
+class Conv:
+    """One convolution layer: descriptor factory + packed-weight buffers (fwd / dgrad order)."""
+
+    _ws = {}          # device -> shared wgrad workspace (uint8 tensor)
+
+    def __init__(self, cin, cout, ksize=3, stride=1, upsample=0, circular=False, out_f32=False):
+        self.cin, self.cout, self.ksize, self.stride, self.upsample = cin, cout, ksize, stride, upsample
+        self.circular, self.out_f32 = circular, out_f32
+        self.wf = self.wd = None
+        self._descs = {}
+
+    def desc(self, n, od, oh, ow, dtype, stride=None):
+        st = self.stride if stride is None else stride
+        key = (n, od, oh, ow, dtype, st)
+        d = self._descs.get(key)
+        if d is None:
+            d = ConvDesc(n=n, od=od, oh=oh, ow=ow, cin=self.cin, cout=self.cout, ksize=self.ksize, stride=st,
+                         upsample=self.upsample, pad_mode=1 if self.circular else 0, dtype=dt_id(dtype),
+                         out_f32=1 if (self.out_f32 and st == self.stride) else 0)
+            self._descs[key] = d
+        return d
+
+    def pack(self, w_master, dtype, need_dgrad):
+        """w_master: fp32 [taps, cout, cin] (a view into the flat parameter vector)."""
+        L = _lib.lib()
+        d = self.desc(1, 2, 2, 2, dtype, stride=1 if self.stride == 2 else None)
+        assert w_master.dtype == torch.float32 and w_master.is_contiguous()
+        assert w_master.numel() == self.ksize ** 3 * self.cout * self.cin
+        if self.wf is None or self.wf.device != w_master.device or self._packed_dtype != dtype:
+            self.wf = torch.empty(L.vdm_conv_packed_bytes(d, PACK_FWD), dtype=torch.uint8, device=w_master.device)
+            self.wd = None
+            self._packed_dtype = dtype
+        check(L.vdm_conv_pack_weights(d, PACK_FWD, _p(w_master), _p(self.wf), _s()), "vdm_conv_pack_weights(fwd)")
+        if need_dgrad:
+            if self.wd is None:
+                self.wd = torch.empty(L.vdm_conv_packed_bytes(d, PACK_DGRAD), dtype=torch.uint8, device=w_master.device)
+            check(L.vdm_conv_pack_weights(d, PACK_DGRAD, _p(w_master), _p(self.wd), _s()), "vdm_conv_pack_weights(dgrad)")
+
+    def out_shape(self, x):
+        n, d, h, w, _ = x.shape
+        if self.stride == 2:
+            return (n, d // 2, h // 2, w // 2, self.cout)
+        if self.upsample:
+            return (n, 2 * d, 2 * h, 2 * w, self.cout)
+        return (n, d, h, w, self.cout)
+
+    def fwd(self, x, bias=None, nbias=None, residual=None, out=None):
+        """out = conv(x) + bias + nbias[n] + residual.  nbias: fp32 [N, >=cout] view (row stride honoured)."""
+        L = _lib.lib()
+        _contig(x, bias, residual)
+        assert x.shape[-1] == cpad(self.cin, x.dtype), f"conv input must have {cpad(self.cin, x.dtype)} channels, got {x.shape[-1]}"
+        shp = self.out_shape(x)
+        if out is None:
+            out = torch.empty(shp, dtype=torch.float32 if self.out_f32 else x.dtype, device=x.device)
+        assert tuple(out.shape) == shp and out.is_contiguous()
+        nstride = 0
+        if nbias is not None:
+            assert nbias.dtype == torch.float32 and nbias.stride(1) == 1 and nbias.shape[0] == x.shape[0]
+            nstride = nbias.stride(0)
+        if residual is not None:
+            assert residual.shape == out.shape and residual.dtype == x.dtype
+        d = self.desc(shp[0], shp[1], shp[2], shp[3], x.dtype)
+        check(L.vdm_conv_fwd(d, _p(x), _p(self.wf), _p(bias), _p(nbias), nstride, _p(residual), _p(out), _s()), "vdm_conv_fwd")
+        return out
+
+    def dgrad(self, dout, residual=None, out=None):
+        """Gradient w.r.t. the conv input grid at OUTPUT resolution for stride 1 (up-sampling convs: pool
+        afterwards).  For the stride-2 conv, `dout` must already be zero-dilated to the fine grid."""
+        L = _lib.lib()
+        _contig(dout, residual)
+        n, od, oh, ow, c = dout.shape
+        assert c == cpad(self.cout, dout.dtype)
+        if out is None:
+            out = torch.empty((n, od, oh, ow, self.cin), dtype=dout.dtype, device=dout.device)
+        d = self.desc(n, od, oh, ow, dout.dtype, stride=1)
+        check(L.vdm_conv_dgrad(d, _p(dout), _p(self.wd), _p(residual), _p(out), _s()), "vdm_conv_dgrad")
+        return out
+
+    def wgrad(self, x, dout, dw, accumulate=False):
+        """dw (fp32 view [taps, cout, cin]) = sum_v dout[v] (x) x[v + tap]."""
+        L = _lib.lib()
+        _contig(x, dout, dw)
+        n, od, oh, ow, c = dout.shape
+        assert c == cpad(self.cout, dout.dtype) and x.shape[-1] == cpad(self.cin, x.dtype)
+        d = self.desc(n, od, oh, ow, x.dtype)
+        need = L.vdm_conv_wgrad_workspace_bytes(d)
+        ws = Conv._ws.get(x.device)
+        if ws is None or ws.numel() < need:
+            ws = torch.empty(max(need, 32 << 20), dtype=torch.uint8, device=x.device)
+            Conv._ws[x.device] = ws
+        check(L.vdm_conv_wgrad(d, _p(x), _p(dout), _p(dw), 1 if accumulate else 0, _p(ws), ws.numel(), _s()), "vdm_conv_wgrad")
+        return dw
+
+
+def _nv(x):
+    n = x.shape[0]
+    return n, x.numel() // (n * x.shape[-1])
+
+
+_gn_ws = {}
+
+
+def gn_stats(x1, x2, groups, out=None):
+    L = _lib.lib()
+    _contig(x1, x2)
+    n, v = _nv(x1)
+    if out is None:
+        out = torch.empty((n, groups, 2), dtype=torch.float32, device=x1.device)
+    ws = _gn_ws.get(x1.device)
+    if ws is None:
+        ws = _gn_ws[x1.device] = torch.empty(_lib.GN_STATS_WS_BYTES // 4, dtype=torch.float32, device=x1.device)
+    c2 = 0 if x2 is None else x2.shape[-1]
+    check(L.vdm_gn_stats(_p(x1), x1.shape[-1], _p(x2), c2, n, v, groups, dt_id(x1.dtype), _p(out), _p(ws), _s()), "vdm_gn_stats")
+    return out
+
+
+def gn_silu_fwd(x1, x2, groups, stats, gamma, beta, dropout_p=0.0, seed=0, out=None):
+    L = _lib.lib()
+    _contig(x1, x2, gamma, beta, stats)
+    n, v = _nv(x1)
+    c1 = x1.shape[-1]
+    c2 = 0 if x2 is None else x2.shape[-1]
+    if out is None:
+        out = torch.empty(x1.shape[:-1] + (c1 + c2,), dtype=x1.dtype, device=x1.device)
+    check(L.vdm_gn_silu_fwd(_p(x1), c1, _p(x2), c2, n, v, groups, dt_id(x1.dtype), _p(stats), _p(gamma), _p(beta), GN_EPS,
+                            float(dropout_p), int(seed), _p(out), _s()), "vdm_gn_silu_fwd")
+    return out
+
+
+def gn_silu_bwd(x1, x2, groups, stats, gamma, beta, dy, dgamma, dbeta, add1=None, add2=None, colsum=None,
+                dropout_p=0.0, seed=0, dx1=None, dx2=None):
+    """Returns (dx1, dx2).  dgamma / dbeta / colsum are accumulated into (caller zeroes)."""
+    L = _lib.lib()
+    _contig(x1, x2, dy, add1, add2, gamma, beta, dgamma, dbeta)
+    n, v = _nv(x1)
+    c1 = x1.shape[-1]
+    c2 = 0 if x2 is None else x2.shape[-1]
+    if dx1 is None:
+        dx1 = torch.empty_like(x1)
+    if x2 is not None and dx2 is None:
+        dx2 = torch.empty_like(x2)
+    red = torch.empty((n, groups, 2), dtype=torch.float32, device=x1.device)
+    cstride = 0
+    if colsum is not None:
+        assert colsum.dtype == torch.float32 and colsum.stride(1) == 1 and colsum.shape[0] == n
+        cstride = colsum.stride(0)
+    check(L.vdm_gn_silu_bwd(_p(x1), c1, _p(x2), c2, n, v, groups, dt_id(x1.dtype), _p(stats), _p(gamma), _p(beta), GN_EPS,
+                            float(dropout_p), int(seed), _p(dy), _p(add1), _p(add2), _p(dx1), _p(dx2), _p(dgamma), _p(dbeta),
+                            _p(colsum), cstride, _p(red), _s()), "vdm_gn_silu_bwd")
+    return dx1, dx2
+
+
+def colsum(x, out, out_stride=None):
+    """out[n*out_stride + c] += sum over voxels of x[n, ..., c].  out: fp32 [N, >=c] view (row stride honoured),
+    or with out_stride=0 a [c] vector that receives the sum over samples too (bias gradients)."""
+    L = _lib.lib()
+    _contig(x)
+    n, v = _nv(x)
+    assert out.dtype == torch.float32
+    if out_stride is None:
+        assert out.dim() == 2 and out.stride(1) == 1 and out.shape[0] == n
+        out_stride = out.stride(0)
+    check(L.vdm_colsum(_p(x), n, v, x.shape[-1], dt_id(x.dtype), _p(out), out_stride, _s()), "vdm_colsum")
+    return out
+
+
+def dilate2(coarse):
+    L = _lib.lib()
+    _contig(coarse)
+    n, d, h, w, c = coarse.shape
+    fine = torch.empty((n, 2 * d, 2 * h, 2 * w, c), dtype=coarse.dtype, device=coarse.device)
+    check(L.vdm_dilate2(_p(coarse), _p(fine), n, d, h, w, c, dt_id(coarse.dtype), _s()), "vdm_dilate2")
+    return fine
+
+
+def pool2_sum(fine):
+    L = _lib.lib()
+    _contig(fine)
+    n, d, h, w, c = fine.shape
+    coarse = torch.empty((n, d // 2, h // 2, w // 2, c), dtype=fine.dtype, device=fine.device)
+    check(L.vdm_pool2_sum(_p(fine), _p(coarse), n, d // 2, h // 2, w // 2, c, dt_id(fine.dtype), _s()), "vdm_pool2_sum")
+    return coarse
+
+
+def pack_input(a, b, dtype, out=None):
+    """[N, D, H, W] fp32 (+ optional second channel) -> NDHWC [N, D, H, W, cpad(2)] of `dtype`, zero padded."""
+    L = _lib.lib()
+    _contig(a, b)
+    assert a.dtype == torch.float32 and (b is None or (b.dtype == torch.float32 and b.shape == a.shape))
+    cp = cpad(2, dtype)
+    if out is None:
+        out = torch.empty(tuple(a.shape) + (cp,), dtype=dtype, device=a.device)
+    check(L.vdm_pack_input(_p(a), _p(b), a.numel(), cp, dt_id(dtype), _p(out), _s()), "vdm_pack_input")
+    return out
+
+
+def diffuse(x, eps, alpha, sigma, out=None):
+    L = _lib.lib()
+    _contig(x, eps, alpha, sigma)
+    n = x.shape[0]
+    if out is None:
+        out = torch.empty_like(x)
+    check(L.vdm_diffuse(_p(x), _p(eps), _p(alpha), _p(sigma), n, x.numel() // n, _p(out), _s()), "vdm_diffuse")
+    return out
+
+
+def loss_terms(x, eps, eps_hat, eps0, sigma0_over_alpha0, coef, sums, d_eps_hat):
+    L = _lib.lib()
+    _contig(x, eps, eps_hat, eps0, coef, sums, d_eps_hat)
+    n = x.shape[0]
+    check(L.vdm_loss_terms(_p(x), _p(eps), _p(eps_hat), _p(eps0), float(sigma0_over_alpha0), _p(coef), n, x.numel() // n,
+                           _p(sums), _p(d_eps_hat), _s()), "vdm_loss_terms")
+
+
+def ancestral_step(z, eps_hat, noise, coef, step_ptr, seed):
+    L = _lib.lib()
+    _contig(z, eps_hat, noise, coef)
+    check(L.vdm_ancestral_step(_p(z), _p(eps_hat), _p(noise), _p(coef), _p(step_ptr), int(seed), z.numel(), _s()),
+          "vdm_ancestral_step")
+
+
+def randn(out, seed, stream_id=0):
+    L = _lib.lib()
+    _contig(out)
+    assert out.dtype == torch.float32
+    check(L.vdm_randn(_p(out), out.numel(), int(seed), int(stream_id), _s()), "vdm_randn")
+    return out
+
+
+def step_inc(step_ptr):
+    check(_lib.lib().vdm_step_inc(_p(step_ptr), _s()), "vdm_step_inc")
+
+
+def sumsq(x, out):
+    L = _lib.lib()
+    _contig(x)
+    assert x.dtype == torch.float32 and out.dtype == torch.float32
+    check(L.vdm_sumsq(_p(x), x.numel(), _p(out), _s()), "vdm_sumsq")
+    return out

@@ -1,0 +1,165 @@
+"""Minimal fit loop standing in for ``lightning.pytorch.Trainer`` on the VDM training path.
+
+Reproduces what the reference's ``train()`` configures (/root/reference/trainVDM3D128_c_c_from_field_name_thick_lowbatch.py:28-50):
+``max_steps``, ``val_check_interval``, ``gradient_clip_val=0.5`` (global L2 norm), a checkpoint every
+``every_n_train_steps`` (``{"state_dict": ...}`` - the key the reference reloads, src/utils.py:468-469), an LR / metric log
+(JSONL instead of Comet: no network).  Data parallelism is a build-side addition: one process per GPU,
+identical weights, ONE all-reduce per step of the flat gradient vector over RCCL (``backend="nccl"`` on ROCm) or gloo on CPU.
+"""
+import json
+import os
+import time
+
+import torch
+import torch.distributed as dist
+
+
+def dist_env():
+    return int(os.environ.get("RANK", 0)), int(os.environ.get("LOCAL_RANK", 0)), int(os.environ.get("WORLD_SIZE", 1))
+
+
+def init_distributed(device_type):
+    """Initialise torch.distributed from the torchrun environment if WORLD_SIZE > 1."""
+    rank, local_rank, world = dist_env()
+    if world > 1 and not dist.is_initialized():
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29500")
+        backend = "nccl" if device_type == "cuda" else "gloo"
+        if device_type == "cuda":
+            torch.cuda.set_device(local_rank)
+        dist.init_process_group(backend=backend, rank=rank, world_size=world)
+    return rank, local_rank, world
+
+
+def allreduce_mean_(t, world):
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+        t.div_(world)
+    return t
+
+
+def clip_grad_norm_flat_(params, max_norm, use_hip):
+    """Global-norm clipping without a host sync.  Returns the (device) total norm."""
+    grads = [p.grad for p in params if p.grad is not None]
+    if use_hip:
+        from . import hip_ops as ops
+        acc = torch.zeros(1, device=grads[0].device)
+        for g in grads:
+            if g.numel() >= 1024 and g.is_contiguous() and g.data_ptr() % 16 == 0:
+                ops.sumsq(g, acc)                                   # K10
+            else:
+                acc += (g.float() ** 2).sum()
+        total = acc.sqrt()
+    else:
+        total = torch.sqrt(sum((g.float() ** 2).sum() for g in grads))
+    coef = torch.clamp(max_norm / (total + 1e-6), max=1.0)
+    for g in grads:
+        g.mul_(coef.to(g.device))
+    return total
+
+
+class Trainer:
+    def __init__(self, max_steps=1_000_000, val_check_interval=1000, gradient_clip_val=0.5, every_n_train_steps=10_000,
+                 default_root_dir="./data/logs", experiment_name="run", limit_val_batches=4, log_every_n_steps=50,
+                 n_val_sampling_steps=250, device=None, enable_progress=True):
+        self.max_steps, self.val_check_interval, self.gradient_clip_val = max_steps, val_check_interval, gradient_clip_val
+        self.every_n_train_steps = every_n_train_steps
+        self.root = os.path.join(default_root_dir, experiment_name)
+        self.limit_val_batches, self.log_every_n_steps = limit_val_batches, log_every_n_steps
+        self.n_val_sampling_steps = n_val_sampling_steps
+        self.device = device
+        self.enable_progress = enable_progress
+        self.global_step = 0
+        self.history = []
+
+    def _log(self, rec):
+        self.history.append(rec)
+        if self.rank == 0:
+            os.makedirs(self.root, exist_ok=True)
+            with open(os.path.join(self.root, "metrics.jsonl"), "a") as f:
+                f.write(json.dumps(rec) + "\n")
+
+    def save_checkpoint(self, model, epoch):
+        if self.rank != 0:
+            return None
+        d = os.path.join(self.root, "checkpoints")
+        os.makedirs(d, exist_ok=True)
+        path = os.path.join(d, f"epoch={epoch}-step={self.global_step}.ckpt")
+        torch.save({"state_dict": model.state_dict(), "global_step": self.global_step, "epoch": epoch}, path)
+        return path
+
+    def fit(self, model, datamodule):
+        dev = self.device
+        if dev is None:
+            dev = "cuda" if torch.cuda.is_available() else "cpu"
+        dev_type = torch.device(dev).type
+        self.rank, local_rank, self.world = init_distributed(dev_type)
+        if dev_type == "cuda":
+            dev = f"cuda:{local_rank}"
+            torch.cuda.set_device(local_rank)
+        model.to(dev)
+        datamodule.device = dev
+        params = [p for p in model.parameters() if p.requires_grad]
+        if self.world > 1:                                   # identical weights on every rank
+            for p in params:
+                dist.broadcast(p.data, src=0)
+        opt = model.configure_optimizers()
+        use_hip = dev_type == "cuda" and getattr(model.model.score_model, "backend", "") == "hip"
+        epoch, t0 = 0, time.time()
+        model.train()
+        while self.global_step < self.max_steps:
+            n_batches = 0
+            for batch in datamodule.train_dataloader(self.rank, self.world):
+                n_batches += 1
+                loss = model.training_step(batch, self.global_step)
+                opt.zero_grad(set_to_none=True)
+                loss.backward()
+                for p in params:                              # one collective per parameter tensor (flat UNet vector + <=2 scalars)
+                    if p.grad is not None:
+                        allreduce_mean_(p.grad, self.world)
+                gnorm = None
+                if self.gradient_clip_val:
+                    gnorm = clip_grad_norm_flat_(params, self.gradient_clip_val, use_hip)
+                opt.step()
+                self.global_step += 1
+                if self.global_step % self.log_every_n_steps == 0 or self.global_step == 1:
+                    rec = {"step": self.global_step, "epoch": epoch, "lr": opt.param_groups[0]["lr"], "time": time.time() - t0,
+                           "loss": float(loss), **dict(model.logged)}
+                    if gnorm is not None:
+                        rec["grad_norm"] = float(gnorm)
+                    self._log(rec)
+                    if self.enable_progress and self.rank == 0:
+                        print(f"step {self.global_step} loss {rec['loss']:.4f} ({rec['time']:.1f}s)", flush=True)
+                if self.val_check_interval and self.global_step % self.val_check_interval == 0:
+                    self.validate(model, datamodule)
+                if self.every_n_train_steps and self.global_step % self.every_n_train_steps == 0:
+                    self.save_checkpoint(model, epoch)
+                if self.global_step >= self.max_steps:
+                    break
+            if n_batches == 0:
+                raise RuntimeError("empty training dataloader")
+            epoch += 1
+        return self
+
+    @torch.no_grad()
+    def validate(self, model, datamodule):
+        model.eval()
+        losses, last = [], None
+        for i, batch in enumerate(datamodule.val_dataloader()):
+            if i >= self.limit_val_batches:
+                break
+            losses.append(float(model.validation_step(batch, i)))
+            last = batch
+        rec = {"step": self.global_step, "val_loss": sum(losses) / max(len(losses), 1), **dict(model.logged)}
+        if last is not None and model.draw_figure is not None and self.rank == 0:
+            x, kw = model._unpack(last)
+            samples = model.draw_samples(batch_size=x.shape[0], n_sampling_steps=self.n_val_sampling_steps, **model._filter(kw))
+            try:
+                fig = model.draw_figure(last, samples)
+                os.makedirs(self.root, exist_ok=True)
+                fig.savefig(os.path.join(self.root, f"val_step{self.global_step}.png"))
+            except Exception as e:                             # figures are diagnostics, never fatal to the fit loop
+                rec["figure_error"] = repr(e)
+        self._log(rec)
+        model.train()
+        return rec

@@ -1,0 +1,233 @@
+"""HIP execution of the CUNet graph: forward and hand-written backward over the C-ABI kernels.
+
+The graph (D1-D8) is walked on the host; every activation-sized operation is one call
+into libvdm4cdm_hip.so on torch's current stream (so a caller can capture the whole denoise step in
+a hipGraph).  PyTorch only allocates buffers and runs the tiny conditioning MLPs (R5).
+
+Tensors: activations NDHWC ``[N, D, H, W, C]`` in the compute dtype (bf16 or fp32); ``eps_hat`` fp32.
+Backward returns the gradient of the flat parameter vector and of the conditioning table.
+"""
+import torch
+
+from . import hip_ops as ops
+from .hip_ops import Conv
+
+
+class _Res:
+    """ResNetBlock (D4) on HIP kernels; input may be two tensors (skip concat, never materialised)."""
+
+    def __init__(self, net, info):
+        self.i, self.net = info, net
+        circ = net.conv_padding_mode == "circular"
+        cin = info.c1 + info.c2
+        self.conv1 = Conv(cin, info.cout, 3, circular=circ)
+        self.conv2 = Conv(info.cout, info.cout, 3, circular=circ)
+        self.skip1 = Conv(info.c1, info.cout, 1) if info.has_skip else None
+        self.skip2 = Conv(info.c2, info.cout, 1) if (info.has_skip and info.c2) else None
+        self.saved = None
+
+    def convs(self):
+        n = self.i.name
+        out = [(self.conv1, n + ".conv1.weight"), (self.conv2, n + ".conv2.weight")]
+        if self.skip1:
+            out.append((self.skip1, n + ".skip.weight"))
+        if self.skip2:
+            out.append((self.skip2, n + ".skip2.weight"))
+        return out
+
+    def fwd(self, P, x1, x2, table, train, seed):
+        i, G, n = self.i, self.net.norm_groups, self.i.name
+        st1 = ops.gn_stats(x1, x2, G)
+        a1 = ops.gn_silu_fwd(x1, x2, G, st1, P(n + ".norm1.weight"), P(n + ".norm1.bias"))
+        h = self.conv1.fwd(a1, P(n + ".conv1.bias"), table[:, i.table_off:i.table_off + i.cout])
+        st2 = ops.gn_stats(h, None, G)
+        p = self.net.dropout_prob if train else 0.0
+        a2 = ops.gn_silu_fwd(h, None, G, st2, P(n + ".norm2.weight"), P(n + ".norm2.bias"), p, seed)
+        if self.skip1 is not None:
+            s = self.skip1.fwd(x1, P(n + ".skip.bias"))
+            if self.skip2 is not None:
+                s = self.skip2.fwd(x2, None, None, s)
+        else:
+            s = x1
+        out = self.conv2.fwd(a2, P(n + ".conv2.bias"), None, s)
+        if train:
+            self.saved = (x1, x2, st1, a1, h, st2, a2, p, seed)
+        return out
+
+    def bwd(self, P, GP, dout, dtable):
+        """dout: gradient of the block output.  Returns (dx1, dx2).  Fills parameter grads via GP(name)."""
+        i, G, n = self.i, self.net.norm_groups, self.i.name
+        x1, x2, st1, a1, h, st2, a2, p, seed = self.saved
+        self.saved = None
+        # conv2 (+ residual path shares dout)
+        self.conv2.wgrad(a2, dout, GP(n + ".conv2.weight"))
+        ops.colsum(dout, GP(n + ".conv2.bias"), 0)
+        da2 = self.conv2.dgrad(dout)
+        dh, _ = ops.gn_silu_bwd(h, None, G, st2, P(n + ".norm2.weight"), P(n + ".norm2.bias"), da2,
+                                GP(n + ".norm2.weight"), GP(n + ".norm2.bias"),
+                                colsum=dtable[:, i.table_off:i.table_off + i.cout], dropout_p=p, seed=seed, dx1=da2)
+        del a2
+        # conv1
+        self.conv1.wgrad(a1, dh, GP(n + ".conv1.weight"))
+        da1 = self.conv1.dgrad(dh)
+        del a1, dh
+        # skip path
+        add1 = add2 = None
+        if self.skip1 is not None:
+            self.skip1.wgrad(x1, dout, GP(n + ".skip.weight"))
+            add1 = self.skip1.dgrad(dout)
+            ops.colsum(dout, GP(n + ".skip.bias"), 0)
+            if self.skip2 is not None:
+                self.skip2.wgrad(x2, dout, GP(n + ".skip2.weight"))
+                add2 = self.skip2.dgrad(dout)
+        else:
+            add1 = dout
+        dx1, dx2 = ops.gn_silu_bwd(x1, x2, G, st1, P(n + ".norm1.weight"), P(n + ".norm1.bias"), da1,
+                                   GP(n + ".norm1.weight"), GP(n + ".norm1.bias"), add1=add1, add2=add2)
+        return dx1, dx2
+
+
+class HipUNet:
+    def __init__(self, net):
+        self.net = net
+        circ = net.conv_padding_mode == "circular"
+        chs, L = net.chs, len(net.chs)
+        self.cin0 = net.in_channels + net.s_conditioning_channels
+        self.conv_in = Conv(self.cin0, chs[0], 3, circular=circ)
+        self.conv_out = Conv(chs[0], net.in_channels, 3, circular=circ, out_f32=True)
+        self.down = [Conv(chs[i], chs[i], 3, stride=2, circular=circ) for i in range(L - 1)]
+        self.up = [Conv(chs[i + 1], chs[i], 3, upsample=1, circular=circ) for i in range(L - 1)]
+        self.res = {b.name: _Res(net, b) for b in net.blocks}
+        self._packed_key = None
+        self.saved = None
+
+    def _all_convs(self):
+        L = len(self.net.chs)
+        out = [(self.conv_in, "conv_in.weight"), (self.conv_out, "conv_out.weight")]
+        for i in range(L - 1):
+            out.append((self.down[i], f"downs.{i}.down.weight"))
+            out.append((self.up[i], f"ups.{i}.up.weight"))
+        for r in self.res.values():
+            out.extend(r.convs())
+        return out
+
+    def pack_weights(self, flat, dtype, need_dgrad):
+        """Re-pack master fp32 weights into MFMA fragment order when the parameters changed."""
+        key = (flat.data_ptr(), flat._version, dtype, bool(need_dgrad))
+        if self._packed_key == key:
+            return
+        if self._packed_key is not None and self._packed_key[:3] == key[:3] and not need_dgrad:
+            return                                   # fwd buffers already current
+        for conv, name in self._all_convs():
+            conv.pack(self.net.view(name, flat), dtype, need_dgrad)
+        self._packed_key = key
+
+    # ---------------------------------------------------------------------------------------
+    def forward(self, flat, table, z, s_cond, train, seed):
+        """z, s_cond: fp32 [N, D, H, W] (single channel).  Returns eps_hat fp32 [N, D, H, W]."""
+        net = self.net
+        dtype = torch.bfloat16 if net.precision == "bf16" else torch.float32
+        self.pack_weights(flat, dtype, train)
+        P = lambda name: net.view(name, flat)
+        L = len(net.chs)
+        xin = ops.pack_input(z, s_cond, dtype)
+        h = self.conv_in.fwd(xin, P("conv_in.bias"))
+        skips = []
+        for i in range(L):
+            h = self.res[f"downs.{i}.block"].fwd(P, h, None, table, train, seed + 2 * i)
+            if i != L - 1:
+                skips.append(h)
+                h = self.down[i].fwd(h, P(f"downs.{i}.down.bias"))
+        for j in range(2):
+            h = self.res[f"mid.{j}"].fwd(P, h, None, table, train, seed + 100 + j)
+        coarse = []
+        for i in reversed(range(L - 1)):
+            coarse.append(h)
+            u = self.up[i].fwd(h, P(f"ups.{i}.up.bias"))
+            h = self.res[f"ups.{i}.block"].fwd(P, u, skips[i], table, train, seed + 200 + i)
+        st = ops.gn_stats(h, None, net.norm_groups)
+        a = ops.gn_silu_fwd(h, None, net.norm_groups, st, P("norm_out.weight"), P("norm_out.bias"))
+        eps = self.conv_out.fwd(a, P("conv_out.bias"))
+        if train:
+            self.saved = (flat, xin, skips, coarse[::-1], h, st, a, table.shape)
+        return eps.view(z.shape)
+
+    def backward(self, d_eps):
+        """d_eps: fp32 [N, D, H, W].  Returns (grad of flat, grad of conditioning table)."""
+        net = self.net
+        flat, xin, skips, coarse, h_last, st, a, tshape = self.saved
+        self.saved = None
+        L = len(net.chs)
+        dtype = xin.dtype
+        gflat = torch.zeros_like(flat)
+        dtable = torch.zeros(tshape, dtype=torch.float32, device=flat.device)
+        P = lambda name: net.view(name, flat)
+        GP = lambda name: net.view(name, gflat)
+
+        dpad = ops.pack_input(d_eps.contiguous(), None, dtype)
+        self.conv_out.wgrad(a, dpad, GP("conv_out.weight"))
+        GP("conv_out.bias").copy_(d_eps.sum().reshape(1))
+        da = self.conv_out.dgrad(dpad)
+        dh, _ = ops.gn_silu_bwd(h_last, None, net.norm_groups, st, P("norm_out.weight"), P("norm_out.bias"), da,
+                                GP("norm_out.weight"), GP("norm_out.bias"), dx1=da)
+        dskips = [None] * (L - 1)
+        for i in range(L - 1):
+            du, dskips[i] = self.res[f"ups.{i}.block"].bwd(P, GP, dh, dtable)
+            self.up[i].wgrad(coarse[i], du, GP(f"ups.{i}.up.weight"))
+            ops.colsum(du, GP(f"ups.{i}.up.bias"), 0)
+            dfine = self.up[i].dgrad(du)
+            dh = ops.pool2_sum(dfine)
+            del dfine, du
+        for j in reversed(range(2)):
+            dh, _ = self.res[f"mid.{j}"].bwd(P, GP, dh, dtable)
+        for i in reversed(range(L)):
+            if i != L - 1:
+                self.down[i].wgrad(skips[i], dh, GP(f"downs.{i}.down.weight"))
+                ops.colsum(dh, GP(f"downs.{i}.down.bias"), 0)
+                dfine = ops.dilate2(dh)
+                dh = self.down[i].dgrad(dfine, residual=dskips[i])
+                del dfine
+            dh, _ = self.res[f"downs.{i}.block"].bwd(P, GP, dh, dtable)
+        self.conv_in.wgrad(xin, dh, GP("conv_in.weight"))
+        ops.colsum(dh, GP("conv_in.bias"), 0)
+        # conv1 biases: column sums of the conditioning-table gradient (same additive broadcast)
+        net.conv1_bias_all(gflat).copy_(dtable.sum(0))
+        return gflat, dtable
+
+
+class _HipUNetFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, flat, table, z, s_cond, ex, train, seed):
+        ctx.ex = ex
+        ctx.train = train
+        with torch.no_grad():
+            return ex.forward(flat.detach(), table.detach().contiguous(), z, s_cond, train, seed)
+
+    @staticmethod
+    def backward(ctx, d_eps):
+        if not ctx.train:
+            raise RuntimeError("HIP CUNet: backward requested but the forward ran without saving activations")
+        gflat, dtable = ctx.ex.backward(d_eps)
+        return gflat, dtable, None, None, None, None, None
+
+
+_seed_counter = [0]
+
+
+def hip_unet_apply(net, x, s_conditioning, table):
+    """x: [B, 1, D, H, W] fp32 on the GPU (NCDHW API; C == 1 so NDHWC is the same memory)."""
+    if net._exec is None:
+        net._exec = HipUNet(net)
+    B = x.shape[0]
+    z = x.to(torch.float32).reshape(B, *x.shape[2:]).contiguous()
+    s = None
+    if net.s_conditioning_channels:
+        assert s_conditioning is not None, "s_conditioning_channels=1 needs s_conditioning"
+        s = s_conditioning.to(torch.float32).reshape(B, *x.shape[2:]).contiguous()
+        if s.shape[0] != B:
+            s = s.expand(B, *s.shape[1:]).contiguous()
+    train = torch.is_grad_enabled() and (net.flat.requires_grad or table.requires_grad)
+    _seed_counter[0] += 1000
+    seed = (torch.initial_seed() + _seed_counter[0]) & 0x7fffffffffffffff
+    eps = _HipUNetFn.apply(net.flat, table, z, s, net._exec, train, seed)
+    return eps.view(x.shape)

@@ -1,0 +1,340 @@
+"""``vdm_model.VDM`` / ``vdm_model.LightVDM`` - variational diffusion model around the CUNet score network.
+
+Mirrors the interface the reference uses for ``mltools.models.vdm_model``:
+* construction ``LightVDM(score_model=, draw_figure=, gamma_min=, gamma_max=, noise_schedule=, learning_rate=)``
+  (/root/reference/trainVDM3D128_c_c_from_field_name_thick_lowbatch.py:128-132, train_uc_uc_from_field_name.py:115-120)
+* ``.model.score_model``, ``.model.gamma_min/gamma_max/w_cfg``, ``.model.sample_zs_given_zt(zt=, t=, s=, return_ddnm=)``,
+  ``.model.sample_zt_given_zs(zs=, t=, s=)``, ``.device`` (/root/reference/src/utils.py:286-299)
+* ``.draw_samples(batch_size, n_sampling_steps, verbose, return_all, **kwargs)`` (notebook frame vdm_model.py:531-557;
+  call sites /root/reference/generate_3D.py:61)
+* ``load_state_dict(torch.load(p)["state_dict"])`` (/root/reference/src/utils.py:468-469)
+The arithmetic is spec D9-D12 of SURVEY.md section 8 (the mltools source is not in the reference tree).
+
+On a GPU with the HIP backend the forward diffusion, the ELBO reductions and the ancestral update are the
+HIP kernels K7-K9 and the denoise step is captured once in a hipGraph and replayed for every step
+(per-step scalars come from a device table indexed by a device-side step counter).
+"""
+import math
+
+import torch
+import torch.nn as nn
+
+DATA_NOISE = 1.0e-3
+
+
+class _DiffusionLossFn(torch.autograd.Function):
+    """sum_n coef_n * sum (eps_hat - eps)^2 / 2 ... via the fused HIP reduction (K8)."""
+
+    @staticmethod
+    def forward(ctx, eps_hat, x, eps, eps0, s0a0, coef, sums):
+        from . import hip_ops as ops
+        d = torch.empty_like(eps_hat)
+        ops.loss_terms(x, eps, eps_hat.contiguous(), eps0, s0a0, coef, sums, d)
+        ctx.save_for_backward(d)
+        # coef_n = 2 w_n  ->  loss = sum_n w_n S_n = 0.5 sum_n coef_n S_n
+        return 0.5 * (coef * sums[:, 0]).sum()
+
+    @staticmethod
+    def backward(ctx, g):
+        (d,) = ctx.saved_tensors
+        return g * d, None, None, None, None, None, None
+
+
+class VDM(nn.Module):
+    def __init__(self, score_model, noise_schedule="fixed_linear", gamma_min=-13.3, gamma_max=13.3,
+                 antithetic_time_sampling=True, data_noise=DATA_NOISE, w_cfg=None):
+        super().__init__()
+        assert noise_schedule in ("fixed_linear", "learned_linear")
+        self.score_model = score_model
+        self.noise_schedule = noise_schedule
+        self.gamma_min = float(gamma_min)
+        self.gamma_max = float(gamma_max)
+        self.antithetic_time_sampling = antithetic_time_sampling
+        self.data_noise = float(data_noise)
+        self.w_cfg = w_cfg
+        if noise_schedule == "learned_linear":                   # D9: gamma(t) = b + |w| t
+            self.gamma_b = nn.Parameter(torch.tensor(self.gamma_min))
+            self.gamma_w = nn.Parameter(torch.tensor(self.gamma_max - self.gamma_min))
+        self._graph = None
+
+    # ---------------------------------------------------------------- schedule (D9)
+    def gamma(self, t):
+        if self.noise_schedule == "learned_linear":
+            return self.gamma_b + self.gamma_w.abs() * t
+        return self.gamma_min + (self.gamma_max - self.gamma_min) * t
+
+    def dgamma_dt(self, t):
+        if self.noise_schedule == "learned_linear":
+            return self.gamma_w.abs() * torch.ones_like(t)
+        return (self.gamma_max - self.gamma_min) * torch.ones_like(t)
+
+    @staticmethod
+    def alpha(g):
+        return torch.sqrt(torch.sigmoid(-g))
+
+    @staticmethod
+    def sigma(g):
+        return torch.sqrt(torch.sigmoid(g))
+
+    def _hip(self, ref):
+        return getattr(self.score_model, "backend", None) == "hip" and ref.is_cuda
+
+    # ---------------------------------------------------------------- score
+    def get_pred_noise(self, zt, gamma_t, **kwargs):
+        """notebook frame vdm_model.py:309-327."""
+        if self.w_cfg is None or self.training:
+            return self.score_model(zt, t=(gamma_t - self.gamma_min) / (self.gamma_max - self.gamma_min), **kwargs)
+        raise NotImplementedError("classifier-free guidance (w_cfg) is a 'next' row of SURVEY.md section 8f; every "
+                                  "script in the reference runs with w_cfg=None")
+
+    # ---------------------------------------------------------------- loss (D10)
+    def sample_times(self, B, device):
+        if self.antithetic_time_sampling:
+            u0 = torch.rand(1, device=device)
+            return torch.remainder(u0 + torch.arange(B, device=device, dtype=torch.float32) / B, 1.0)
+        return torch.rand(B, device=device)
+
+    def get_loss(self, x, times=None, eps=None, eps0=None, **kwargs):
+        """Continuous-time ELBO in bits/dim.  Returns (loss, metrics dict)."""
+        B = x.shape[0]
+        numel = x[0].numel()
+        bpd = 1.0 / (numel * math.log(2.0))
+        x = x.to(torch.float32).contiguous()
+        if times is None:
+            times = self.sample_times(B, x.device)
+        g_t = self.gamma(times)
+        # 0-dim CPU tensors act as scalars (no device sync for the fixed schedule)
+        # (fp64: var1 - log(var1) - 1 ~ 1e-12 cancels catastrophically in fp32)
+        g0 = self.gamma(torch.zeros((), dtype=torch.float64))
+        g1 = self.gamma(torch.ones((), dtype=torch.float64))
+        var1 = torch.sigmoid(g1)
+        a0, s0 = self.alpha(g0), self.sigma(g0)
+        bc = (B,) + (1,) * (x.dim() - 1)
+        if self._hip(x):
+            from . import hip_ops as ops
+            if self.noise_schedule != "fixed_linear":
+                raise NotImplementedError("HIP training path supports noise_schedule='fixed_linear' (all 3D scripts); "
+                                          "'learned_linear' needs d loss / d z_t which the HIP backward does not emit")
+            if eps is None:
+                eps = ops.randn(torch.empty_like(x), int(torch.randint(0, 2 ** 62, (1,)).item()), 1)
+            if eps0 is None:
+                eps0 = ops.randn(torch.empty_like(x), int(torch.randint(0, 2 ** 62, (1,)).item()), 2)
+            z_t = ops.diffuse(x, eps.contiguous(), self.alpha(g_t).contiguous(), self.sigma(g_t).contiguous())
+            eps_hat = self.get_pred_noise(z_t, g_t, **kwargs)
+            w = 0.5 * self.dgamma_dt(times) * bpd / B                      # per-sample weight of S_n
+            sums = torch.zeros(B, 3, device=x.device)
+            diff = _DiffusionLossFn.apply(eps_hat, x, eps, eps0.contiguous(), float(s0 / a0), (2.0 * w).contiguous(), sums)
+            sum_x2, sum_r2 = sums[:, 1], sums[:, 2]
+        else:
+            red = tuple(range(1, x.dim()))
+            eps = torch.randn_like(x) if eps is None else eps
+            eps0 = torch.randn_like(x) if eps0 is None else eps0
+            z_t = self.alpha(g_t).view(bc) * x + self.sigma(g_t).view(bc) * eps
+            eps_hat = self.get_pred_noise(z_t, g_t, **kwargs)
+            diff = (0.5 * self.dgamma_dt(times) * ((eps - eps_hat) ** 2).sum(red)).mean() * bpd
+            sum_x2 = (x ** 2).sum(red)
+            sum_r2 = (((s0 / a0).float() * eps0) ** 2).sum(red)
+        latent = (0.5 * ((numel * (var1 - torch.log(var1) - 1.0)).float() + (1.0 - var1).float() * sum_x2)).mean() * bpd
+        recons = (0.5 * sum_r2 / self.data_noise ** 2
+                  + numel * (math.log(self.data_noise) + 0.5 * math.log(2 * math.pi))).mean() * bpd
+        loss = diff + latent + recons
+        metrics = {"elbo": loss.detach(), "diffusion_loss": diff.detach(), "latent_loss": latent.detach(),
+                   "reconstruction_loss": recons.detach()}
+        return loss, metrics
+
+    # ---------------------------------------------------------------- sampler (D12)
+    def _as_t(self, v, ref):
+        return torch.as_tensor(v, dtype=torch.float32, device=ref.device)
+
+    def sample_zs_given_zt(self, zt, t, s, return_ddnm=False, conditioning=None, **kwargs):
+        """One ancestral step t -> s (notebook frame vdm_model.py:370-378).  `conditioning` is accepted and
+        ignored: /root/reference/src/utils.py:296 still passes the pre-CUNet kwarg ``conditioning=None``."""
+        t, s = self._as_t(t, zt), self._as_t(s, zt)
+        gamma_t, gamma_s = self.gamma(t), self.gamma(s)
+        c = -torch.expm1(gamma_s - gamma_t)
+        alpha_t, alpha_s = self.alpha(gamma_t), self.alpha(gamma_s)
+        sigma_t, sigma_s = self.sigma(gamma_t), self.sigma(gamma_s)
+        pred_noise = self.get_pred_noise(zt=zt, gamma_t=gamma_t, **kwargs)
+        if not return_ddnm:
+            mean = alpha_s / alpha_t * (zt - c * sigma_t * pred_noise)
+            scale = sigma_s * torch.sqrt(c)
+            return mean + scale * torch.randn_like(zt)
+        x_0t = (zt - sigma_t * pred_noise) / alpha_t
+        return (alpha_s / alpha_t) * (1.0 - c), alpha_s * c, x_0t, sigma_s * torch.sqrt(c)
+
+    def sample_zt_given_zs(self, zs, t, s):
+        t, s = self._as_t(t, zs), self._as_t(s, zs)
+        gamma_t, gamma_s = self.gamma(t), self.gamma(s)
+        alpha_ts = self.alpha(gamma_t) / self.alpha(gamma_s)
+        var = torch.sigmoid(gamma_t) - alpha_ts ** 2 * torch.sigmoid(gamma_s)
+        return alpha_ts * zs + torch.sqrt(var) * torch.randn_like(zs)
+
+    def step_table(self, n_sampling_steps):
+        """Host fp64 table [n, 4] = {alpha_s/alpha_t, c*sigma_t, sigma_s*sqrt(c), t_norm} on the fp32 time grid
+        ``linspace(1, 0, n+1)`` (/root/reference/src/utils.py:286)."""
+        steps = torch.linspace(1.0, 0.0, n_sampling_steps + 1).double()
+        with torch.no_grad():
+            if self.noise_schedule == "learned_linear":
+                g = (self.gamma_b.double().cpu() + self.gamma_w.abs().double().cpu() * steps)
+            else:
+                g = self.gamma_min + (self.gamma_max - self.gamma_min) * steps
+        g_t, g_s = g[:-1], g[1:]
+        c = -torch.expm1(g_s - g_t)
+        a_t, a_s = torch.sqrt(torch.sigmoid(-g_t)), torch.sqrt(torch.sigmoid(-g_s))
+        s_t, s_s = torch.sqrt(torch.sigmoid(g_t)), torch.sqrt(torch.sigmoid(g_s))
+        t_norm = (g_t - self.gamma_min) / (self.gamma_max - self.gamma_min)
+        return torch.stack([a_s / a_t, c * s_t, s_s * torch.sqrt(c), t_norm], dim=1)
+
+    @torch.no_grad()
+    def sample(self, batch_size, n_sampling_steps, device, z=None, return_all=False, verbose=False,
+               noises=None, seed=None, use_graph=True, **kwargs):
+        """Ancestral sampling (notebook frame vdm_model.py:429-442).  `noises` (optional list of n tensors) and
+        `seed` make a chain reproducible; on the HIP backend the step is a replayed hipGraph."""
+        shape = (batch_size, *self.score_model.shape)
+        if z is None:
+            z = torch.randn(shape, device=device) if seed is None else \
+                torch.randn(shape, generator=torch.Generator().manual_seed(int(seed))).to(device)
+        z = z.to(device=device, dtype=torch.float32).contiguous()
+        if self._hip(z) and not return_all:
+            return self._sample_hip(z, n_sampling_steps, noises, seed, verbose, use_graph, kwargs)
+        steps = torch.linspace(1.0, 0.0, n_sampling_steps + 1, device=device)
+        zs = []
+        rng = range(n_sampling_steps)
+        if verbose:
+            try:
+                from tqdm import trange
+                rng = trange(n_sampling_steps, desc="sampling")
+            except ImportError:
+                pass
+        for i in rng:
+            if noises is None:
+                z = self.sample_zs_given_zt(zt=z, t=steps[i], s=steps[i + 1], **kwargs)
+            else:
+                w_z, w_x, x0, scale = self.sample_zs_given_zt(zt=z, t=steps[i], s=steps[i + 1], return_ddnm=True, **kwargs)
+                z = w_z * z + w_x * x0 + scale * noises[i].to(z)
+            if return_all:
+                zs.append(z)
+        return torch.stack(zs, dim=0) if return_all else z
+
+    def _sample_hip(self, z, n, noises, seed, verbose, use_graph, kwargs):
+        from . import hip_ops as ops
+        dev = z.device
+        coef = self.step_table(n).to(device=dev, dtype=torch.float32).contiguous()
+        step = torch.zeros(1, dtype=torch.int32, device=dev)
+        B = z.shape[0]
+        seed = int(torch.randint(0, 2 ** 62, (1,)).item()) if seed is None else int(seed)
+        noise_buf = torch.empty_like(z) if noises is not None else None
+
+        def one_step():
+            t_norm = coef[:, 3].index_select(0, step.to(torch.int64)).expand(B)
+            eps_hat = self.score_model(z, t=t_norm, **kwargs)
+            ops.ancestral_step(z, eps_hat.contiguous(), noise_buf, coef, step, seed)
+            ops.step_inc(step)
+
+        graph = None
+        if use_graph and n > 2:
+            # warm-up on a side stream (packs weights, sizes the allocator), then capture one step
+            side = torch.cuda.Stream(device=dev)
+            z_keep = z.clone()
+            side.wait_stream(torch.cuda.current_stream(dev))
+            with torch.cuda.stream(side):
+                if noise_buf is not None:
+                    noise_buf.copy_(noises[0].to(z))
+                one_step()
+            torch.cuda.current_stream(dev).wait_stream(side)
+            z.copy_(z_keep)
+            step.zero_()
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph):
+                one_step()
+            z.copy_(z_keep)             # capture does not execute, but keep the state explicit
+            step.zero_()
+        for i in range(n):
+            if noise_buf is not None:
+                noise_buf.copy_(noises[i].to(z))
+            if graph is not None:
+                graph.replay()
+            else:
+                one_step()
+            if verbose and (i % 50 == 0 or i == n - 1):
+                print(f"sampling: {i + 1}/{n}", flush=True)
+        return z
+
+
+class LightVDM(nn.Module):
+    """Stand-in for the LightningModule of the reference: same constructor / attributes / methods that the
+    reference scripts touch; the fit loop lives in vdm4cdm_amd.trainer.Trainer."""
+
+    def __init__(self, score_model, draw_figure=None, gamma_min=-13.3, gamma_max=13.3, noise_schedule="fixed_linear",
+                 learning_rate=3.0e-4, **vdm_kwargs):
+        super().__init__()
+        self.model = VDM(score_model, noise_schedule=noise_schedule, gamma_min=gamma_min, gamma_max=gamma_max, **vdm_kwargs)
+        self.draw_figure = draw_figure
+        self.learning_rate = learning_rate
+        self.logged = {}
+
+    @property
+    def device(self):
+        return self.model.score_model.flat.device
+
+    def log_dict(self, d):
+        self.logged.update({k: float(v) for k, v in d.items()})
+
+    @staticmethod
+    def _unpack(batch):
+        """Batch dict contract (/root/reference/trainVDM3D128_c_c_from_field_name_thick_lowbatch.py:75-76)."""
+        kw = {}
+        if batch.get("conditioning") is not None:
+            kw["s_conditioning"] = batch["conditioning"]
+        if batch.get("conditioning_values") is not None:
+            kw["v_conditionings"] = list(batch["conditioning_values"])
+        return batch["x"], kw
+
+    def _filter(self, kw):
+        sm = self.model.score_model
+        if not getattr(sm, "s_conditioning_channels", 1):
+            kw.pop("s_conditioning", None)
+        if not getattr(sm, "v_conditioning_dims", [1]):
+            kw["v_conditionings"] = []
+        return kw
+
+    def training_step(self, batch, batch_idx=0):
+        x, kw = self._unpack(batch)
+        loss, metrics = self.model.get_loss(x, **self._filter(kw))
+        self.log_dict({f"train/{k}": v for k, v in metrics.items()})
+        return loss
+
+    @torch.no_grad()
+    def validation_step(self, batch, batch_idx=0):
+        x, kw = self._unpack(batch)
+        loss, metrics = self.model.get_loss(x, **self._filter(kw))
+        self.log_dict({f"val/{k}": v for k, v in metrics.items()})
+        return loss
+
+    def configure_optimizers(self):
+        return torch.optim.AdamW(self.parameters(), lr=self.learning_rate)      # D11
+
+    def draw_samples(self, batch_size, n_sampling_steps=250, verbose=False, return_all=False, **kwargs):
+        return self.model.sample(batch_size=batch_size, n_sampling_steps=n_sampling_steps, device=self.device,
+                                 verbose=verbose, return_all=return_all, **kwargs)
+
+    # state dict: {"model.score_model.<name>": tensor, "model.gamma_b": ..., ...}
+    def state_dict(self, *args, destination=None, prefix="", keep_vars=False):
+        out = {} if destination is None else destination
+        self.model.score_model.state_dict(destination=out, prefix=prefix + "model.score_model.", keep_vars=keep_vars)
+        if self.model.noise_schedule == "learned_linear":
+            out[prefix + "model.gamma_b"] = self.model.gamma_b.detach().clone()
+            out[prefix + "model.gamma_w"] = self.model.gamma_w.detach().clone()
+        return out
+
+    def load_state_dict(self, state_dict, strict=True):
+        pre = "model.score_model."
+        sub = {k[len(pre):]: v for k, v in state_dict.items() if k.startswith(pre)}
+        res = self.model.score_model.load_state_dict(sub, strict=strict)
+        if self.model.noise_schedule == "learned_linear":
+            with torch.no_grad():
+                if "model.gamma_b" in state_dict:
+                    self.model.gamma_b.copy_(state_dict["model.gamma_b"])
+                if "model.gamma_w" in state_dict:
+                    self.model.gamma_w.copy_(state_dict["model.gamma_w"])
+        return res
