@@ -1,0 +1,216 @@
+#!/usr/bin/env python
+"""bench.py - headline benchmark of the vdm4cdm VDM denoising path on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
+
+One "step" = one full training step of the 128^3 conditional VDM (BASELINE config C3,
+trainVDM3D128_c_c thick_lowbatch: chs [32,64,128,256], batch 2 per GPU, bf16 storage / fp32 accumulate):
+forward diffusion + UNet forward + ELBO + UNet backward + gradient all-reduce (N>1) + global-norm clip + AdamW,
+on synthetic lognormal density cubes already resident in HBM.  Metric: 3D voxels/s = N * B * D^3 / step time.
+
+Rank 0 prints ONE JSON line (contract in the task statement) with two extra objects:
+  roofline     - the dominant kernel (3^3 implicit-GEMM conv on bf16 MFMA): algorithmic FLOPs of its launches in the
+                 timed region / their summed HIP-event durations, against the 2.5 PFLOP/s dense bf16 MFMA peak;
+                 plus the whole-step HBM fraction (algorithmic bytes of SURVEY.md section 8d / step time / 8 TB/s).
+  cpu_baseline - the oracle (plain torch CPU fp32, kind "port") timed on this host's cores on a bounded sample.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+CONFIGS = {
+    # name: (D, batch per GPU, chs, precision)
+    "c2": (64, 2, [32, 64, 128, 256], "fp32"),
+    "c3": (128, 2, [32, 64, 128, 256], "bf16"),
+    "c4": (192, 2, [32, 64, 128, 256], "bf16"),
+    "c224": (224, 2, [16, 32, 64, 128], "bf16"),
+    "tiny": (32, 2, [16, 32, 64], "bf16"),
+}
+# algorithmic work per voxel per forward at chs [32,64,128,256]: 720 kFLOP, 1.53 kB (bf16) / 3.05 kB (fp32);
+# fwd+bwd = 3x forward.
+FLOP_PER_VOXEL_FWD = 720.0e3
+BYTES_PER_VOXEL_FWD = {"bf16": 1.53e3, "fp32": 3.05e3}
+HBM_PEAK = 8.0e12
+MFMA_PEAK = {"bf16": 2.5e15, "fp32": 157.3e12}
+
+
+def build_model(D, chs, precision, device, seed=42):
+    from vdm4cdm_amd.networks import CUNet
+    from vdm4cdm_amd.vdm_model import LightVDM
+    torch.manual_seed(seed)                                     # [REF trainVDM3D128...py:54] seed_everything(42)
+    net = CUNet(shape=(1, D, D, D), chs=chs, s_conditioning_channels=1, v_conditioning_dims=[6], t_conditioning=True,
+                norm_groups=8, mid_attn=False, dropout_prob=0.1, conv_padding_mode="zeros", n_attention_heads=4,
+                backend="hip", precision=precision)
+    g = torch.Generator().manual_seed(seed)
+    net.reset_parameters(generator=g, zero_init_std=0.02)       # zero-init convs -> N(0, 0.02): non-trivial gradients
+    return LightVDM(score_model=net, draw_figure=None, gamma_max=13.3, learning_rate=3.0e-4).to(device)
+
+
+def make_batch(D, B, rank, device):
+    from vdm4cdm_amd.data import SyntheticAstroDataModule
+    dm = SyntheticAstroDataModule(cropsize=D, batch_size=B, seed=1000 + rank)
+    b = dm._make_batch(1000 + rank, B)
+    return {"x": b["x"].to(device), "conditioning": b["conditioning"].to(device),
+            "conditioning_values": [b["conditioning_values"][0].to(device)]}
+
+
+def cpu_baseline(chs, budget_D=64):
+    """Oracle fwd+bwd on the host cores on a bounded sample (same network, one 64^3 crop, fp32)."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from helpers import oracle_cfg, oracle_params
+    from oracle import unet_oracle
+    from vdm4cdm_amd.networks import CUNet
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    net = CUNet(shape=(1, budget_D, budget_D, budget_D), chs=chs, s_conditioning_channels=1, v_conditioning_dims=[6],
+                norm_groups=8, backend="torch")
+    net.reset_parameters(generator=torch.Generator().manual_seed(42), zero_init_std=0.02)
+    P = {k: v.clone().requires_grad_(True) for k, v in oracle_params(net).items()}
+    g = torch.Generator().manual_seed(7)
+    x = torch.randn(1, 1, budget_D, budget_D, budget_D, generator=g)
+    s = torch.randn(1, 1, budget_D, budget_D, budget_D, generator=g)
+    t = torch.rand(1, generator=g)
+    v = [torch.rand(1, 6, generator=g)]
+    times = []
+    for it in range(2):                                          # 1 warm-up + 1 timed (bounded: ~10-30 s total)
+        t0 = time.time()
+        y = unet_oracle.cunet_forward(P, oracle_cfg(net), x, t, s, v)
+        (y * x).sum().backward()
+        times.append(time.time() - t0)
+    vox = budget_D ** 3
+    return {"value": vox / times[-1], "unit": "voxels/s", "cores": cores, "kind": "port",
+            "sample": f"oracle (torch CPU fp32) fwd+bwd of the same UNet on one {budget_D}^3 cube, batch 1, {cores} threads, "
+                      f"{times[-1]:.1f} s (warm-up {times[0]:.1f} s)"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--config", default="c3", choices=sorted(CONFIGS))
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-kernel-events", action="store_true", help="skip per-launch HIP events (pure wall-clock run)")
+    ap.add_argument("--sample-steps", type=int, default=0, help="also time an n-step reverse-diffusion sample (batch 1)")
+    args = ap.parse_args()
+
+    import torch.distributed as dist
+    from vdm4cdm_amd import hip_ops
+    from vdm4cdm_amd.trainer import allreduce_mean_, clip_grad_norm_flat_, init_distributed
+
+    assert torch.cuda.is_available(), "bench.py needs a GPU (the HIP path has no CPU fallback)"
+    rank, local_rank, world = init_distributed("cuda")
+    assert world == args.gpus or world == 1, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+    device = f"cuda:{local_rank}"
+    torch.cuda.set_device(local_rank)
+
+    D, B, chs, precision = CONFIGS[args.config]
+    vdm = build_model(D, chs, precision, device)
+    net = vdm.model.score_model
+    params = [p for p in vdm.parameters() if p.requires_grad]
+    if world > 1:
+        for p in params:
+            dist.broadcast(p.data, src=0)
+    opt = vdm.configure_optimizers()
+    batch = make_batch(D, B, rank, device)
+    vdm.train()
+
+    def step():
+        loss = vdm.training_step(batch, 0)
+        opt.zero_grad(set_to_none=True)
+        loss.backward()
+        for p in params:
+            if p.grad is not None:
+                allreduce_mean_(p.grad, world)
+        clip_grad_norm_flat_(params, 0.5, use_hip=True)
+        opt.step()
+        return loss
+
+    for _ in range(args.warmup):
+        step()
+    prof = None
+    if not args.no_kernel_events:
+        prof = hip_ops.PROFILER = hip_ops.KernelProfiler()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss = step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    hip_ops.PROFILER = None
+    el = torch.tensor([elapsed], device=device, dtype=torch.float64)
+    if world > 1:
+        dist.all_reduce(el, op=dist.ReduceOp.MAX)
+    elapsed = el.item()
+    ms_per_step = 1e3 * elapsed / args.steps
+    voxels_per_step = world * B * D ** 3
+    value = voxels_per_step * args.steps / elapsed
+
+    if rank == 0:
+        scale = 1.0 if chs == [32, 64, 128, 256] else None
+        out = {
+            "metric": "3D voxels/sec UNet fwd+bwd @128^3 (VDM training step)", "value": value, "unit": "voxels/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": precision, "data": "synthetic",
+            "config": {"workload": f"{args.config}: {D}^3 conditional VDM (trainVDM3D128_c_c thick_lowbatch), chs {chs}, "
+                                   f"batch {B}/GPU, full training step (diffuse + UNet fwd + ELBO + UNet bwd + clip + AdamW), dropout 0.1",
+                       "global_batch": world * B, "cube": D, "parallelism": f"dp{world}"},
+            "loss": float(loss),
+        }
+        roof = {}
+        if prof is not None:
+            agg = prof.summary()
+            conv = {k: v for k, v in agg.items() if k.startswith("conv_fwd_kernel") and ",k3," in k}
+            dom_key = max(conv, key=lambda k: conv[k]["ms"]) if conv else None
+            total_ms = sum(v["ms"] for v in agg.values())
+            if dom_key:
+                d = conv[dom_key]
+                ach = d["flops"] / (d["ms"] * 1e-3)
+                roof = {"bound": "mfma", "kernel": dom_key, "achieved": ach / 1e12, "peak": MFMA_PEAK[precision] / 1e12,
+                        "unit": "TFLOP/s", "frac": ach / MFMA_PEAK[precision], "traffic": None,
+                        "launches": d["launches"], "avg_launch_ms": d["ms"] / d["launches"],
+                        "share_of_kernel_time": d["ms"] / total_ms}
+            out["kernels"] = {k: {"launches": v["launches"], "ms_per_step": v["ms"] / args.steps,
+                                  "TFLOP/s": (v["flops"] / (v["ms"] * 1e-3) / 1e12) if v["flops"] else None,
+                                  "GB/s": (v["bytes"] / (v["ms"] * 1e-3) / 1e9) if v["bytes"] else None}
+                              for k, v in sorted(agg.items(), key=lambda kv: -kv[1]["ms"])}
+        if scale is not None:
+            alg_bytes = 3.0 * BYTES_PER_VOXEL_FWD[precision] * B * D ** 3          # per GPU per step (fwd+bwd)
+            alg_flops = 3.0 * FLOP_PER_VOXEL_FWD * B * D ** 3
+            roof["step_hbm_frac"] = alg_bytes / (ms_per_step * 1e-3) / HBM_PEAK
+            roof["step_mfma_frac"] = alg_flops / (ms_per_step * 1e-3) / MFMA_PEAK[precision]
+            roof["step_algorithmic_GB"] = alg_bytes / 1e9
+            roof["step_algorithmic_TFLOP"] = alg_flops / 1e12
+        out["roofline"] = roof
+        if args.sample_steps:
+            vdm.eval()
+            s = batch["conditioning"][:1]
+            v = [batch["conditioning_values"][0][:1]]
+            vdm.draw_samples(batch_size=1, n_sampling_steps=3, s_conditioning=s, v_conditionings=v)
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            vdm.draw_samples(batch_size=1, n_sampling_steps=args.sample_steps, s_conditioning=s, v_conditionings=v)
+            torch.cuda.synchronize()
+            out["sample"] = {"steps": args.sample_steps, "seconds": time.perf_counter() - t1, "cube": D, "batch": 1}
+        if not args.no_cpu_baseline and world == 1:
+            out["cpu_baseline"] = cpu_baseline(chs)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -14,6 +14,55 @@ from ._lib import ConvDesc, PACK_DGRAD, PACK_FWD, VDM_BF16, VDM_F32, check
 GN_EPS = 1e-5
 
 
+class KernelProfiler:
+    """Optional per-launch HIP-event timing (bench.py): events are recorded on the launch stream around each
+    C-ABI call; `summary()` aggregates per kernel key after a synchronize."""
+
+    def __init__(self):
+        self.records = []          # (key, start, end, flops, bytes)
+
+    def begin(self):
+        e = torch.cuda.Event(enable_timing=True)
+        e.record()
+        return e
+
+    def end(self, start, key, flops=0.0, nbytes=0.0):
+        e = torch.cuda.Event(enable_timing=True)
+        e.record()
+        self.records.append((key, start, e, flops, nbytes))
+
+    def summary(self):
+        torch.cuda.synchronize()
+        agg = {}
+        for key, s, e, fl, nb in self.records:
+            a = agg.setdefault(key, {"launches": 0, "ms": 0.0, "flops": 0.0, "bytes": 0.0})
+            a["launches"] += 1
+            a["ms"] += s.elapsed_time(e)
+            a["flops"] += fl
+            a["bytes"] += nb
+        return agg
+
+
+PROFILER = None        # set to a KernelProfiler by bench.py
+
+
+def _pb():
+    return PROFILER.begin() if PROFILER is not None else None
+
+
+def _pe(ev, key, flops=0.0, nbytes=0.0):
+    if ev is not None:
+        PROFILER.end(ev, key, flops, nbytes)
+
+
+def _nc_for(cout):
+    return 1 if cout <= 16 else (2 if cout <= 32 else 4)
+
+
+def _tname(dtype):
+    return "float" if dtype == torch.float32 else "bf16_t"
+
+
 def dt_id(dtype):
     if dtype == torch.float32:
         return VDM_F32
@@ -111,7 +160,14 @@ class Conv:
         if residual is not None:
             assert residual.shape == out.shape and residual.dtype == x.dtype
         d = self.desc(shp[0], shp[1], shp[2], shp[3], x.dtype)
+        ev = _pb()
         check(L.vdm_conv_fwd(d, _p(x), _p(self.wf), _p(bias), _p(nbias), nstride, _p(residual), _p(out), _s()), "vdm_conv_fwd")
+        if ev is not None:
+            nvox = shp[0] * shp[1] * shp[2] * shp[3]
+            es = x.element_size()
+            _pe(ev, f"conv_fwd_kernel<{_tname(x.dtype)},k{self.ksize},s{self.stride},u{self.upsample},NC{_nc_for(self.cout)}>",
+                2.0 * nvox * self.ksize ** 3 * self.cin * self.cout,
+                x.numel() * es + out.numel() * out.element_size() + (residual.numel() * es if residual is not None else 0))
         return out
 
     def dgrad(self, dout, residual=None, out=None):
@@ -124,7 +180,14 @@ class Conv:
         if out is None:
             out = torch.empty((n, od, oh, ow, self.cin), dtype=dout.dtype, device=dout.device)
         d = self.desc(n, od, oh, ow, dout.dtype, stride=1)
+        ev = _pb()
         check(L.vdm_conv_dgrad(d, _p(dout), _p(self.wd), _p(residual), _p(out), _s()), "vdm_conv_dgrad")
+        if ev is not None:
+            nvox = n * od * oh * ow // (8 if self.stride == 2 else 1)         # algorithmic: only the non-dilated taps count
+            es = dout.element_size()
+            _pe(ev, f"conv_fwd_kernel<{_tname(dout.dtype)},k{self.ksize},s1,u0,NC{_nc_for(self.cin)}>",
+                2.0 * nvox * self.ksize ** 3 * self.cin * self.cout,
+                dout.numel() * es + out.numel() * es + (residual.numel() * es if residual is not None else 0))
         return out
 
     def wgrad(self, x, dout, dw, accumulate=False):
@@ -139,7 +202,12 @@ class Conv:
         if ws is None or ws.numel() < need:
             ws = torch.empty(max(need, 32 << 20), dtype=torch.uint8, device=x.device)
             Conv._ws[x.device] = ws
+        ev = _pb()
         check(L.vdm_conv_wgrad(d, _p(x), _p(dout), _p(dw), 1 if accumulate else 0, _p(ws), ws.numel(), _s()), "vdm_conv_wgrad")
+        if ev is not None:
+            es = x.element_size()
+            _pe(ev, f"conv_wgrad_kernel<{_tname(x.dtype)},k{self.ksize},s{self.stride},u{self.upsample}>+reduce",
+                2.0 * n * od * oh * ow * self.ksize ** 3 * self.cin * self.cout, x.numel() * es + dout.numel() * es)
         return dw
 
 
@@ -161,7 +229,9 @@ def gn_stats(x1, x2, groups, out=None):
     if ws is None:
         ws = _gn_ws[x1.device] = torch.empty(_lib.GN_STATS_WS_BYTES // 4, dtype=torch.float32, device=x1.device)
     c2 = 0 if x2 is None else x2.shape[-1]
+    ev = _pb()
     check(L.vdm_gn_stats(_p(x1), x1.shape[-1], _p(x2), c2, n, v, groups, dt_id(x1.dtype), _p(out), _p(ws), _s()), "vdm_gn_stats")
+    _pe(ev, "gn_stats", 0.0, x1.numel() * x1.element_size() + (x2.numel() * x2.element_size() if x2 is not None else 0))
     return out
 
 
@@ -173,8 +243,10 @@ def gn_silu_fwd(x1, x2, groups, stats, gamma, beta, dropout_p=0.0, seed=0, out=N
     c2 = 0 if x2 is None else x2.shape[-1]
     if out is None:
         out = torch.empty(x1.shape[:-1] + (c1 + c2,), dtype=x1.dtype, device=x1.device)
+    ev = _pb()
     check(L.vdm_gn_silu_fwd(_p(x1), c1, _p(x2), c2, n, v, groups, dt_id(x1.dtype), _p(stats), _p(gamma), _p(beta), GN_EPS,
                             float(dropout_p), int(seed), _p(out), _s()), "vdm_gn_silu_fwd")
+    _pe(ev, "gn_silu_fwd", 0.0, 2.0 * out.numel() * out.element_size())
     return out
 
 
@@ -195,9 +267,11 @@ def gn_silu_bwd(x1, x2, groups, stats, gamma, beta, dy, dgamma, dbeta, add1=None
     if colsum is not None:
         assert colsum.dtype == torch.float32 and colsum.stride(1) == 1 and colsum.shape[0] == n
         cstride = colsum.stride(0)
+    ev = _pb()
     check(L.vdm_gn_silu_bwd(_p(x1), c1, _p(x2), c2, n, v, groups, dt_id(x1.dtype), _p(stats), _p(gamma), _p(beta), GN_EPS,
                             float(dropout_p), int(seed), _p(dy), _p(add1), _p(add2), _p(dx1), _p(dx2), _p(dgamma), _p(dbeta),
                             _p(colsum), cstride, _p(red), _s()), "vdm_gn_silu_bwd")
+    _pe(ev, "gn_silu_bwd(reduce+apply)", 0.0, (5.0 + (1.0 if add1 is not None else 0.0)) * dy.numel() * dy.element_size())
     return dx1, dx2
 
 
