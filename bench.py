@@ -62,13 +62,13 @@ def make_batch(D, B, rank, device):
             "conditioning_values": [b["conditioning_values"][0].to(device)]}
 
 
-def cpu_baseline(chs, budget_D=64):
-    """Oracle fwd+bwd on the host cores on a bounded sample (same network, one 64^3 crop, fp32)."""
+def cpu_baseline(chs, budget_D=96):
+    """Oracle fwd+bwd on the host cores on a bounded sample (same network, one 96^3 crop, fp32)."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     from helpers import oracle_cfg, oracle_params
     from oracle import unet_oracle
     from vdm4cdm_amd.networks import CUNet
-    cores = os.cpu_count() or 1
+    cores = min(os.cpu_count() or 1, 64)          # oneDNN does not scale a 48^3 conv past a few dozen threads
     torch.set_num_threads(cores)
     net = CUNet(shape=(1, budget_D, budget_D, budget_D), chs=chs, s_conditioning_channels=1, v_conditioning_dims=[6],
                 norm_groups=8, backend="torch")

@@ -108,6 +108,45 @@ __device__ __forceinline__ void stage_halo(char* lds, const T* __restrict__ x, c
     }
 }
 
+// 64 zero bytes: source of every padded / out-of-range piece of the LDS-DMA staging below.
+__device__ uint4 g_zero_page[4];
+
+// LDS image of the forward kernel: voxel-major, 64 B per halo voxel, the four 16-B pieces of a voxel stored at
+// slot = piece ^ ((hx >> 1) & 3), hx = x position inside the halo row.  With this swizzle the MFMA operand read
+// (ds_read_b128, 16 x-consecutive voxels x 4 k-chunks) is bank-conflict-free for every row alignment, and the
+// (dz, dy, row) shifts stay compile-time ds_read offsets.
+// Filled by LDS-DMA (global_load_lds_dwordx4): one wave-instruction = 16 voxels x 64 B = 1 KiB of LDS written
+// linearly; the four lanes of a voxel fetch its (permuted) pieces, i.e. whole 64-B segments of the NDHWC row.
+template <typename T, typename G, int UPS>
+__device__ __forceinline__ void stage_halo_dma(char* lds, const T* __restrict__ x, const ConvArgs& a, int n,
+                                               int oz0, int oy0, int ox0, int kb, int wave, int lane) {
+    constexpr int EPL = DT<T>::EPL, KB = DT<T>::KB;
+    constexpr int NCHUNK = (G::HVOX + 15) / 16;
+    const int iz0 = oz0 * G::STRIDE - G::PAD, iy0 = oy0 * G::STRIDE - G::PAD, ix0 = ox0 * G::STRIDE - G::PAD;
+    const int k = lane >> 2, j = lane & 3;
+    for (int c = wave; c < NCHUNK; c += 4) {
+        const int hv = c * 16 + k;
+        const int hx = hv % G::HX;
+        const int t = hv / G::HX;
+        const int hy = t % G::HY;
+        const int hz = t / G::HY;
+        const int pc = j ^ ((hx >> 1) & 3);
+        int iz = iz0 + hz, iy = iy0 + hy, ix = ix0 + hx;
+        const int ci = kb * KB + pc * EPL;
+        bool ok = ci < a.Cin && hv < G::HVOX;
+        if (a.circular) {
+            iz = wrap(iz, a.Iz); iy = wrap(iy, a.Iy); ix = wrap(ix, a.Ix);
+        } else {
+            ok = ok && (unsigned)iz < (unsigned)a.Iz && (unsigned)iy < (unsigned)a.Iy && (unsigned)ix < (unsigned)a.Ix;
+        }
+        if (UPS) { iz >>= 1; iy >>= 1; ix >>= 1; }
+        const size_t off = ((((size_t)n * a.Sz + iz) * a.Sy + iy) * a.Sx + ix) * a.CinStride + ci;
+        const void* src = ok ? static_cast<const void*>(x + off) : static_cast<const void*>(g_zero_page);
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                         (__attribute__((address_space(3))) void*)(lds + c * 1024), 16, 0, 0);
+    }
+}
+
 // Stage the (halo-free) dOut tile of a wgrad workgroup: OVOX voxels x 64 B (one channel block).
 template <typename T, typename G>
 __device__ __forceinline__ void stage_dout(char* lds, const T* __restrict__ g, const ConvArgs& a, int n, int oz0,
@@ -180,38 +219,79 @@ __global__ void __launch_bounds__(256, 2) conv_fwd_kernel(const ConvArgs a) {
 #pragma unroll
         for (int c = 0; c < NC; ++c) acc[v][c] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    // per-row LDS base (tap 0) of this lane: piece q, halo voxel ((rz*S)*HY + ry*S)*HX + lx*S
-    int rowbase[NV];
+    // Operand-read addressing (see stage_halo_dma): address = lanex[dx] + immediate((v, dz, dy) row shifts).
+    // lanex[dx] = wave's first row + this lane's voxel (hx = lx*S + dx) + swizzled k-chunk slot.
+    static_assert(TY % NV == 0, "a wave's rows must stay inside one z-slab");
+    const int r0 = wave * NV;
+    const int wavebase = (((r0 / TY) * STRIDE) * G::HY + (r0 % TY) * STRIDE) * G::HX * 64;
+    int lanex[KS];
 #pragma unroll
-    for (int v = 0; v < NV; ++v) {
-        const int r = wave * NV + v;
-        const int rz = r / TY, ry = r % TY;
-        rowbase[v] = q * G::PLANE + (((rz * STRIDE) * G::HY + ry * STRIDE) * G::HX + lx * STRIDE) * 16;
+    for (int dx = 0; dx < KS; ++dx) {
+        const int hx = lx * STRIDE + dx;
+        lanex[dx] = wavebase + hx * 64 + ((q * 16) ^ ((hx & 6) << 3));
     }
+    constexpr int ROWB = STRIDE * G::HX * 64;            // byte shift between consecutive rows v of a wave
 
     const uint4* wbase = reinterpret_cast<const uint4*>(a.w) + (size_t)chunk * a.nkb * TAPS * NC * 64 + lane;
     const T* x = reinterpret_cast<const T*>(a.x);
 
     for (int kb = 0; kb < a.nkb; ++kb) {
         if (kb) __syncthreads();
-        stage_halo<T, G, UPS, 0>(lds, x, a, n, oz0, oy0, ox0, kb, tid);
-        __syncthreads();
+        stage_halo_dma<T, G, UPS>(lds, x, a, n, oz0, oy0, ox0, kb, wave, lane);
         const uint4* wk = wbase + (size_t)kb * TAPS * NC * 64;
-        // bf16: all taps unrolled (tap offsets become immediates).  fp32: rolled - the 4x longer MFMA
-        // chain otherwise makes the scheduler hoist LDS reads until it spills.
-        constexpr int TAP_UNROLL = sizeof(T) == 2 ? TAPS : 1;
-#pragma clang loop unroll_count(TAP_UNROLL)
-        for (int tap = 0; tap < TAPS; ++tap) {
-            const int dz = tap / (KS * KS), dy = (tap / KS) % KS, dx = tap % KS;
-            const int toff = ((dz * G::HY + dy) * G::HX + dx) * 16;
-            uint4 wf[NC];
+        if constexpr (sizeof(T) == 2) {
+            // bf16: explicit software pipeline over the fully unrolled taps.
+            //   weights (global, L2-resident)  : WPD taps ahead, ring of WPD+1 register sets
+            //   activations (LDS)              : one tap ahead, two register sets of NV fragments
+            // sched_barrier(0) pins [issue next operands] | [MFMAs of this tap] so the loads stay early.
+            constexpr int WPD = (NC <= 2) ? 2 : 1;
+            uint4 wf[WPD + 1][NC];
+            uint4 af[2][NV];
 #pragma unroll
-            for (int c = 0; c < NC; ++c) wf[c] = wk[(tap * NC + c) * 64];
+            for (int p = 0; p < WPD && p < TAPS; ++p)
 #pragma unroll
-            for (int v = 0; v < NV; ++v) {
-                const uint4 af = *reinterpret_cast<const uint4*>(lds + rowbase[v] + toff);
+                for (int c = 0; c < NC; ++c) wf[p][c] = wk[(p * NC + c) * 64];
+            __syncthreads();
 #pragma unroll
-                for (int c = 0; c < NC; ++c) mma16<T>(acc[v][c], wf[c], af);
+            for (int v = 0; v < NV; ++v) af[0][v] = *reinterpret_cast<const uint4*>(lds + lanex[0] + v * ROWB);
+#pragma unroll
+            for (int tap = 0; tap < TAPS; ++tap) {
+                if (tap + WPD < TAPS) {
+#pragma unroll
+                    for (int c = 0; c < NC; ++c) wf[(tap + WPD) % (WPD + 1)][c] = wk[((tap + WPD) * NC + c) * 64];
+                }
+                if (tap + 1 < TAPS) {
+                    const int t1 = tap + 1;
+                    const int dz = t1 / (KS * KS), dy = (t1 / KS) % KS, dx = t1 % KS;
+                    const int toff = (dz * G::HY + dy) * G::HX * 64;
+#pragma unroll
+                    for (int v = 0; v < NV; ++v)
+                        af[t1 & 1][v] = *reinterpret_cast<const uint4*>(lds + lanex[dx] + v * ROWB + toff);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int v = 0; v < NV; ++v)
+#pragma unroll
+                    for (int c = 0; c < NC; ++c) mma16<T>(acc[v][c], wf[tap % (WPD + 1)][c], af[tap & 1][v]);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        } else {
+            // fp32: MFMA-bound (4 x 32-cycle MFMAs per fragment pair); rolled tap loop keeps registers low.
+            __syncthreads();
+#pragma unroll 1
+            for (int tap = 0; tap < TAPS; ++tap) {
+                const int dz = tap / (KS * KS), dy = (tap / KS) % KS, dx = tap % KS;
+                const int toff = (dz * G::HY + dy) * G::HX * 64;
+                const int lx0 = (dx == 0) ? lanex[0] : ((dx == 1) ? lanex[KS > 1 ? 1 : 0] : lanex[KS > 2 ? 2 : 0]);
+                uint4 wf[NC];
+#pragma unroll
+                for (int c = 0; c < NC; ++c) wf[c] = wk[(tap * NC + c) * 64];
+#pragma unroll
+                for (int v = 0; v < NV; ++v) {
+                    const uint4 af = *reinterpret_cast<const uint4*>(lds + lx0 + v * ROWB + toff);
+#pragma unroll
+                    for (int c = 0; c < NC; ++c) mma16<T>(acc[v][c], wf[c], af);
+                }
             }
         }
     }
@@ -305,45 +385,52 @@ template <typename T> struct WG;     // 16x16 tiles per 64-byte channel block
 template <> struct WG<bf16_t> { static constexpr int NT = 2; };
 template <> struct WG<float> { static constexpr int NT = 1; };
 
-// transposed operand fetch: 16 channels (tile ct of the 64 B block) x the k-step's voxels.
-// bf16: two ds_read_b64_tr_b16 (rows r0 and r0+1 of 16 voxels);  fp32: four ds_read_b32.
-// `vox0`/`vox1`: LDS voxel index (already including tap shift) of x==0 in row r0 / r0+1, `xs` = x stride.
+// Transposed operand fetch: 16 channels (tile ct of the 64-B block) x the k-step's voxels.
+//   address = LDS base + per-lane offset (lane_off, computed once) + wave-uniform voxel offset (uni, bytes)
+//   bf16: two ds_read_b64_tr_b16 (rows r and r+1; the second row is a compile-time byte delta HI);
+//   fp32: four ds_read_b32 (MFMA step s reads voxel x = 4*s + (lane>>4)).
 template <typename T, int PLANE>
 struct TrFetch;
 template <int PLANE>
 struct TrFetch<bf16_t, PLANE> {
     // lane: g = lane>>4 (voxels 4g..4g+3), li = lane&15: row-in-block q' = li>>2, column quad p = li&3
-    static __device__ __forceinline__ uint4 get(const char* lds, int ct, int vox0, int vox1, int xs, int lane) {
+    static __device__ __forceinline__ int lane_off(int ct, int xs, int lane) {
         const int g = lane >> 4, li = lane & 15, qp = li >> 2, p = li & 3;
         const int pc = 2 * ct + (p >> 1);
-        const int xo = (4 * g + qp) * xs;
-        const int base = pc * (PLANE + 128) + (p & 1) * 8;
+        return pc * (PLANE + 128) + (p & 1) * 8 + (4 * g + qp) * xs * 16;
+    }
+    template <int HI, int XS>
+    static __device__ __forceinline__ uint4 get(const char* lds, int loff, int uni) {
         typedef __attribute__((address_space(3))) s16x4* lptr;
-        const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lptr)(lds + base + (vox0 + xo) * 16));
-        const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lptr)(lds + base + (vox1 + xo) * 16));
+        const char* p = lds + uni + loff;
+        const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lptr)(p));
+        const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lptr)(p + HI));
         const uint2 l2 = __builtin_bit_cast(uint2, lo), h2 = __builtin_bit_cast(uint2, hi);
         return make_uint4(l2.x, l2.y, h2.x, h2.y);
     }
 };
 template <int PLANE>
 struct TrFetch<float, PLANE> {
-    // lane: channel m = lane&15, k-slot kq = lane>>4; MFMA step s reads voxel x = 4*s + kq of row r0.
-    static __device__ __forceinline__ uint4 get(const char* lds, int ct, int vox0, int vox1, int xs, int lane) {
-        (void)ct; (void)vox1;
+    // lane: channel m = lane&15, k-slot kq = lane>>4
+    static __device__ __forceinline__ int lane_off(int ct, int xs, int lane) {
+        (void)ct;
         const int m = lane & 15, kq = lane >> 4;
-        const int pc = m >> 2;
-        const int base = pc * (PLANE + 128) + (m & 3) * 4;
+        return (m >> 2) * (PLANE + 128) + (m & 3) * 4 + kq * xs * 16;
+    }
+    template <int HI, int XS>
+    static __device__ __forceinline__ uint4 get(const char* lds, int loff, int uni) {
+        const char* p = lds + uni + loff;
         uint4 r;
-        r.x = *reinterpret_cast<const uint32_t*>(lds + base + (vox0 + (0 + kq) * xs) * 16);
-        r.y = *reinterpret_cast<const uint32_t*>(lds + base + (vox0 + (4 + kq) * xs) * 16);
-        r.z = *reinterpret_cast<const uint32_t*>(lds + base + (vox0 + (8 + kq) * xs) * 16);
-        r.w = *reinterpret_cast<const uint32_t*>(lds + base + (vox0 + (12 + kq) * xs) * 16);
+        r.x = *reinterpret_cast<const uint32_t*>(p);
+        r.y = *reinterpret_cast<const uint32_t*>(p + 4 * XS * 16);
+        r.z = *reinterpret_cast<const uint32_t*>(p + 8 * XS * 16);
+        r.w = *reinterpret_cast<const uint32_t*>(p + 12 * XS * 16);
         return r;
     }
 };
 
 template <typename T, int KS, int STRIDE, int UPS, int TZ, int TY>
-__global__ void __launch_bounds__(256, 1) conv_wgrad_kernel(const WgradArgs w) {
+__global__ void __launch_bounds__(256, 2) conv_wgrad_kernel(const WgradArgs w) {
     using G = Geo<KS, STRIDE, TZ, TY>;
     constexpr int NT = WG<T>::NT;
     constexpr int TAPS = G::TAPS;
@@ -384,6 +471,12 @@ __global__ void __launch_bounds__(256, 1) conv_wgrad_kernel(const WgradArgs w) {
 
     const T* x = reinterpret_cast<const T*>(a.x);
     const T* g = reinterpret_cast<const T*>(w.dout);
+    int lo_in[NT], lo_do[NT];
+#pragma unroll
+    for (int i = 0; i < NT; ++i) {
+        lo_in[i] = TrFetch<T, G::PLANE>::lane_off(i, STRIDE, lane);
+        lo_do[i] = TrFetch<T, G::OPLANE>::lane_off(i, 1, lane);
+    }
 
     for (int tile = pidx; tile < w.ntiles; tile += w.P) {
         int b = tile;
@@ -396,24 +489,48 @@ __global__ void __launch_bounds__(256, 1) conv_wgrad_kernel(const WgradArgs w) {
         stage_halo<T, G, UPS, 128>(lds_in, x, a, n, oz0, oy0, ox0, kb, tid);
         stage_dout<T, G>(lds_do, g, a, n, oz0, oy0, ox0, cb, w.dout_stride, tid);
         __syncthreads();
-        for (int r = row0; r < G::ROWS; r += rowinc) {
-            const int r1 = r + RSTEP - 1;
-            const int o0 = r * 16, o1 = r1 * 16;
-            const int i0 = ((r / TY) * STRIDE * G::HY + (r % TY) * STRIDE) * G::HX;
-            const int i1 = ((r1 / TY) * STRIDE * G::HY + (r1 % TY) * STRIDE) * G::HX;
-            uint4 af[NT];
+        // Software pipeline: while the MFMAs of tap t run, the transposed fragments of tap t+1 (or of the next
+        // row's tap 0 and its dOut fragments) are already in flight; sched_barrier(0) pins that order.
+        static_assert(sizeof(T) == 4 || (TY % 2) == 0, "bf16 k-step = two rows of the same z-slab");
+        constexpr int HI_IN = STRIDE * G::HX * 16;            // byte delta to the second row of a bf16 k-step
+        constexpr int HI_DO = 16 * 16;
+        auto in_base = [&](int r) { return (((r / TY) * STRIDE * G::HY + (r % TY) * STRIDE) * G::HX) * 16; };
+        uint4 af[NT], afn[NT], bfA[NT], bfB[NT];
 #pragma unroll
-            for (int i = 0; i < NT; ++i) af[i] = TrFetch<T, G::OPLANE>::get(lds_do, i, o0, o1, 1, lane);
+        for (int i = 0; i < NT; ++i) af[i] = TrFetch<T, G::OPLANE>::template get<HI_DO, 1>(lds_do, lo_do[i], row0 * 256);
+#pragma unroll
+        for (int j = 0; j < NT; ++j)
+            bfA[j] = TrFetch<T, G::PLANE>::template get<HI_IN, STRIDE>(lds_in, lo_in[j], in_base(row0) + tapoff[0] * 16);
+        for (int r = row0; r < G::ROWS; r += rowinc) {
+            const int rn = (r + rowinc < G::ROWS) ? r + rowinc : r;      // clamp: the last prefetch is harmless
+            const int i0 = in_base(r), in0 = in_base(rn);
 #pragma unroll
             for (int t = 0; t < TPW; ++t) {
-                uint4 bf[NT];
+                uint4 (&cur)[NT] = (t & 1) ? bfB : bfA;
+                uint4 (&nxt)[NT] = (t & 1) ? bfA : bfB;
+                if (t + 1 < TPW) {
 #pragma unroll
-                for (int j = 0; j < NT; ++j)
-                    bf[j] = TrFetch<T, G::PLANE>::get(lds_in, j, i0 + tapoff[t], i1 + tapoff[t], STRIDE, lane);
+                    for (int j = 0; j < NT; ++j)
+                        nxt[j] = TrFetch<T, G::PLANE>::template get<HI_IN, STRIDE>(lds_in, lo_in[j], i0 + tapoff[t + 1] * 16);
+                } else {
+#pragma unroll
+                    for (int i = 0; i < NT; ++i) afn[i] = TrFetch<T, G::OPLANE>::template get<HI_DO, 1>(lds_do, lo_do[i], rn * 256);
+#pragma unroll
+                    for (int j = 0; j < NT; ++j)
+                        nxt[j] = TrFetch<T, G::PLANE>::template get<HI_IN, STRIDE>(lds_in, lo_in[j], in0 + tapoff[0] * 16);
+                }
+                __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                 for (int i = 0; i < NT; ++i)
 #pragma unroll
-                    for (int j = 0; j < NT; ++j) mma16<T>(acc[t][i][j], af[i], bf[j]);
+                    for (int j = 0; j < NT; ++j) mma16<T>(acc[t][i][j], af[i], cur[j]);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+#pragma unroll
+            for (int i = 0; i < NT; ++i) af[i] = afn[i];
+            if (TPW & 1) {
+#pragma unroll
+                for (int j = 0; j < NT; ++j) bfA[j] = bfB[j];
             }
         }
     }
@@ -535,7 +652,7 @@ static int launch_fwd_cfg(const ConvArgs& a0, hipStream_t s) {
     using G = Geo<KS, STRIDE, TZ, TY>;
     ConvArgs a = a0;
     a.ntz = cdiv(a.Dz, TZ); a.nty = cdiv(a.Dy, TY); a.ntx = cdiv(a.Dx, 16);
-    const size_t lds = 4 * (size_t)G::PLANE;
+    const size_t lds = (size_t)((G::HVOX + 15) / 16) * 1024;
     auto kern = conv_fwd_kernel<T, TO, KS, STRIDE, UPS, NC, TZ, TY>;
     static bool attr_done = false;
     if (!attr_done) {
@@ -595,7 +712,7 @@ static int launch_wgrad_cfg(WgradArgs w, float* dw, int accumulate, int cout, in
     a.ntz = cdiv(a.Dz, TZ); a.nty = cdiv(a.Dy, TY); a.ntx = cdiv(a.Dx, 16);
     w.ntiles = a.N * a.ntz * a.nty * a.ntx;
     const int npairs = w.ncb * w.nkb;
-    int P = 256 / npairs;
+    int P = 512 / npairs;                     // persistent: ~2 workgroups per CU over all (cout, cin) block pairs
     if (P < 1) P = 1;
     if (P > w.ntiles) P = w.ntiles;
     w.P = P;
@@ -624,8 +741,8 @@ static int launch_wgrad(const WgradArgs& w, float* dw, int acc, int cout, int ci
                         hipStream_t s) {
     if (ks == 1) return launch_wgrad_cfg<T, 1, 1, 0, 4, 8>(w, dw, acc, cout, cin, ws, s);
     if (stride == 2) return launch_wgrad_cfg<T, 3, 2, 0, 2, 4>(w, dw, acc, cout, cin, ws, s);
-    if (ups) return launch_wgrad_cfg<T, 3, 1, 1, 4, 8>(w, dw, acc, cout, cin, ws, s);
-    return launch_wgrad_cfg<T, 3, 1, 0, 4, 8>(w, dw, acc, cout, cin, ws, s);
+    if (ups) return launch_wgrad_cfg<T, 3, 1, 1, 2, 8>(w, dw, acc, cout, cin, ws, s);
+    return launch_wgrad_cfg<T, 3, 1, 0, 2, 8>(w, dw, acc, cout, cin, ws, s);
 }
 
 static void fill_dims(ConvArgs& a, const vdm_conv_desc* d) {
@@ -701,7 +818,7 @@ extern "C" size_t vdm_conv_wgrad_workspace_bytes(const vdm_conv_desc* d) {
     const int CL = d->dtype == VDM_F32 ? 16 : 32;
     const int taps = d->ksize * d->ksize * d->ksize;
     const int npairs = cdiv(d->cout, CL) * cdiv(d->cin, CL);
-    int P = 256 / npairs;
+    int P = 512 / npairs;
     if (P < 1) P = 1;
     return (size_t)npairs * P * (taps > 1 ? 1 : 4) * taps * CL * CL * sizeof(float);
 }

@@ -52,7 +52,6 @@ __global__ void __launch_bounds__(256) gn_stats_kernel(const T* __restrict__ x, 
 #pragma unroll
     for (int j = 0; j < EPL; ++j) s[j] = ss[j] = 0.f;
     const int64_t start = (int64_t)bn * 256 + threadIdx.x;
-    const int pc = (int)(start % PPV);
     for (int64_t i = start; i < npieces; i += stride) {
         Piece<T> p;
         p.load(xp[i]);
@@ -60,27 +59,58 @@ __global__ void __launch_bounds__(256) gn_stats_kernel(const T* __restrict__ x, 
         for (int j = 0; j < EPL; ++j) { s[j] += p.f[j]; ss[j] += p.f[j] * p.f[j]; }
     }
     // Fixed-order block reduction (no float atomics: the forward pass must be bit-reproducible).
-    // Every thread parks its per-channel sums in LDS; thread e < 2G then walks the 256 entries in order.
     __shared__ float sm[256 * EPL * 2];
     __shared__ float sh[2 * 64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if ((64 % PPV) == 0) {
+        // lanes with equal (lane % PPV) own the same piece column: xor-butterfly over the other lane bits,
+        // then 4 waves x PPV columns x EPL channels go through LDS and 2G threads finish in channel order.
+        for (int off = 32; off >= PPV; off >>= 1) {
 #pragma unroll
-    for (int j = 0; j < EPL; ++j) {
-        sm[(threadIdx.x * EPL + j) * 2] = s[j];
-        sm[(threadIdx.x * EPL + j) * 2 + 1] = ss[j];
-    }
-    __syncthreads();
-    if ((int)threadIdx.x < 2 * G) {
-        const int g = (int)threadIdx.x >> 1, which = threadIdx.x & 1;
-        float acc = 0.f;
-        for (int t = 0; t < 256; ++t) {
-            const int pct = (int)(((int64_t)bn * 256 + t) % PPV);
-            const int c0 = pct * EPL;
-            if (g0 + c0 / gs > g || g0 + (c0 + EPL - 1) / gs < g) continue;
-#pragma unroll
-            for (int j = 0; j < EPL; ++j)
-                if (g0 + (c0 + j) / gs == g) acc += sm[(t * EPL + j) * 2 + which];
+            for (int j = 0; j < EPL; ++j) {
+                s[j] += __shfl_xor(s[j], off, 64);
+                ss[j] += __shfl_xor(ss[j], off, 64);
+            }
         }
-        sh[threadIdx.x] = acc;
+        if (lane < PPV) {
+#pragma unroll
+            for (int j = 0; j < EPL; ++j) {
+                sm[((wave * PPV + lane) * EPL + j) * 2] = s[j];
+                sm[((wave * PPV + lane) * EPL + j) * 2 + 1] = ss[j];
+            }
+        }
+        __syncthreads();
+        if ((int)threadIdx.x < 2 * G) {
+            const int g = (int)threadIdx.x >> 1, which = threadIdx.x & 1;
+            float acc = 0.f;
+            const int c_lo = (g - g0) * gs;
+            if (g >= g0 && c_lo < C) {
+                for (int c = c_lo; c < c_lo + gs; ++c)
+                    for (int w = 0; w < 4; ++w) acc += sm[((w * PPV + c / EPL) * EPL + c % EPL) * 2 + which];
+            }
+            sh[threadIdx.x] = acc;
+        }
+    } else {
+        // generic (e.g. 96 channels): every thread parks its sums; 2G threads walk the 256 entries in order.
+#pragma unroll
+        for (int j = 0; j < EPL; ++j) {
+            sm[(threadIdx.x * EPL + j) * 2] = s[j];
+            sm[(threadIdx.x * EPL + j) * 2 + 1] = ss[j];
+        }
+        __syncthreads();
+        if ((int)threadIdx.x < 2 * G) {
+            const int g = (int)threadIdx.x >> 1, which = threadIdx.x & 1;
+            float acc = 0.f;
+            const unsigned base = (unsigned)((int64_t)bn * 256 % PPV);
+            for (int t = 0; t < 256; ++t) {
+                const int c0 = (int)((base + t) % (unsigned)PPV) * EPL;
+                if (g0 + c0 / gs > g || g0 + (c0 + EPL - 1) / gs < g) continue;
+#pragma unroll
+                for (int j = 0; j < EPL; ++j)
+                    if (g0 + (c0 + j) / gs == g) acc += sm[(t * EPL + j) * 2 + which];
+            }
+            sh[threadIdx.x] = acc;
+        }
     }
     __syncthreads();
     // per-block partials; gn_stats_finalize_kernel sums them in a fixed order (bit-reproducible forward)
