@@ -385,46 +385,69 @@ template <typename T> struct WG;     // 16x16 tiles per 64-byte channel block
 template <> struct WG<bf16_t> { static constexpr int NT = 2; };
 template <> struct WG<float> { static constexpr int NT = 1; };
 
-// Transposed operand fetch: 16 channels (tile ct of the 64-B block) x the k-step's voxels.
-//   address = LDS base + per-lane offset (lane_off, computed once) + wave-uniform voxel offset (uni, bytes)
-//   bf16: two ds_read_b64_tr_b16 (rows r and r+1; the second row is a compile-time byte delta HI);
-//   fp32: four ds_read_b32 (MFMA step s reads voxel x = 4*s + (lane>>4)).
-template <typename T, int PLANE>
-struct TrFetch;
-template <int PLANE>
-struct TrFetch<bf16_t, PLANE> {
-    // lane: g = lane>>4 (voxels 4g..4g+3), li = lane&15: row-in-block q' = li>>2, column quad p = li&3
-    static __device__ __forceinline__ int lane_off(int ct, int xs, int lane) {
-        const int g = lane >> 4, li = lane & 15, qp = li >> 2, p = li & 3;
-        const int pc = 2 * ct + (p >> 1);
-        return pc * (PLANE + 128) + (p & 1) * 8 + (4 * g + qp) * xs * 16;
+// dOut tile of a wgrad workgroup by LDS-DMA: OVOX voxels x 64 B (one cout block), same x-swizzled voxel-major
+// image as stage_halo_dma (one chunk = one 16-voxel row).
+template <typename T, typename G>
+__device__ __forceinline__ void stage_dout_dma(char* lds, const T* __restrict__ g, const ConvArgs& a, int n, int oz0, int oy0,
+                                               int ox0, int cb, int cstride, int wave, int lane) {
+    constexpr int EPL = DT<T>::EPL, KB = DT<T>::KB;
+    const int k = lane >> 2, j = lane & 3;
+    const int pc = j ^ ((k >> 1) & 3);
+    const int co = cb * KB + pc * EPL;
+    for (int r = wave; r < G::ROWS; r += 4) {
+        const int oz = oz0 + r / G::TY, oy = oy0 + r % G::TY, ox = ox0 + k;
+        const bool ok = co < a.Cout && oz < a.Dz && oy < a.Dy && ox < a.Dx;
+        const size_t off = ((((size_t)n * a.Dz + oz) * a.Dy + oy) * a.Dx + ox) * cstride + co;
+        const void* src = ok ? static_cast<const void*>(g + off) : static_cast<const void*>(g_zero_page);
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                         (__attribute__((address_space(3))) void*)(lds + r * 1024), 16, 0, 0);
     }
-    template <int HI, int XS>
-    static __device__ __forceinline__ uint4 get(const char* lds, int loff, int uni) {
+}
+
+// Transposed operand fetch from the x-swizzled voxel-major image: 16 channels (tile ct of the 64-B block) x the
+// k-step's voxels.  address = LDS base + wave-uniform row/tap offset (uni) + per-lane offset(s) (computed once per tap).
+//   bf16: NOFF = 1, two ds_read_b64_tr_b16 (rows r and r+1; the second row is a compile-time byte delta HI);
+//         lane: g = lane>>4 (voxels 4g..4g+3), li = lane&15: voxel-in-quad q' = li>>2, column quad p = li&3.
+//         Voxels x and x+4 of a 32-lane half use opposite piece pairs ((hx>>1)&3 differs by 2): conflict-free.
+//   fp32: NOFF = 4, four ds_read_b32 (MFMA step s reads voxel x = 4*s + (lane>>4), channel lane&15).
+template <typename T> struct TrFetch;
+template <> struct TrFetch<bf16_t> {
+    static constexpr int NOFF = 1;
+    static __device__ __forceinline__ void lane_off(int (&o)[1], int ct, int xs, int dx, int lane) {
+        const int g = lane >> 4, li = lane & 15, qp = li >> 2, p = li & 3;
+        const int hx = (4 * g + qp) * xs + dx;
+        const int slot = (2 * ct + (p >> 1)) ^ ((hx >> 1) & 3);
+        o[0] = hx * 64 + slot * 16 + (p & 1) * 8;
+    }
+    template <int HI>
+    static __device__ __forceinline__ uint4 get(const char* lds, const int (&o)[1], int uni) {
         typedef __attribute__((address_space(3))) s16x4* lptr;
-        const char* p = lds + uni + loff;
+        const char* p = lds + uni + o[0];
         const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lptr)(p));
         const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lptr)(p + HI));
         const uint2 l2 = __builtin_bit_cast(uint2, lo), h2 = __builtin_bit_cast(uint2, hi);
         return make_uint4(l2.x, l2.y, h2.x, h2.y);
     }
 };
-template <int PLANE>
-struct TrFetch<float, PLANE> {
-    // lane: channel m = lane&15, k-slot kq = lane>>4
-    static __device__ __forceinline__ int lane_off(int ct, int xs, int lane) {
+template <> struct TrFetch<float> {
+    static constexpr int NOFF = 4;
+    static __device__ __forceinline__ void lane_off(int (&o)[4], int ct, int xs, int dx, int lane) {
         (void)ct;
         const int m = lane & 15, kq = lane >> 4;
-        return (m >> 2) * (PLANE + 128) + (m & 3) * 4 + kq * xs * 16;
+#pragma unroll
+        for (int st = 0; st < 4; ++st) {
+            const int hx = (4 * st + kq) * xs + dx;
+            o[st] = hx * 64 + (((m >> 2) ^ ((hx >> 1) & 3)) * 16) + (m & 3) * 4;
+        }
     }
-    template <int HI, int XS>
-    static __device__ __forceinline__ uint4 get(const char* lds, int loff, int uni) {
-        const char* p = lds + uni + loff;
+    template <int HI>
+    static __device__ __forceinline__ uint4 get(const char* lds, const int (&o)[4], int uni) {
+        const char* p = lds + uni;
         uint4 r;
-        r.x = *reinterpret_cast<const uint32_t*>(p);
-        r.y = *reinterpret_cast<const uint32_t*>(p + 4 * XS * 16);
-        r.z = *reinterpret_cast<const uint32_t*>(p + 8 * XS * 16);
-        r.w = *reinterpret_cast<const uint32_t*>(p + 12 * XS * 16);
+        r.x = *reinterpret_cast<const uint32_t*>(p + o[0]);
+        r.y = *reinterpret_cast<const uint32_t*>(p + o[1]);
+        r.z = *reinterpret_cast<const uint32_t*>(p + o[2]);
+        r.w = *reinterpret_cast<const uint32_t*>(p + o[3]);
         return r;
     }
 };
@@ -432,11 +455,15 @@ struct TrFetch<float, PLANE> {
 template <typename T, int KS, int STRIDE, int UPS, int TZ, int TY>
 __global__ void __launch_bounds__(256, 2) conv_wgrad_kernel(const WgradArgs w) {
     using G = Geo<KS, STRIDE, TZ, TY>;
-    constexpr int NT = WG<T>::NT;
+    using TF = TrFetch<T>;
+    constexpr int NT = WG<T>::NT, NOFF = TF::NOFF;
     constexpr int TAPS = G::TAPS;
     constexpr int TPW = (TAPS + 3) / 4;                    // taps per wave (KS=3: 7; KS=1: 1)
     constexpr int RSTEP = (sizeof(T) == 2) ? 2 : 1;        // rows consumed per k-step
-    constexpr int IN_BYTES = 4 * (G::PLANE + 128);
+    constexpr int IN_BYTES = ((G::HVOX + 15) / 16) * 1024;
+    static_assert(sizeof(T) == 4 || (TY % 2) == 0, "bf16 k-step = two rows of the same z-slab");
+    constexpr int HI_IN = STRIDE * G::HX * 64;             // byte delta to the second row of a bf16 k-step
+    constexpr int HI_DO = 16 * 64;
     extern __shared__ __attribute__((aligned(16))) char lds[];
     char* lds_in = lds;
     char* lds_do = lds + IN_BYTES;
@@ -458,25 +485,26 @@ __global__ void __launch_bounds__(256, 2) conv_wgrad_kernel(const WgradArgs w) {
             for (int j = 0; j < NT; ++j) acc[t][i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
     // KS=3: wave owns taps wave, wave+4, ... over all rows.  KS=1: all waves own tap 0, rows split.
-    int tapoff[TPW];
+    int tap_u[TPW];                       // wave-uniform byte offset of the tap's (dz, dy) shift
+    int lo_in[TPW][NT][NOFF];             // per-lane offsets (depend on the tap's dx through the x-swizzle)
+    int lo_do[NT][NOFF];
 #pragma unroll
     for (int t = 0; t < TPW; ++t) {
         int tap = (TAPS > 1) ? wave + 4 * t : 0;
         if (tap >= TAPS) tap = TAPS - 1;                   // dummy (result discarded)
         const int dz = tap / (KS * KS), dy = (tap / KS) % KS, dx = tap % KS;
-        tapoff[t] = (dz * G::HY + dy) * G::HX + dx;
+        tap_u[t] = (dz * G::HY + dy) * G::HX * 64;
+#pragma unroll
+        for (int j = 0; j < NT; ++j) TF::lane_off(lo_in[t][j], j, STRIDE, dx, lane);
     }
+#pragma unroll
+    for (int i = 0; i < NT; ++i) TF::lane_off(lo_do[i], i, 1, 0, lane);
     const int row0 = (TAPS > 1) ? 0 : wave * RSTEP;
     const int rowinc = (TAPS > 1) ? RSTEP : 4 * RSTEP;
 
     const T* x = reinterpret_cast<const T*>(a.x);
     const T* g = reinterpret_cast<const T*>(w.dout);
-    int lo_in[NT], lo_do[NT];
-#pragma unroll
-    for (int i = 0; i < NT; ++i) {
-        lo_in[i] = TrFetch<T, G::PLANE>::lane_off(i, STRIDE, lane);
-        lo_do[i] = TrFetch<T, G::OPLANE>::lane_off(i, 1, lane);
-    }
+    auto in_base = [&](int r) { return (((r / TY) * STRIDE * G::HY + (r % TY) * STRIDE) * G::HX) * 64; };
 
     for (int tile = pidx; tile < w.ntiles; tile += w.P) {
         int b = tile;
@@ -485,22 +513,17 @@ __global__ void __launch_bounds__(256, 2) conv_wgrad_kernel(const WgradArgs w) {
         const int tz = b % a.ntz; b /= a.ntz;
         const int n = b;
         const int oz0 = tz * TZ, oy0 = ty * TY, ox0 = tx * 16;
-        __syncthreads();
-        stage_halo<T, G, UPS, 128>(lds_in, x, a, n, oz0, oy0, ox0, kb, tid);
-        stage_dout<T, G>(lds_do, g, a, n, oz0, oy0, ox0, cb, w.dout_stride, tid);
-        __syncthreads();
+        __syncthreads();                                   // every wave is done reading the previous tile
+        stage_halo_dma<T, G, UPS>(lds_in, x, a, n, oz0, oy0, ox0, kb, wave, lane);
+        stage_dout_dma<T, G>(lds_do, g, a, n, oz0, oy0, ox0, cb, w.dout_stride, wave, lane);
+        __syncthreads();                                   // (drains the LDS-DMA: vmcnt(0) + barrier)
         // Software pipeline: while the MFMAs of tap t run, the transposed fragments of tap t+1 (or of the next
         // row's tap 0 and its dOut fragments) are already in flight; sched_barrier(0) pins that order.
-        static_assert(sizeof(T) == 4 || (TY % 2) == 0, "bf16 k-step = two rows of the same z-slab");
-        constexpr int HI_IN = STRIDE * G::HX * 16;            // byte delta to the second row of a bf16 k-step
-        constexpr int HI_DO = 16 * 16;
-        auto in_base = [&](int r) { return (((r / TY) * STRIDE * G::HY + (r % TY) * STRIDE) * G::HX) * 16; };
         uint4 af[NT], afn[NT], bfA[NT], bfB[NT];
 #pragma unroll
-        for (int i = 0; i < NT; ++i) af[i] = TrFetch<T, G::OPLANE>::template get<HI_DO, 1>(lds_do, lo_do[i], row0 * 256);
+        for (int i = 0; i < NT; ++i) af[i] = TF::template get<HI_DO>(lds_do, lo_do[i], row0 * 1024);
 #pragma unroll
-        for (int j = 0; j < NT; ++j)
-            bfA[j] = TrFetch<T, G::PLANE>::template get<HI_IN, STRIDE>(lds_in, lo_in[j], in_base(row0) + tapoff[0] * 16);
+        for (int j = 0; j < NT; ++j) bfA[j] = TF::template get<HI_IN>(lds_in, lo_in[0][j], in_base(row0) + tap_u[0]);
         for (int r = row0; r < G::ROWS; r += rowinc) {
             const int rn = (r + rowinc < G::ROWS) ? r + rowinc : r;      // clamp: the last prefetch is harmless
             const int i0 = in_base(r), in0 = in_base(rn);
@@ -510,14 +533,12 @@ __global__ void __launch_bounds__(256, 2) conv_wgrad_kernel(const WgradArgs w) {
                 uint4 (&nxt)[NT] = (t & 1) ? bfA : bfB;
                 if (t + 1 < TPW) {
 #pragma unroll
-                    for (int j = 0; j < NT; ++j)
-                        nxt[j] = TrFetch<T, G::PLANE>::template get<HI_IN, STRIDE>(lds_in, lo_in[j], i0 + tapoff[t + 1] * 16);
+                    for (int j = 0; j < NT; ++j) nxt[j] = TF::template get<HI_IN>(lds_in, lo_in[t + 1 < TPW ? t + 1 : 0][j], i0 + tap_u[t + 1 < TPW ? t + 1 : 0]);
                 } else {
 #pragma unroll
-                    for (int i = 0; i < NT; ++i) afn[i] = TrFetch<T, G::OPLANE>::template get<HI_DO, 1>(lds_do, lo_do[i], rn * 256);
+                    for (int i = 0; i < NT; ++i) afn[i] = TF::template get<HI_DO>(lds_do, lo_do[i], rn * 1024);
 #pragma unroll
-                    for (int j = 0; j < NT; ++j)
-                        nxt[j] = TrFetch<T, G::PLANE>::template get<HI_IN, STRIDE>(lds_in, lo_in[j], in0 + tapoff[0] * 16);
+                    for (int j = 0; j < NT; ++j) nxt[j] = TF::template get<HI_IN>(lds_in, lo_in[0][j], in0 + tap_u[0]);
                 }
                 __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -555,19 +576,35 @@ __global__ void __launch_bounds__(256, 2) conv_wgrad_kernel(const WgradArgs w) {
     }
 }
 
-// dw[tap][co][ci] (+)= sum over slabs
-__global__ void wgrad_reduce_kernel(const float* __restrict__ slabs, float* __restrict__ dw, int taps, int cout, int cin,
-                                    int ncb, int nkb, int CL, int nslabs, int accumulate) {
+// dw[tap][co][ci] (+)= sum over slabs.  Block = 64 outputs x 4 slab groups; each thread sums its slabs with 8
+// independent loads in flight, then the 4 groups are combined through LDS in a fixed order (deterministic).
+__global__ void __launch_bounds__(256) wgrad_reduce_kernel(const float* __restrict__ slabs, float* __restrict__ dw, int taps,
+                                                          int cout, int cin, int ncb, int nkb, int CL, int nslabs, int accumulate) {
     const int total = taps * cout * cin;
-    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+    const int o = threadIdx.x & 63, sg = threadIdx.x >> 6;
+    const int i = blockIdx.x * 64 + o;
+    __shared__ float part[4][64];
+    float sum = 0.f;
+    if (i < total) {
         const int ci = i % cin, co = (i / cin) % cout, tap = i / (cin * cout);
-        const int cb = co / CL, kb = ci / CL;
-        const int pair = cb * nkb + kb;
+        const int pair = (co / CL) * nkb + ci / CL;
         const size_t slab_elems = (size_t)taps * CL * CL;
         const float* s = slabs + (size_t)pair * nslabs * slab_elems + ((size_t)tap * CL + co % CL) * CL + ci % CL;
-        float sum = 0.f;
-        for (int k = 0; k < nslabs; ++k) sum += s[(size_t)k * slab_elems];
-        dw[i] = accumulate ? dw[i] + sum : sum;
+        int k = sg;
+        for (; k + 28 < nslabs; k += 32) {
+            float v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = s[(size_t)(k + 4 * u) * slab_elems];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) sum += v[u];
+        }
+        for (; k < nslabs; k += 4) sum += s[(size_t)k * slab_elems];
+    }
+    part[sg][o] = sum;
+    __syncthreads();
+    if (sg == 0 && i < total) {
+        const float tot = (part[0][o] + part[1][o]) + (part[2][o] + part[3][o]);
+        dw[i] = accumulate ? dw[i] + tot : tot;
     }
 }
 
@@ -719,7 +756,7 @@ static int launch_wgrad_cfg(WgradArgs w, float* dw, int accumulate, int cout, in
     const int per_wg = (G::TAPS > 1) ? 1 : 4;
     const size_t need = (size_t)npairs * P * per_wg * G::TAPS * CL * CL * sizeof(float);
     if (need > ws_bytes) { set_error("conv_wgrad: workspace too small (%zu < %zu)", ws_bytes, need); return VDM_ERR_ARG; }
-    const size_t lds = 4 * ((size_t)G::PLANE + 128) + 4 * ((size_t)G::OPLANE + 128);
+    const size_t lds = (size_t)((G::HVOX + 15) / 16) * 1024 + (size_t)G::OVOX * 64;
     auto kern = conv_wgrad_kernel<T, KS, STRIDE, UPS, TZ, TY>;
     static bool attr_done = false;
     if (!attr_done) {
@@ -730,7 +767,7 @@ static int launch_wgrad_cfg(WgradArgs w, float* dw, int accumulate, int cout, in
     hipLaunchKernelGGL(kern, dim3(npairs * P), dim3(256), lds, s, w);
     VDM_LAUNCH_CHECK("conv_wgrad_kernel");
     const int total = G::TAPS * cout * cin;
-    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(cdiv(total, 256) < 1024 ? cdiv(total, 256) : 1024), dim3(256), 0, s,
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(cdiv(total, 64)), dim3(256), 0, s,
                        (const float*)w.slabs, dw, G::TAPS, cout, cin, w.ncb, w.nkb, CL, P * per_wg, accumulate);
     VDM_LAUNCH_CHECK("wgrad_reduce_kernel");
     return VDM_OK;
