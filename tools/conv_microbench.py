@@ -1,0 +1,66 @@
+#!/usr/bin/env python
+"""Micro-benchmark of the conv kernels at the shapes of the 128^3 VDM UNet (B=2): fwd / dgrad / wgrad TFLOP/s.
+    python tools/conv_microbench.py [--dtype bf16] [--only L0_32_32] [--iters 20] [--ops fwd,dgrad,wgrad]
+"""
+import argparse
+import os
+import sys
+import time
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from vdm4cdm_amd import hip_ops as ops  # noqa: E402
+
+SHAPES = [  # name, N, D (output), cin, cout, ks, stride, ups
+    ("L0_32_32", 2, 128, 32, 32, 3, 1, 0),
+    ("L0_64_32", 2, 128, 64, 32, 3, 1, 0),
+    ("L0_up_64_32", 2, 128, 64, 32, 3, 1, 1),
+    ("L1_64_64", 2, 64, 64, 64, 3, 1, 0),
+    ("L1_128_64", 2, 64, 128, 64, 3, 1, 0),
+    ("L2_128_128", 2, 32, 128, 128, 3, 1, 0),
+    ("L3_256_256", 2, 16, 256, 256, 3, 1, 0),
+    ("L0_down_32_32", 2, 64, 32, 32, 3, 2, 0),
+    ("L0_skip_64_32", 2, 128, 64, 32, 1, 1, 0),
+]
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--dtype", default="bf16")
+    ap.add_argument("--only", default="")
+    ap.add_argument("--iters", type=int, default=20)
+    ap.add_argument("--ops", default="fwd,dgrad,wgrad")
+    args = ap.parse_args()
+    dt = torch.bfloat16 if args.dtype == "bf16" else torch.float32
+    dev = "cuda:0"
+    for name, N, D, cin, cout, ks, stride, ups in SHAPES:
+        if args.only and args.only not in name:
+            continue
+        conv = ops.Conv(cin, cout, ks, stride=stride, upsample=ups)
+        w = torch.randn(ks ** 3, cout, cin, device=dev) * 0.05
+        conv.pack(w, dt, need_dgrad=True)
+        iD = D * 2 if stride == 2 else (D // 2 if ups else D)
+        x = torch.randn(N, iD, iD, iD, cin, device=dev).to(dt)
+        dout = torch.randn(N, D, D, D, cout, device=dev).to(dt)
+        dw = torch.zeros(ks ** 3, cout, cin, device=dev)
+        flops = 2.0 * N * D ** 3 * ks ** 3 * cin * cout
+        res = []
+        for op in args.ops.split(","):
+            if op == "dgrad" and stride == 2:
+                continue
+            fn = {"fwd": lambda: conv.fwd(x), "dgrad": lambda: conv.dgrad(dout), "wgrad": lambda: conv.wgrad(x, dout, dw)}[op]
+            for _ in range(3):
+                fn()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(args.iters):
+                fn()
+            torch.cuda.synchronize()
+            dtm = (time.perf_counter() - t0) / args.iters
+            res.append(f"{op} {dtm * 1e3:7.3f} ms {flops / dtm / 1e12:7.1f} TF/s")
+        print(f"{name:16s} " + " | ".join(res), flush=True)
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,184 @@
+"""Entry points with the reference's command lines.
+
+* ``trainVDM3D*_..._thick_lowbatch.py <field_in> <field_out> <cropsize>`` ->  ``train_vdm3d(variant, argv)``
+  (hyper-parameters per variant: /root/reference/trainVDM3D{,128,160,192,224}_c_c_from_field_name_thick_lowbatch.py:57-73,
+  trainVDM3D_c_uc_from_field_name_thick_lowbatch.py:57-73; trainer settings :38-49).
+* ``train_uc_uc_from_field_name.py <field_name>`` (2D, learned-linear schedule, circular padding; BASELINE config C1 runs it on
+  CPU PyTorch) -> ``train_uc_uc(argv)`` (/root/reference/train_uc_uc_from_field_name.py:50-120).
+* ``generate_3D.py <model_name> <save_path> <runtype>`` -> ``generate_3d(argv)`` (/root/reference/generate_3D.py).
+Environment knobs (build-side, all optional): VDM4CDM_MAX_STEPS, VDM4CDM_PRECISION (bf16|fp32), VDM4CDM_SAMPLING_STEPS,
+VDM4CDM_LOG_DIR, VDM4CDM_CROPSIZE_2D / VDM4CDM_BATCH_2D (shrink the 2D plumbing config).
+Multi-GPU: launch the same script under ``python -m torch.distributed.run --nproc-per-node N`` (one rank per GPU, RCCL).
+"""
+import argparse
+import os
+import sys
+
+import numpy as np
+import torch
+
+# variant -> (dataset_name, chs, conditioning_values, val_check_interval, experiment-name pattern, slab thickness of the image)
+VDM3D_VARIANTS = {
+    "128": ("CMD_128", [32, 64, 128, 256], 6, 1000, "LH128_c_c_{i}_to_{o}_thick_lowbatch_{c}", 48),
+    "160": ("CMD_160", [32, 64, 128, 256], 6, 5000, "LH160_c_c_{i}_to_{o}_thick_lowbatch_{c}", 48),
+    "192": ("CMD_192", [32, 64, 128, 256], 6, 5000, "LH192_c_c_{i}_to_{o}_thick_lowbatch_{c}_re2", 48),
+    "224": ("CMD_224", [16, 32, 64, 128], 6, 5000, "LH224_c_c_{i}_to_{o}_thick_lowbatch_{c}", 48),
+    "256": ("CMD", [16, 32, 64, 128], 6, 5000, "LH_c_c_{i}_to_{o}_thick_lowbatch_{c}_re3", 32),
+    "256_c_uc": ("CMD", [16, 32, 64, 128], 0, 5000, "LH_c_uc_{i}_to_{o}_thick_lowbatch_{c}_re2", 32),
+}
+
+
+def _seed_everything(seed=42):
+    import random
+    random.seed(seed)
+    np.random.seed(seed)
+    torch.manual_seed(seed)
+
+
+def _figure_closure(dm, thickness, with_values):
+    """draw_figure(batch, samples) as the scripts build it (images of a projected slab, P(k), cross-correlation)."""
+    from . import figures, utils
+
+    def to_np(t):
+        return t.detach().cpu().numpy()
+
+    def x_to_im(field):
+        return to_np(dm.norm_func(dm.unnorm_func(field, 1)[0, :, :, :thickness].sum(-1), 1))
+
+    def conditioning_to_im(field):
+        return to_np(dm.norm_func(dm.unnorm_func(field, 0)[0, :, :, :thickness].sum(-1), 0))
+
+    def pk_for_plot(field):
+        ks, pks, _ = utils.pk(field[None, None] / field.sum())
+        return to_np(ks[0]), to_np(pks[0])
+
+    def cc_for_plot(f1, f2):
+        ks, ccs = utils.get_ccs(f1[None, None] / f1.sum(), f2[None, None] / f2.sum(), full=False)
+        return to_np(ks[0]), to_np(ccs[0])
+
+    def draw_figure(batch, samples):
+        return figures.draw_figure(
+            batch, samples, x_to_im=x_to_im, conditioning_to_im=conditioning_to_im,
+            conditioning_values_to_str=str if with_values else None,
+            pk_func=lambda f, ic: pk_for_plot(dm.unnorm_func(f, ic)),
+            cc_func=lambda f1, f2, ic: cc_for_plot(dm.unnorm_func(f1, ic), dm.unnorm_func(f2, ic)))
+
+    return draw_figure
+
+
+def train_vdm3d(variant, argv=None):
+    from . import data, networks, vdm_model
+    from .trainer import Trainer
+    argv = sys.argv[1:] if argv is None else argv
+    if len(argv) != 3:
+        raise SystemExit("usage: <script> <field_in> <field_out> <cropsize>")
+    field_in, field_out, cropsize = argv[0], argv[1], int(argv[2])
+    dataset_name, chs, n_values, val_every, name_pat, thick = VDM3D_VARIANTS[variant]
+    _seed_everything(42)
+    batch_size = 2
+
+    def return_func(fields, params):
+        return {"conditioning": fields[0], "x": fields[1], "conditioning_values": [params] if n_values else None}
+
+    dm = data.get_dataset(dataset_name=dataset_name, suite_name="Astrid", return_func=return_func, set_name="LH", z_name="z_0.0",
+                          channel_names=[field_in, field_out], stage="fit", batch_size=batch_size, cropsize=cropsize,
+                          num_workers=16, mmap=False)
+    score_model = networks.CUNet(
+        shape=(1, cropsize, cropsize, cropsize), chs=chs, s_conditioning_channels=1,
+        v_conditioning_dims=[] if n_values == 0 else [n_values], t_conditioning=True, norm_groups=8, mid_attn=False,
+        dropout_prob=0.1, conv_padding_mode="circular" if cropsize == 256 else "zeros", n_attention_heads=4,
+        backend="hip", precision=os.environ.get("VDM4CDM_PRECISION", "bf16"))
+    vdm = vdm_model.LightVDM(score_model=score_model, draw_figure=_figure_closure(dm, thick, n_values > 0), gamma_max=13.3,
+                             learning_rate=3.0e-4)
+    trainer = Trainer(max_steps=int(os.environ.get("VDM4CDM_MAX_STEPS", 1_000_000)), val_check_interval=val_every,
+                      gradient_clip_val=0.5, every_n_train_steps=10_000,
+                      default_root_dir=os.environ.get("VDM4CDM_LOG_DIR", "./data/logs/vdm4cdm-3D"),
+                      experiment_name=name_pat.format(i=field_in, o=field_out, c=cropsize),
+                      n_val_sampling_steps=int(os.environ.get("VDM4CDM_SAMPLING_STEPS", 250)))
+    trainer.fit(model=vdm, datamodule=dm)
+    return trainer
+
+
+def train_uc_uc(argv=None):
+    """2D unconditional VDM.  Runs on CPU PyTorch via the explicit backend='torch' (BASELINE config C1)."""
+    from . import data, networks, vdm_model
+    from .trainer import Trainer
+    argv = sys.argv[1:] if argv is None else argv
+    if len(argv) != 1:
+        raise SystemExit("usage: train_uc_uc_from_field_name.py <field_name>")
+    field_name = argv[0]
+    _seed_everything(42)
+    cropsize = int(os.environ.get("VDM4CDM_CROPSIZE_2D", 256))
+    batch_size = int(os.environ.get("VDM4CDM_BATCH_2D", 12))
+    dm = data.SyntheticAstroDataModule(cropsize=cropsize, batch_size=batch_size, dim=2, channel_names=[field_name, field_name],
+                                       conditioning=False, n_params=0,
+                                       return_func=lambda fields, params: {"x": fields[1], "conditioning": None, "conditioning_values": None})
+    score_model = networks.CUNet(shape=(1, cropsize, cropsize), chs=[48, 96, 192, 384], s_conditioning_channels=0,
+                                 v_conditioning_dims=[], t_conditioning=True, norm_groups=8, dropout_prob=0.1,
+                                 conv_padding_mode="circular", n_attention_heads=4, backend="torch")
+    vdm = vdm_model.LightVDM(score_model=score_model, gamma_min=-13.3, gamma_max=13.3, noise_schedule="learned_linear",
+                             draw_figure=None)
+    trainer = Trainer(max_steps=int(os.environ.get("VDM4CDM_MAX_STEPS", 1_000_000)), val_check_interval=5000, gradient_clip_val=0.5,
+                      every_n_train_steps=10_000, default_root_dir=os.environ.get("VDM4CDM_LOG_DIR", "./data/logs/vdm4cdm-2D"),
+                      experiment_name=f"LH_uc_uc_{field_name}", device="cpu")
+    trainer.fit(model=vdm, datamodule=dm)
+    return trainer
+
+
+GENERATE_WHITELIST = ["VDM_Go7_Mcdm_c_c_128", "VDM_Go8_Mcdm_c_c_128", "VDM_Go9_Mcdm_c_c_128", "VDM_Mstar_Mcdm_c_c_128",
+                      "VDM_Mstar_Mcdm_c_c_160", "VDM_Mstar_Mcdm_c_c_192", "VDM_Mstar_Mcdm_c_c_224", "VDM_Mstar_Mcdm_c_c_256",
+                      "VDM_Mstar_Mcdm_c_uc_256", "SFM_Mstar_Mcdm_c_c_128", "SFM_Mstar_Mcdm_c_c_256"]
+
+
+def generate_3d(argv=None, configs_path=None):
+    """Sampling entry point; (cube, repetition) chains are dealt round-robin to the ranks when launched under torchrun."""
+    import yaml
+    from . import utils
+    from .trainer import dist_env
+    ap = argparse.ArgumentParser(description="Generate 3D CDM")
+    ap.add_argument("model_name", type=str, help="Model name")
+    ap.add_argument("save_path", type=str, help="Save path")
+    ap.add_argument("runtype", type=str, help="Type of the generation")
+    args = ap.parse_args(argv)
+    assert args.model_name in GENERATE_WHITELIST, f"unknown model {args.model_name}"
+    if "SFM" in args.model_name:
+        raise NotImplementedError("This model is not implemented yet")
+    assert args.runtype in ["CV_12_12", "CV_1_128"]
+    os.makedirs(args.save_path, exist_ok=True)
+    rank, local_rank, world = dist_env()
+    device = f"cuda:{local_rank}" if torch.cuda.is_available() else "cpu"
+    if torch.cuda.is_available():
+        torch.cuda.set_device(local_rank)
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    configs = yaml.safe_load(open(configs_path or os.path.join(root, "configs.yaml")))
+    config = configs[args.model_name]
+    model = utils.get_model(config)
+    model.to(device)
+    model.eval()
+    config["data_params"].update(set_name="CV", stage="test", batch_size=1)
+    dm = utils.get_datamodule(config)
+    dm.device = device
+    n_steps = int(os.environ.get("VDM4CDM_SAMPLING_STEPS", 250))
+    n_cubes, rep, sel = (12, 12, None) if args.runtype == "CV_12_12" else (1, 128, 2)
+    rep = int(os.environ.get("VDM4CDM_REP", rep))
+    count = 0
+    for i_batch, batch in enumerate(dm.test_dataloader()):
+        if sel is not None and i_batch != sel:
+            continue
+        s_conditioning = batch["conditioning"].to(device)
+        v_conditionings = [d.to(device) for d in batch["conditioning_values"]] if config.get("conditioning_values", 6) else []
+        gens = []
+        for i in range(rep):
+            chain = count * rep + i
+            if chain % world != rank:
+                continue
+            gen = model.draw_samples(batch_size=1, n_sampling_steps=n_steps, seed=1_000_003 * chain + 17,
+                                     s_conditioning=s_conditioning, v_conditionings=v_conditionings, verbose=(rank == 0))
+            gens.append(gen.detach().cpu().numpy())
+        if gens:
+            suffix = "" if world == 1 else f"_rank{rank}"
+            np.save(os.path.join(args.save_path, f"gen_{count}{suffix}.npy"), np.concatenate(gens, axis=0))
+        count += 1
+        if count == n_cubes:
+            break
+    return count
