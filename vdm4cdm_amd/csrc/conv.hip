@@ -17,6 +17,7 @@
 //   (deterministic, no float atomics).
 #include <stdarg.h>
 #include <stdio.h>
+#include <stdlib.h>
 
 #include "common.h"
 
@@ -193,110 +194,101 @@ __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
 // ---------------------------------------------------------------------------------------------
 // forward / dgrad kernel
 // ---------------------------------------------------------------------------------------------
-template <typename T, typename TO, int KS, int STRIDE, int UPS, int NC, int TZ, int TY>
-__global__ void __launch_bounds__(256, 2) conv_fwd_kernel(const ConvArgs a) {
-    using G = Geo<KS, STRIDE, TZ, TY>;
-    constexpr int EPL = DT<T>::EPL;
-    constexpr int NV = G::NV, TAPS = G::TAPS;
-    extern __shared__ __attribute__((aligned(16))) char lds[];
-
-    const int tid = threadIdx.x;
-    const int lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+// Operand-read addressing (see stage_halo_dma): address = lanex[dx] + immediate((v, dz, dy) row shifts).
+// lanex[dx] = wave's first row + this lane's voxel (hx = lx*S + dx) + swizzled k-chunk slot.
+template <typename G, int NV>
+__device__ __forceinline__ void operand_lane_offsets(int (&lanex)[G::KS], int cwave, int lane) {
+    static_assert(G::TY % NV == 0, "a wave's rows must stay inside one z-slab");
     const int lx = lane & 15, q = lane >> 4;
-
-    int b = xcd_remap(blockIdx.x, gridDim.x);
-    const int tx = b % a.ntx; b /= a.ntx;
-    const int ty = b % a.nty; b /= a.nty;
-    const int tz = b % a.ntz; b /= a.ntz;
-    const int n = b % a.N;
-    const int chunk = b / a.N;
-    const int oz0 = tz * TZ, oy0 = ty * TY, ox0 = tx * 16;
-
-    f32x4 acc[NV][NC];
+    const int r0 = cwave * NV;
+    const int wavebase = (((r0 / G::TY) * G::STRIDE) * G::HY + (r0 % G::TY) * G::STRIDE) * G::HX * 64;
 #pragma unroll
-    for (int v = 0; v < NV; ++v)
-#pragma unroll
-        for (int c = 0; c < NC; ++c) acc[v][c] = f32x4{0.f, 0.f, 0.f, 0.f};
-
-    // Operand-read addressing (see stage_halo_dma): address = lanex[dx] + immediate((v, dz, dy) row shifts).
-    // lanex[dx] = wave's first row + this lane's voxel (hx = lx*S + dx) + swizzled k-chunk slot.
-    static_assert(TY % NV == 0, "a wave's rows must stay inside one z-slab");
-    const int r0 = wave * NV;
-    const int wavebase = (((r0 / TY) * STRIDE) * G::HY + (r0 % TY) * STRIDE) * G::HX * 64;
-    int lanex[KS];
-#pragma unroll
-    for (int dx = 0; dx < KS; ++dx) {
-        const int hx = lx * STRIDE + dx;
+    for (int dx = 0; dx < G::KS; ++dx) {
+        const int hx = lx * G::STRIDE + dx;
         lanex[dx] = wavebase + hx * 64 + ((q * 16) ^ ((hx & 6) << 3));
     }
-    constexpr int ROWB = STRIDE * G::HX * 64;            // byte shift between consecutive rows v of a wave
+}
 
-    const uint4* wbase = reinterpret_cast<const uint4*>(a.w) + (size_t)chunk * a.nkb * TAPS * NC * 64 + lane;
-    const T* x = reinterpret_cast<const T*>(a.x);
+template <int NC> struct WPipe { static constexpr int WPD = (NC <= 2) ? 2 : 1; };   // weight prefetch depth (taps)
 
-    for (int kb = 0; kb < a.nkb; ++kb) {
-        if (kb) __syncthreads();
-        stage_halo_dma<T, G, UPS>(lds, x, a, n, oz0, oy0, ox0, kb, wave, lane);
-        const uint4* wk = wbase + (size_t)kb * TAPS * NC * 64;
-        if constexpr (sizeof(T) == 2) {
-            // bf16: explicit software pipeline over the fully unrolled taps.
-            //   weights (global, L2-resident)  : WPD taps ahead, ring of WPD+1 register sets
-            //   activations (LDS)              : one tap ahead, two register sets of NV fragments
-            // sched_barrier(0) pins [issue next operands] | [MFMAs of this tap] so the loads stay early.
-            constexpr int WPD = (NC <= 2) ? 2 : 1;
-            uint4 wf[WPD + 1][NC];
-            uint4 af[2][NV];
+// bf16: first WPD taps' weights (issued before the staging barrier so their latency overlaps it)
+template <int TAPS, int NC, int WPD>
+__device__ __forceinline__ void taps_prefetch_weights(uint4 (&wf)[WPD + 1][NC], const uint4* wk) {
 #pragma unroll
-            for (int p = 0; p < WPD && p < TAPS; ++p)
+    for (int p = 0; p < WPD && p < TAPS; ++p)
 #pragma unroll
-                for (int c = 0; c < NC; ++c) wf[p][c] = wk[(p * NC + c) * 64];
-            __syncthreads();
+        for (int c = 0; c < NC; ++c) wf[p][c] = wk[(p * NC + c) * 64];
+}
+
+// bf16: explicit software pipeline over the fully unrolled taps.
+//   weights (global, L2-resident)  : WPD taps ahead, ring of WPD+1 register sets
+//   activations (LDS)              : one tap ahead, two register sets of NV fragments
+// sched_barrier(0) pins [issue next operands] | [MFMAs of this tap] so the loads stay early.
+template <typename T, typename G, int NC, int NV, int WPD>
+__device__ __forceinline__ void taps_pipelined(f32x4 (&acc)[NV][NC], const char* lds, const uint4* wk,
+                                               uint4 (&wf)[WPD + 1][NC], const int (&lanex)[G::KS]) {
+    constexpr int TAPS = G::TAPS, KS = G::KS;
+    constexpr int ROWB = G::STRIDE * G::HX * 64;            // byte shift between consecutive rows v of a wave
+    uint4 af[2][NV];
 #pragma unroll
-            for (int v = 0; v < NV; ++v) af[0][v] = *reinterpret_cast<const uint4*>(lds + lanex[0] + v * ROWB);
+    for (int v = 0; v < NV; ++v) af[0][v] = *reinterpret_cast<const uint4*>(lds + lanex[0] + v * ROWB);
 #pragma unroll
-            for (int tap = 0; tap < TAPS; ++tap) {
-                if (tap + WPD < TAPS) {
+    for (int tap = 0; tap < TAPS; ++tap) {
+        if (tap + WPD < TAPS) {
 #pragma unroll
-                    for (int c = 0; c < NC; ++c) wf[(tap + WPD) % (WPD + 1)][c] = wk[((tap + WPD) * NC + c) * 64];
-                }
-                if (tap + 1 < TAPS) {
-                    const int t1 = tap + 1;
-                    const int dz = t1 / (KS * KS), dy = (t1 / KS) % KS, dx = t1 % KS;
-                    const int toff = (dz * G::HY + dy) * G::HX * 64;
+            for (int c = 0; c < NC; ++c) wf[(tap + WPD) % (WPD + 1)][c] = wk[((tap + WPD) * NC + c) * 64];
+        }
+        if (tap + 1 < TAPS) {
+            const int t1 = tap + 1;
+            const int dz = t1 / (KS * KS), dy = (t1 / KS) % KS, dx = t1 % KS;
+            const int toff = (dz * G::HY + dy) * G::HX * 64;
 #pragma unroll
-                    for (int v = 0; v < NV; ++v)
-                        af[t1 & 1][v] = *reinterpret_cast<const uint4*>(lds + lanex[dx] + v * ROWB + toff);
-                }
-                __builtin_amdgcn_sched_barrier(0);
+            for (int v = 0; v < NV; ++v) af[t1 & 1][v] = *reinterpret_cast<const uint4*>(lds + lanex[dx] + v * ROWB + toff);
+        }
 #pragma unroll
-                for (int v = 0; v < NV; ++v)
+        for (int v = 0; v < NV; ++v)
 #pragma unroll
-                    for (int c = 0; c < NC; ++c) mma16<T>(acc[v][c], wf[tap % (WPD + 1)][c], af[tap & 1][v]);
-                __builtin_amdgcn_sched_barrier(0);
-            }
-        } else {
-            // fp32: MFMA-bound (4 x 32-cycle MFMAs per fragment pair); rolled tap loop keeps registers low.
-            __syncthreads();
+            for (int c = 0; c < NC; ++c) mma16<T>(acc[v][c], wf[tap % (WPD + 1)][c], af[tap & 1][v]);
+        // Interleave: the NC weight loads first, then one LDS read of the NEXT tap after every NC MFMAs of THIS tap
+        // (masks: 0x8 MFMA, 0x20 VMEM read, 0x100 DS read).  Keeps the matrix pipe fed while the loads issue.
+        __builtin_amdgcn_sched_group_barrier(0x20, NC, 0);
+#pragma unroll
+        for (int v = 0; v < NV; ++v) {
+            __builtin_amdgcn_sched_group_barrier(0x8, NC, 0);
+            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    }
+}
+
+// fp32: MFMA-bound (4 x 32-cycle MFMAs per fragment pair); rolled tap loop keeps registers low.
+template <typename T, typename G, int NC, int NV>
+__device__ __forceinline__ void taps_rolled(f32x4 (&acc)[NV][NC], const char* lds, const uint4* wk, const int (&lanex)[G::KS]) {
+    constexpr int TAPS = G::TAPS, KS = G::KS;
+    constexpr int ROWB = G::STRIDE * G::HX * 64;
 #pragma unroll 1
-            for (int tap = 0; tap < TAPS; ++tap) {
-                const int dz = tap / (KS * KS), dy = (tap / KS) % KS, dx = tap % KS;
-                const int toff = (dz * G::HY + dy) * G::HX * 64;
-                const int lx0 = (dx == 0) ? lanex[0] : ((dx == 1) ? lanex[KS > 1 ? 1 : 0] : lanex[KS > 2 ? 2 : 0]);
-                uint4 wf[NC];
+    for (int tap = 0; tap < TAPS; ++tap) {
+        const int dz = tap / (KS * KS), dy = (tap / KS) % KS, dx = tap % KS;
+        const int toff = (dz * G::HY + dy) * G::HX * 64;
+        const int lx0 = (dx == 0) ? lanex[0] : ((dx == 1) ? lanex[KS > 1 ? 1 : 0] : lanex[KS > 2 ? 2 : 0]);
+        uint4 wf[NC];
 #pragma unroll
-                for (int c = 0; c < NC; ++c) wf[c] = wk[(tap * NC + c) * 64];
+        for (int c = 0; c < NC; ++c) wf[c] = wk[(tap * NC + c) * 64];
 #pragma unroll
-                for (int v = 0; v < NV; ++v) {
-                    const uint4 af = *reinterpret_cast<const uint4*>(lds + lx0 + v * ROWB + toff);
+        for (int v = 0; v < NV; ++v) {
+            const uint4 af = *reinterpret_cast<const uint4*>(lds + lx0 + v * ROWB + toff);
 #pragma unroll
-                    for (int c = 0; c < NC; ++c) mma16<T>(acc[v][c], wf[c], af);
-                }
-            }
+            for (int c = 0; c < NC; ++c) mma16<T>(acc[v][c], wf[c], af);
         }
     }
+}
 
-    // ---- epilogue: + bias + per-sample conditioning bias + residual, cast, store ----------------
+// epilogue: + bias + per-sample conditioning bias + residual, cast, 16-byte NDHWC stores
+template <typename T, typename TO, typename G, int NC, int NV>
+__device__ __forceinline__ void conv_epilogue(const f32x4 (&acc)[NV][NC], const ConvArgs& a, int n, int chunk, int oz0, int oy0,
+                                              int ox0, int cwave, int lane) {
+    constexpr int EPL = DT<T>::EPL;
+    const int lx = lane & 15, q = lane >> 4;
     const int cbase = chunk * NC * 16 + q * NC * 4;     // first of this lane's NC*4 consecutive couts
     float badd[NC * 4];
 #pragma unroll
@@ -313,8 +305,8 @@ __global__ void __launch_bounds__(256, 2) conv_fwd_kernel(const ConvArgs a) {
     const T* res = reinterpret_cast<const T*>(a.res);
 #pragma unroll
     for (int v = 0; v < NV; ++v) {
-        const int r = wave * NV + v;
-        const int oz = oz0 + r / TY, oy = oy0 + r % TY, ox = ox0 + lx;
+        const int r = cwave * NV + v;
+        const int oz = oz0 + r / G::TY, oy = oy0 + r % G::TY, ox = ox0 + lx;
         if (oz >= a.Dz || oy >= a.Dy || ox >= a.Dx) continue;
         const size_t vo = ((((size_t)n * a.Dz + oz) * a.Dy + oy) * a.Dx + ox) * a.Cout + cbase;
         float val[NC * 4];
@@ -366,6 +358,56 @@ __global__ void __launch_bounds__(256, 2) conv_fwd_kernel(const ConvArgs a) {
             }
         }
     }
+}
+
+// ---------------------------------------------------------------------------------------------
+// forward / dgrad kernel, one tile per workgroup (all variants; small grids)
+// ---------------------------------------------------------------------------------------------
+template <typename T, typename TO, int KS, int STRIDE, int UPS, int NC, int TZ, int TY>
+__global__ void __launch_bounds__(256, (TZ * TY <= 16 && NC <= 2) ? 3 : 2) conv_fwd_kernel(const ConvArgs a) {
+    using G = Geo<KS, STRIDE, TZ, TY>;
+    constexpr int NV = G::NV, TAPS = G::TAPS;
+    extern __shared__ __attribute__((aligned(16))) char lds[];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+
+    int b = xcd_remap(blockIdx.x, gridDim.x);
+    const int tx = b % a.ntx; b /= a.ntx;
+    const int ty = b % a.nty; b /= a.nty;
+    const int tz = b % a.ntz; b /= a.ntz;
+    const int n = b % a.N;
+    const int chunk = b / a.N;
+    const int oz0 = tz * TZ, oy0 = ty * TY, ox0 = tx * 16;
+
+    f32x4 acc[NV][NC];
+#pragma unroll
+    for (int v = 0; v < NV; ++v)
+#pragma unroll
+        for (int c = 0; c < NC; ++c) acc[v][c] = f32x4{0.f, 0.f, 0.f, 0.f};
+    int lanex[KS];
+    operand_lane_offsets<G, NV>(lanex, wave, lane);
+
+    const uint4* wbase = reinterpret_cast<const uint4*>(a.w) + (size_t)chunk * a.nkb * TAPS * NC * 64 + lane;
+    const T* x = reinterpret_cast<const T*>(a.x);
+
+    for (int kb = 0; kb < a.nkb; ++kb) {
+        if (kb) __syncthreads();
+        stage_halo_dma<T, G, UPS>(lds, x, a, n, oz0, oy0, ox0, kb, wave, lane);
+        const uint4* wk = wbase + (size_t)kb * TAPS * NC * 64;
+        if constexpr (sizeof(T) == 2) {
+            constexpr int WPD = WPipe<NC>::WPD;
+            uint4 wf[WPD + 1][NC];
+            taps_prefetch_weights<TAPS, NC, WPD>(wf, wk);
+            __syncthreads();
+            taps_pipelined<T, G, NC, NV, WPD>(acc, lds, wk, wf, lanex);
+        } else {
+            __syncthreads();
+            taps_rolled<T, G, NC, NV>(acc, lds, wk, lanex);
+        }
+    }
+    conv_epilogue<T, TO, G, NC, NV>(acc, a, n, chunk, oz0, oy0, ox0, wave, lane);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -704,11 +746,26 @@ static int launch_fwd_cfg(const ConvArgs& a0, hipStream_t s) {
     return VDM_OK;
 }
 
+static int cu_count() {
+    static int n = 0;
+    if (n == 0) {
+        int dev = 0;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0)
+            n = 256;
+    }
+    return n;
+}
+
 template <typename T, typename TO, int KS, int STRIDE, int UPS, int NC>
 static int launch_fwd_geo(const ConvArgs& a, hipStream_t s) {
     if constexpr (STRIDE == 2)
         return launch_fwd_cfg<T, TO, KS, STRIDE, UPS, NC, 2, 4>(a, s);
-    else
+    else if constexpr (KS == 3 && sizeof(T) == 2) {
+        // small grids (deep UNet levels): 2x8x16 tiles (46 KB LDS, 3 workgroups / CU) fill the chip better
+        const long long tiles48 = (long long)a.nchunks * a.N * cdiv(a.Dz, 4) * cdiv(a.Dy, 8) * cdiv(a.Dx, 16);
+        if (tiles48 < 2LL * cu_count()) return launch_fwd_cfg<T, TO, KS, STRIDE, UPS, NC, 2, 8>(a, s);
+        return launch_fwd_cfg<T, TO, KS, STRIDE, UPS, NC, 4, 8>(a, s);
+    } else
         return launch_fwd_cfg<T, TO, KS, STRIDE, UPS, NC, 4, 8>(a, s);
 }
 
