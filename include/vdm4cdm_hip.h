@@ -72,9 +72,11 @@ int vdm_conv_fwd(const vdm_conv_desc* d, const void* x, const void* w_packed_fwd
  * gradient w.r.t. the up-sampled fine tensor - reduce it with vdm_pool2_sum). */
 int vdm_conv_dgrad(const vdm_conv_desc* d, const void* dout, const void* w_packed_dgrad, const void* residual, void* dx,
                    void* stream); /* dx = dgrad (+ residual, same shape as dx, may be NULL) */
-/* dw[taps][cout][cin] (fp32) = sum over voxels; workspace holds per-workgroup partial slabs. */
+/* dw[taps][cout][cin] (fp32) = sum over voxels; workspace holds per-workgroup partial slabs.
+ * dbias (optional, ksize 3 only): dbias[cout] = sum over samples and voxels of dout (the conv bias gradient), computed
+ * from the dOut tiles the kernel stages anyway.  accumulate != 0 adds to dw / dbias instead of overwriting. */
 size_t vdm_conv_wgrad_workspace_bytes(const vdm_conv_desc* d);
-int vdm_conv_wgrad(const vdm_conv_desc* d, const void* x, const void* dout, float* dw, int accumulate,
+int vdm_conv_wgrad(const vdm_conv_desc* d, const void* x, const void* dout, float* dw, float* dbias, int accumulate,
                    void* workspace, size_t workspace_bytes, void* stream);
 
 /* ---- K2: GroupNorm + SiLU (+ dropout) -----------------------------------------------------

@@ -152,13 +152,19 @@ def test_conv_grads(case, dtype):
     dd[..., :cout] = dout.to(dtype).to(DEV)
     # wgrad
     dw = torch.full((ks ** 3, cout, cin), float("nan"), device=DEV)
-    conv.wgrad(xd, dd, dw)
+    db = torch.full((cout,), float("nan"), device=DEV) if ks == 3 else None
+    conv.wgrad(xd, dd, dw, db)
+    if db is not None:                       # fused bias gradient = column sums of dout
+        bref = dout.reshape(-1, cout).sum(0)
+        assert (db.cpu() - bref).abs().max().item() <= 1e-3 * max(bref.abs().max().item(), 1.0) + 1e-3, f"{name}: fused dbias"
     tol_w = (2e-4 if dtype == torch.float32 else 2.0 ** -7) * max(wr.grad.abs().max().item(), 1e-6)
     err_w = (dw.cpu() - wr.grad).abs().max().item()
     assert err_w <= tol_w, f"{name}: wgrad err {err_w} > {tol_w}"
     # accumulate flag
-    conv.wgrad(xd, dd, dw, accumulate=True)
+    conv.wgrad(xd, dd, dw, db, accumulate=True)
     assert (dw.cpu() - 2 * wr.grad).abs().max().item() <= 2 * tol_w
+    if db is not None:
+        assert (db.cpu() - 2 * dout.reshape(-1, cout).sum(0)).abs().max().item() <= 2e-3 * max(dout.reshape(-1, cout).sum(0).abs().max().item(), 1.0) + 2e-3
     # dgrad
     if stride == 2:
         conv.pack(w.to(DEV), dtype, need_dgrad=True)

@@ -37,7 +37,7 @@ SIGNATURES = {
     "vdm_conv_fwd": (_i, [_D, _p, _p, _p, _p, _i64, _p, _p, _p]),
     "vdm_conv_dgrad": (_i, [_D, _p, _p, _p, _p, _p]),
     "vdm_conv_wgrad_workspace_bytes": (_sz, [_D]),
-    "vdm_conv_wgrad": (_i, [_D, _p, _p, _p, _i, _p, _sz, _p]),
+    "vdm_conv_wgrad": (_i, [_D, _p, _p, _p, _p, _i, _p, _sz, _p]),
     "vdm_gn_stats": (_i, [_p, _i, _p, _i, _i, _i64, _i, _i, _p, _p, _p]),
     "vdm_gn_silu_fwd": (_i, [_p, _i, _p, _i, _i, _i64, _i, _i, _p, _p, _p, _f, _f, _u64, _p, _p]),
     "vdm_gn_silu_bwd": (_i, [_p, _i, _p, _i, _i, _i64, _i, _i, _p, _p, _p, _f, _f, _u64, _p, _p, _p, _p, _p, _p, _p, _p, _i64, _p, _p]),

@@ -418,6 +418,7 @@ struct WgradArgs {
     const void* dout;
     int dout_stride;
     float* slabs;        // [pair][P][slot]... see wgrad_reduce
+    float* bslabs;       // optional [cout block][P][CL] partial column sums of dOut (bias gradient), or NULL
     int P;               // persistent workgroups per (cout block, cin block) pair
     int ntiles;          // N * ntz * nty * ntx
     int ncb, nkb;        // cout blocks, cin blocks (64 B each)
@@ -546,6 +547,9 @@ __global__ void __launch_bounds__(256, 2) conv_wgrad_kernel(const WgradArgs w) {
 
     const T* x = reinterpret_cast<const T*>(a.x);
     const T* g = reinterpret_cast<const T*>(w.dout);
+    float bsum[DT<T>::EPL];
+#pragma unroll
+    for (int j = 0; j < DT<T>::EPL; ++j) bsum[j] = 0.f;
     auto in_base = [&](int r) { return (((r / TY) * STRIDE * G::HY + (r % TY) * STRIDE) * G::HX) * 64; };
 
     for (int tile = pidx; tile < w.ntiles; tile += w.P) {
@@ -596,10 +600,36 @@ __global__ void __launch_bounds__(256, 2) conv_wgrad_kernel(const WgradArgs w) {
                 for (int j = 0; j < NT; ++j) bfA[j] = bfB[j];
             }
         }
+        // bias gradient: column sums of this dOut tile (already in LDS), by the workgroups with cin block 0; every wave
+        // takes a quarter of the rows.  Lane l sums the 16-B slot (l & 3) of voxels x = l >> 2: with the x-swizzle that
+        // is always the same channel piece, so the sums stay in EPL registers until the kernel ends.
+        if (TAPS > 1 && w.bslabs != nullptr && kb == 0) {
+            const int vx = lane >> 2, sl = lane & 3;
+#pragma unroll
+            for (int r = wave; r < G::ROWS; r += 4) {
+                Piece<T> pz;
+                pz.load(*reinterpret_cast<const uint4*>(lds_do + r * 1024 + vx * 64 + sl * 16));
+#pragma unroll
+                for (int j = 0; j < DT<T>::EPL; ++j) bsum[j] += pz.f[j];
+            }
+        }
     }
 
-    // ---- write this wave's partial tiles: slab[tap][co_local][ci_local] ------------------------
     constexpr int CL = NT * 16;                               // channels per 64-B block
+    if (TAPS > 1 && w.bslabs != nullptr && kb == 0) {          // workgroup-uniform condition
+        float* shb = reinterpret_cast<float*>(lds);           // all tiles are done: the LDS image is free
+        __syncthreads();
+        if (tid < CL) shb[tid] = 0.f;
+        __syncthreads();
+        {
+            const int piece = (lane & 3) ^ (((lane >> 2) >> 1) & 3);
+#pragma unroll
+            for (int j = 0; j < DT<T>::EPL; ++j) atomicAdd(&shb[piece * DT<T>::EPL + j], bsum[j]);
+        }
+        __syncthreads();
+        if (tid < CL) w.bslabs[((size_t)cb * w.P + pidx) * CL + tid] = shb[tid];
+    }
+    // ---- write this wave's partial tiles: slab[tap][co_local][ci_local] ------------------------
     constexpr int SLAB = TAPS * CL * CL;
     const int nslab_per_wg = (TAPS > 1) ? 1 : 4;
     float* slab = w.slabs + ((size_t)(pair * w.P + pidx) * nslab_per_wg + ((TAPS > 1) ? 0 : wave)) * SLAB;
@@ -648,6 +678,17 @@ __global__ void __launch_bounds__(256) wgrad_reduce_kernel(const float* __restri
         const float tot = (part[0][o] + part[1][o]) + (part[2][o] + part[3][o]);
         dw[i] = accumulate ? dw[i] + tot : tot;
     }
+}
+
+// dbias[co] (+)= sum over the P workgroups of bslab[co / CL][p][co % CL]   (fixed order: deterministic)
+__global__ void __launch_bounds__(256) wgrad_bias_reduce_kernel(const float* __restrict__ bslabs, float* __restrict__ dbias, int cout,
+                                                               int CL, int P, int accumulate) {
+    const int co = blockIdx.x * 256 + threadIdx.x;
+    if (co >= cout) return;
+    const float* s = bslabs + (size_t)(co / CL) * P * CL + co % CL;
+    float sum = 0.f;
+    for (int p = 0; p < P; ++p) sum += s[(size_t)p * CL];
+    dbias[co] = accumulate ? dbias[co] + sum : sum;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -799,7 +840,7 @@ static int launch_fwd(const ConvArgs& a, int dtype, int out_f32, int ks, int str
 }
 
 template <typename T, int KS, int STRIDE, int UPS, int TZ, int TY>
-static int launch_wgrad_cfg(WgradArgs w, float* dw, int accumulate, int cout, int cin, size_t ws_bytes, hipStream_t s) {
+static int launch_wgrad_cfg(WgradArgs w, float* dw, float* dbias, int accumulate, int cout, int cin, size_t ws_bytes, hipStream_t s) {
     using G = Geo<KS, STRIDE, TZ, TY>;
     constexpr int CL = WG<T>::NT * 16;
     ConvArgs& a = w.c;
@@ -811,8 +852,11 @@ static int launch_wgrad_cfg(WgradArgs w, float* dw, int accumulate, int cout, in
     if (P > w.ntiles) P = w.ntiles;
     w.P = P;
     const int per_wg = (G::TAPS > 1) ? 1 : 4;
-    const size_t need = (size_t)npairs * P * per_wg * G::TAPS * CL * CL * sizeof(float);
+    const size_t slab_bytes = (size_t)npairs * P * per_wg * G::TAPS * CL * CL * sizeof(float);
+    const size_t need = slab_bytes + (size_t)w.ncb * P * CL * sizeof(float);
     if (need > ws_bytes) { set_error("conv_wgrad: workspace too small (%zu < %zu)", ws_bytes, need); return VDM_ERR_ARG; }
+    if (dbias != nullptr && G::TAPS == 1) { set_error("conv_wgrad: fused bias gradient is only built for ksize 3"); return VDM_ERR_UNSUPPORTED; }
+    w.bslabs = dbias ? reinterpret_cast<float*>(reinterpret_cast<char*>(w.slabs) + slab_bytes) : nullptr;
     const size_t lds = (size_t)((G::HVOX + 15) / 16) * 1024 + (size_t)G::OVOX * 64;
     auto kern = conv_wgrad_kernel<T, KS, STRIDE, UPS, TZ, TY>;
     static bool attr_done = false;
@@ -827,16 +871,20 @@ static int launch_wgrad_cfg(WgradArgs w, float* dw, int accumulate, int cout, in
     hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(cdiv(total, 64)), dim3(256), 0, s,
                        (const float*)w.slabs, dw, G::TAPS, cout, cin, w.ncb, w.nkb, CL, P * per_wg, accumulate);
     VDM_LAUNCH_CHECK("wgrad_reduce_kernel");
+    if (dbias) {
+        hipLaunchKernelGGL(wgrad_bias_reduce_kernel, dim3(cdiv(cout, 256)), dim3(256), 0, s, (const float*)w.bslabs, dbias, cout, CL, P, accumulate);
+        VDM_LAUNCH_CHECK("wgrad_bias_reduce_kernel");
+    }
     return VDM_OK;
 }
 
 template <typename T>
-static int launch_wgrad(const WgradArgs& w, float* dw, int acc, int cout, int cin, int ks, int stride, int ups, size_t ws,
+static int launch_wgrad(const WgradArgs& w, float* dw, float* db, int acc, int cout, int cin, int ks, int stride, int ups, size_t ws,
                         hipStream_t s) {
-    if (ks == 1) return launch_wgrad_cfg<T, 1, 1, 0, 4, 8>(w, dw, acc, cout, cin, ws, s);
-    if (stride == 2) return launch_wgrad_cfg<T, 3, 2, 0, 2, 4>(w, dw, acc, cout, cin, ws, s);
-    if (ups) return launch_wgrad_cfg<T, 3, 1, 1, 2, 8>(w, dw, acc, cout, cin, ws, s);
-    return launch_wgrad_cfg<T, 3, 1, 0, 2, 8>(w, dw, acc, cout, cin, ws, s);
+    if (ks == 1) return launch_wgrad_cfg<T, 1, 1, 0, 4, 8>(w, dw, db, acc, cout, cin, ws, s);
+    if (stride == 2) return launch_wgrad_cfg<T, 3, 2, 0, 2, 4>(w, dw, db, acc, cout, cin, ws, s);
+    if (ups) return launch_wgrad_cfg<T, 3, 1, 1, 2, 8>(w, dw, db, acc, cout, cin, ws, s);
+    return launch_wgrad_cfg<T, 3, 1, 0, 2, 8>(w, dw, db, acc, cout, cin, ws, s);
 }
 
 static void fill_dims(ConvArgs& a, const vdm_conv_desc* d) {
@@ -914,11 +962,11 @@ extern "C" size_t vdm_conv_wgrad_workspace_bytes(const vdm_conv_desc* d) {
     const int npairs = cdiv(d->cout, CL) * cdiv(d->cin, CL);
     int P = 512 / npairs;
     if (P < 1) P = 1;
-    return (size_t)npairs * P * (taps > 1 ? 1 : 4) * taps * CL * CL * sizeof(float);
+    return (size_t)npairs * P * (taps > 1 ? 1 : 4) * taps * CL * CL * sizeof(float) + (size_t)cdiv(d->cout, CL) * P * CL * sizeof(float);
 }
 
-extern "C" int vdm_conv_wgrad(const vdm_conv_desc* d, const void* x, const void* dout, float* dw, int accumulate, void* workspace,
-                              size_t workspace_bytes, void* stream) {
+extern "C" int vdm_conv_wgrad(const vdm_conv_desc* d, const void* x, const void* dout, float* dw, float* dbias, int accumulate,
+                              void* workspace, size_t workspace_bytes, void* stream) {
     int e = validate(d);
     if (e) return e;
     VDM_REQUIRE(x && dout && dw && workspace, "conv_wgrad: NULL pointer");
@@ -932,6 +980,6 @@ extern "C" int vdm_conv_wgrad(const vdm_conv_desc* d, const void* x, const void*
     w.ncb = cdiv(d->cout, CL); w.nkb = cdiv(d->cin, CL);
     hipStream_t s = (hipStream_t)stream;
     if (d->dtype == VDM_F32)
-        return launch_wgrad<float>(w, dw, accumulate, d->cout, d->cin, d->ksize, d->stride, d->upsample, workspace_bytes, s);
-    return launch_wgrad<bf16_t>(w, dw, accumulate, d->cout, d->cin, d->ksize, d->stride, d->upsample, workspace_bytes, s);
+        return launch_wgrad<float>(w, dw, dbias, accumulate, d->cout, d->cin, d->ksize, d->stride, d->upsample, workspace_bytes, s);
+    return launch_wgrad<bf16_t>(w, dw, dbias, accumulate, d->cout, d->cin, d->ksize, d->stride, d->upsample, workspace_bytes, s);
 }

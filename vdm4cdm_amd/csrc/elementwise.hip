@@ -264,19 +264,34 @@ __global__ void __launch_bounds__(256) gn_silu_bwd_reduce_kernel(const GnArgs a)
             sdyx[j] += d * (px.f[j] - mean[j]) * rstd[j];
         }
     }
-    // block-level accumulation in LDS: per channel (C <= 512) and per group
+    // block-level accumulation in LDS: per channel (C <= 512) and per group.  When the piece column is a function of
+    // (lane % PPV) the 64/PPV lanes of a wave that share it are first folded with xor-butterflies, so only PPV lanes per
+    // wave touch the LDS accumulators (the contended LDS atomics used to cost more than the streaming loop).
     __shared__ float shc[2 * 512];
     __shared__ float shg[2 * 64];
     for (int i = threadIdx.x; i < 2 * C; i += 256) shc[i] = 0.f;
     for (int i = threadIdx.x; i < 2 * a.G; i += 256) shg[i] = 0.f;
     __syncthreads();
+    bool writer = true;
+    if ((64 % PPV) == 0) {
+        for (int off = 32; off >= PPV; off >>= 1) {
 #pragma unroll
-    for (int j = 0; j < EPL; ++j) {
-        const int c = pc * EPL + j;
-        atomicAdd(&shc[2 * c], sdy[j]);
-        atomicAdd(&shc[2 * c + 1], sdyx[j]);
-        atomicAdd(&shg[2 * (c / gs)], gam[j] * sdy[j]);
-        atomicAdd(&shg[2 * (c / gs) + 1], gam[j] * sdyx[j]);
+            for (int j = 0; j < EPL; ++j) {
+                sdy[j] += __shfl_xor(sdy[j], off, 64);
+                sdyx[j] += __shfl_xor(sdyx[j], off, 64);
+            }
+        }
+        writer = (int)(threadIdx.x & 63) < PPV;
+    }
+    if (writer) {
+#pragma unroll
+        for (int j = 0; j < EPL; ++j) {
+            const int c = pc * EPL + j;
+            atomicAdd(&shc[2 * c], sdy[j]);
+            atomicAdd(&shc[2 * c + 1], sdyx[j]);
+            atomicAdd(&shg[2 * (c / gs)], gam[j] * sdy[j]);
+            atomicAdd(&shg[2 * (c / gs) + 1], gam[j] * sdyx[j]);
+        }
     }
     __syncthreads();
     for (int i = threadIdx.x; i < C; i += 256) {
@@ -358,8 +373,18 @@ __global__ void __launch_bounds__(256) gn_silu_bwd_apply_kernel(const GnArgs a) 
         __shared__ float shc[512];
         for (int i = threadIdx.x; i < C; i += 256) shc[i] = 0.f;
         __syncthreads();
+        bool writer = true;
+        if ((64 % PPV) == 0) {
+            for (int off = 32; off >= PPV; off >>= 1) {
 #pragma unroll
-        for (int j = 0; j < EPL; ++j) atomicAdd(&shc[pc * EPL + j], cs[j]);
+                for (int j = 0; j < EPL; ++j) cs[j] += __shfl_xor(cs[j], off, 64);
+            }
+            writer = (int)(threadIdx.x & 63) < PPV;
+        }
+        if (writer) {
+#pragma unroll
+            for (int j = 0; j < EPL; ++j) atomicAdd(&shc[pc * EPL + j], cs[j]);
+        }
         __syncthreads();
         for (int i = threadIdx.x; i < C; i += 256) atomicAdd(&a.colsum[(size_t)n * a.colsum_stride + i], shc[i]);
     }
@@ -388,8 +413,18 @@ __global__ void __launch_bounds__(256) colsum_kernel(const T* __restrict__ x, in
     __shared__ float shc[512];
     for (int i = threadIdx.x; i < C; i += 256) shc[i] = 0.f;
     __syncthreads();
+    bool writer = true;
+    if ((64 % PPV) == 0) {
+        for (int off = 32; off >= PPV; off >>= 1) {
 #pragma unroll
-    for (int j = 0; j < EPL; ++j) atomicAdd(&shc[pc * EPL + j], s[j]);
+            for (int j = 0; j < EPL; ++j) s[j] += __shfl_xor(s[j], off, 64);
+        }
+        writer = (int)(threadIdx.x & 63) < PPV;
+    }
+    if (writer) {
+#pragma unroll
+        for (int j = 0; j < EPL; ++j) atomicAdd(&shc[pc * EPL + j], s[j]);
+    }
     __syncthreads();
     for (int i = threadIdx.x; i < C; i += 256) atomicAdd(&out[(size_t)n * out_stride + i], shc[i]);
 }

@@ -190,8 +190,8 @@ class Conv:
                 dout.numel() * es + out.numel() * es + (residual.numel() * es if residual is not None else 0))
         return out
 
-    def wgrad(self, x, dout, dw, accumulate=False):
-        """dw (fp32 view [taps, cout, cin]) = sum_v dout[v] (x) x[v + tap]."""
+    def wgrad(self, x, dout, dw, dbias=None, accumulate=False):
+        """dw (fp32 view [taps, cout, cin]) = sum_v dout[v] (x) x[v + tap];  dbias (optional, ksize 3): sum_v dout[v]."""
         L = _lib.lib()
         _contig(x, dout, dw)
         n, od, oh, ow, c = dout.shape
@@ -203,7 +203,7 @@ class Conv:
             ws = torch.empty(max(need, 32 << 20), dtype=torch.uint8, device=x.device)
             Conv._ws[x.device] = ws
         ev = _pb()
-        check(L.vdm_conv_wgrad(d, _p(x), _p(dout), _p(dw), 1 if accumulate else 0, _p(ws), ws.numel(), _s()), "vdm_conv_wgrad")
+        check(L.vdm_conv_wgrad(d, _p(x), _p(dout), _p(dw), _p(dbias), 1 if accumulate else 0, _p(ws), ws.numel(), _s()), "vdm_conv_wgrad")
         if ev is not None:
             es = x.element_size()
             _pe(ev, f"conv_wgrad_kernel<{_tname(x.dtype)},k{self.ksize},s{self.stride},u{self.upsample}>+reduce",

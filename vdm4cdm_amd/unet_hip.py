@@ -60,8 +60,7 @@ class _Res:
         x1, x2, st1, a1, h, st2, a2, p, seed = self.saved
         self.saved = None
         # conv2 (+ residual path shares dout)
-        self.conv2.wgrad(a2, dout, GP(n + ".conv2.weight"))
-        ops.colsum(dout, GP(n + ".conv2.bias"), 0)
+        self.conv2.wgrad(a2, dout, GP(n + ".conv2.weight"), GP(n + ".conv2.bias"))      # bias grad fused (column sums of dout)
         da2 = self.conv2.dgrad(dout)
         dh, _ = ops.gn_silu_bwd(h, None, G, st2, P(n + ".norm2.weight"), P(n + ".norm2.bias"), da2,
                                 GP(n + ".norm2.weight"), GP(n + ".norm2.bias"),
@@ -76,7 +75,7 @@ class _Res:
         if self.skip1 is not None:
             self.skip1.wgrad(x1, dout, GP(n + ".skip.weight"))
             add1 = self.skip1.dgrad(dout)
-            ops.colsum(dout, GP(n + ".skip.bias"), 0)
+            GP(n + ".skip.bias").copy_(GP(n + ".conv2.bias"))          # same column sums of dout
             if self.skip2 is not None:
                 self.skip2.wgrad(x2, dout, GP(n + ".skip2.weight"))
                 add2 = self.skip2.dgrad(dout)
@@ -173,8 +172,7 @@ class HipUNet:
         dskips = [None] * (L - 1)
         for i in range(L - 1):
             du, dskips[i] = self.res[f"ups.{i}.block"].bwd(P, GP, dh, dtable)
-            self.up[i].wgrad(coarse[i], du, GP(f"ups.{i}.up.weight"))
-            ops.colsum(du, GP(f"ups.{i}.up.bias"), 0)
+            self.up[i].wgrad(coarse[i], du, GP(f"ups.{i}.up.weight"), GP(f"ups.{i}.up.bias"))
             dfine = self.up[i].dgrad(du)
             dh = ops.pool2_sum(dfine)
             del dfine, du
@@ -182,14 +180,12 @@ class HipUNet:
             dh, _ = self.res[f"mid.{j}"].bwd(P, GP, dh, dtable)
         for i in reversed(range(L)):
             if i != L - 1:
-                self.down[i].wgrad(skips[i], dh, GP(f"downs.{i}.down.weight"))
-                ops.colsum(dh, GP(f"downs.{i}.down.bias"), 0)
+                self.down[i].wgrad(skips[i], dh, GP(f"downs.{i}.down.weight"), GP(f"downs.{i}.down.bias"))
                 dfine = ops.dilate2(dh)
                 dh = self.down[i].dgrad(dfine, residual=dskips[i])
                 del dfine
             dh, _ = self.res[f"downs.{i}.block"].bwd(P, GP, dh, dtable)
-        self.conv_in.wgrad(xin, dh, GP("conv_in.weight"))
-        ops.colsum(dh, GP("conv_in.bias"), 0)
+        self.conv_in.wgrad(xin, dh, GP("conv_in.weight"), GP("conv_in.bias"))
         # conv1 biases: column sums of the conditioning-table gradient (same additive broadcast)
         net.conv1_bias_all(gflat).copy_(dtable.sum(0))
         return gflat, dtable

@@ -312,7 +312,8 @@ class LightVDM(nn.Module):
         return loss
 
     def configure_optimizers(self):
-        return torch.optim.AdamW(self.parameters(), lr=self.learning_rate)      # D11
+        fused = all(p.is_cuda for p in self.parameters())                       # one fused kernel over the flat vector
+        return torch.optim.AdamW(self.parameters(), lr=self.learning_rate, fused=fused)      # D11
 
     def draw_samples(self, batch_size, n_sampling_steps=250, verbose=False, return_all=False, **kwargs):
         return self.model.sample(batch_size=batch_size, n_sampling_steps=n_sampling_steps, device=self.device,
