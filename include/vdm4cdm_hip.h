@@ -67,9 +67,10 @@ int vdm_conv_pack_weights(const vdm_conv_desc* d, int pack_mode, const float* w_
  * element distance between samples (the table of all blocks is one [n][sum cout] matrix). */
 int vdm_conv_fwd(const vdm_conv_desc* d, const void* x, const void* w_packed_fwd, const float* bias,
                  const float* nbias, int64_t nbias_stride, const void* residual, void* out, void* stream);
-/* dx = conv_transpose(dout, w) for stride-1 convs: the descriptor is the FORWARD conv's; dout has
- * cout channels, dx gets cin channels (spatial dims od/oh/ow; for an up-sampling conv dx is the
- * gradient w.r.t. the up-sampled fine tensor - reduce it with vdm_pool2_sum). */
+/* dx = gradient w.r.t. the conv INPUT: the descriptor is the FORWARD conv's; dout has cout channels and the output
+ * dims (od,oh,ow); dx gets cin channels and the input dims (stride 1: same; stride 2: 2x; up-sampling conv: the
+ * coarse source grid od/2...).  Stride-2 and up-sampling convs run as per-parity-class convs (no dilated /
+ * up-sampled intermediate). */
 int vdm_conv_dgrad(const vdm_conv_desc* d, const void* dout, const void* w_packed_dgrad, const void* residual, void* dx,
                    void* stream); /* dx = dgrad (+ residual, same shape as dx, may be NULL) */
 /* dw[taps][cout][cin] (fp32) = sum over voxels; workspace holds per-workgroup partial slabs.

@@ -69,6 +69,10 @@ CONV_CASES = [
     ("k3_s2_circ", 1, (4, 6, 8), 64, 64, 3, 2, 0, True),
     ("k3_ups", 1, (8, 8, 16), 64, 32, 3, 1, 1, False),
     ("k3_ups_circ", 1, (4, 8, 12), 32, 16, 3, 1, 1, True),
+    ("k3_ups_ragged", 2, (12, 20, 40), 64, 32, 3, 1, 1, False),
+    ("k3_ups_128_64", 1, (8, 16, 32), 128, 64, 3, 1, 1, False),
+    ("k3_s2_ragged", 1, (6, 10, 20), 32, 32, 3, 2, 0, False),
+    ("k3_s2_128", 1, (4, 8, 16), 128, 128, 3, 2, 0, False),
     ("k1_64_32", 2, (8, 8, 16), 64, 32, 1, 1, 0, False),
     ("k1_32_128", 1, (4, 8, 12), 32, 128, 1, 1, 0, False),
     ("k3_16_16", 1, (8, 8, 16), 16, 16, 3, 1, 0, False),
@@ -103,9 +107,9 @@ def test_conv_fwd(case, dtype):
     bias = rnd((cout,), 5)
     nbias_full = rnd((N, cout + 7), 6)                     # strided view: row stride cout+7
     res = rnd((N, D, H, W, cout), 7, dtype)
-    nb_dev = nbias_full.to(DEV)[:, 3:3 + cout]
+    nb_dev = None if ups else nbias_full.to(DEV)[:, 3:3 + cout]         # (the up-sampling conv has no conditioning bias)
     out = conv.fwd(xd, bias.to(DEV), nb_dev, to_dev(res, dtype))
-    ref = ref_conv(x, w, bias, nbias_full[:, 3:3 + cout], res, ks, stride, ups, circ)
+    ref = ref_conv(x, w, bias, None if ups else nbias_full[:, 3:3 + cout], res, ks, stride, ups, circ)
     err = (out.float().cpu() - ref).abs().max().item()
     assert out.shape == ref.shape
     assert err <= conv_tol(dtype, ref), f"{name}: max err {err} > {conv_tol(dtype, ref)}"
@@ -132,7 +136,8 @@ def test_conv_out_f32():
 
 
 GRAD_CASES = [c for c in CONV_CASES if c[0] in ("k3_32_32", "k3_32_32_ragged", "k3_64_32", "k3_32_64", "k3_128_256", "k3_cin2pad",
-                                                  "k3_cout1", "k3_circ", "k3_s2", "k3_s2_circ", "k3_ups", "k3_ups_circ", "k1_64_32",
+                                                  "k3_cout1", "k3_circ", "k3_s2", "k3_s2_circ", "k3_ups", "k3_ups_circ", "k3_ups_ragged", "k3_ups_128_64",
+                                                  "k3_s2_ragged", "k3_s2_128", "k1_64_32",
                                                   "k1_32_128", "k3_48_96")]
 
 
@@ -168,11 +173,7 @@ def test_conv_grads(case, dtype):
     # dgrad
     if stride == 2:
         conv.pack(w.to(DEV), dtype, need_dgrad=True)
-        dx = conv.dgrad(ops.dilate2(dd))
-    else:
-        dx = conv.dgrad(dd)
-        if ups:
-            dx = ops.pool2_sum(dx)
+    dx = conv.dgrad(dd)
     gref = xr.grad
     err_x = (dx.float().cpu()[..., :cin] - gref).abs().max().item()
     assert dx.shape[:-1] == gref.shape[:-1]

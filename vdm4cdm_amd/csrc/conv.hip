@@ -411,6 +411,234 @@ __global__ void __launch_bounds__(256, (TZ * TY <= 16 && NC <= 2) ? 3 : 2) conv_
 }
 
 // ---------------------------------------------------------------------------------------------
+// "Class" convolutions: the convs that couple a coarse grid c and the 2x finer grid u = 2c + p, p in {0,1}^3.
+// For a fixed parity class p only a subset of the 27 taps (possibly merged) touches a given coarse offset, so these
+// convs are run per class on the COARSE index space with a short tap list (<= 8 entries) instead of 27 taps on the fine
+// grid:
+//   * nearest-x2 up-sampling conv, forward : out[2c+p] = sum_i Weff[p][i] . C[c + o_i]        (8 merged taps;  MODE_F)
+//       per dim  p=0: {o=-1: w0, o=0: w1+w2}   p=1: {o=0: w0+w1, o=+1: w2}          -> 27/8 = 3.4x fewer FLOPs, exact
+//   * its input gradient                  : dC[c]  = sum_p sum_i Weff[p][i]^T . dOut[2(c - o_i) + p]          (MODE_B)
+//   * stride-2 conv, input gradient       : dIn[2c+p] = sum_i W[t_i]^T . dOut[c + o_i]   (1/2/4/8 taps per class; MODE_F)
+//       per dim  p=0: {o=0: w1}                p=1: {o=+1: w0, o=0: w2}             -> no zero-dilated tensor, 1/8 of the FLOPs
+// MODE_F: one workgroup = one class x one coarse tile, output scattered to the fine grid (stride 2).
+// MODE_B: one workgroup = one coarse tile; loops over the 8 classes, re-staging the class sub-grid G_p[c] = dOut[2c+p]
+//         (source stride 2) and accumulating in registers.
+// The packed weights hold 64 (class, entry) slots per (chunk, K-block); pack_weights_cls_kernel sums the master taps of
+// each slot's mask (and transposes for the gradient modes).
+// ---------------------------------------------------------------------------------------------
+struct ClsEntry { int lds_off; int dx; };                   // halo offset ((dz*HY+dy)*HX)*64 bytes and dx in 0..2
+struct ClsTable {
+    int n[8];                                                // entries per class
+    ClsEntry e[8][8];
+};
+struct ClsArgs {
+    ConvArgs c;                                              // Dz/Dy/Dx = COARSE tile index space; out dims in oD*
+    ClsTable t;
+    int oDz, oDy, oDx;                                       // output tensor spatial dims (fine for MODE_F, coarse for MODE_B)
+    int sDz, sDy, sDx;                                       // staged source tensor spatial dims
+};
+
+// LDS-DMA staging of a halo tile whose logical voxel i maps to source voxel ss*i + so (class sub-grid when ss == 2).
+template <typename T, typename G>
+__device__ __forceinline__ void stage_halo_dma_sub(char* lds, const T* __restrict__ x, const ClsArgs& ca, int n, int oz0, int oy0,
+                                                   int ox0, int kb, int ss, int soz, int soy, int sox, int wave, int lane) {
+    constexpr int EPL = DT<T>::EPL, KB = DT<T>::KB;
+    constexpr int NCHUNK = (G::HVOX + 15) / 16;
+    const ConvArgs& a = ca.c;
+    const int iz0 = oz0 - G::PAD, iy0 = oy0 - G::PAD, ix0 = ox0 - G::PAD;
+    const int k = lane >> 2, j = lane & 3;
+    for (int c = wave; c < NCHUNK; c += 4) {
+        const int hv = c * 16 + k;
+        const int hx = hv % G::HX;
+        const int t = hv / G::HX;
+        const int hy = t % G::HY;
+        const int hz = t / G::HY;
+        const int pc = j ^ ((hx >> 1) & 3);
+        int iz = iz0 + hz, iy = iy0 + hy, ix = ix0 + hx;
+        const int ci = kb * KB + pc * EPL;
+        bool ok = ci < a.Cin && hv < G::HVOX;
+        if (a.circular) {
+            iz = wrap(iz, a.Iz); iy = wrap(iy, a.Iy); ix = wrap(ix, a.Ix);
+        } else {
+            ok = ok && (unsigned)iz < (unsigned)a.Iz && (unsigned)iy < (unsigned)a.Iy && (unsigned)ix < (unsigned)a.Ix;
+        }
+        const size_t off = ((((size_t)n * ca.sDz + (ss * iz + soz)) * ca.sDy + (ss * iy + soy)) * ca.sDx + (ss * ix + sox)) * a.CinStride + ci;
+        const void* src = ok ? static_cast<const void*>(x + off) : static_cast<const void*>(g_zero_page);
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                         (__attribute__((address_space(3))) void*)(lds + c * 1024), 16, 0, 0);
+    }
+}
+
+// tap-list MFMA loop (runtime offsets): weights one entry ahead, activations one entry ahead.
+template <typename T, typename G, int NC, int NV>
+__device__ __forceinline__ void taps_list(f32x4 (&acc)[NV][NC], const char* lds, const uint4* wk /* slot 0 of this class */,
+                                          const int nent, const ClsEntry (&ent)[8], const int (&lanex)[3]) {
+    constexpr int ROWB = G::HX * 64;
+    auto lane_base = [&](int i) { return (ent[i].dx == 0 ? lanex[0] : (ent[i].dx == 1 ? lanex[1] : lanex[2])) + ent[i].lds_off; };
+    uint4 wf[2][NC];
+    uint4 af[2][NV];
+#pragma unroll
+    for (int c = 0; c < NC; ++c) wf[0][c] = wk[c * 64];
+    {
+        const int b0 = lane_base(0);
+#pragma unroll
+        for (int v = 0; v < NV; ++v) af[0][v] = *reinterpret_cast<const uint4*>(lds + b0 + v * ROWB);
+    }
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        if (i < nent) {
+            if (i + 1 < nent) {
+#pragma unroll
+                for (int c = 0; c < NC; ++c) wf[(i + 1) & 1][c] = wk[((i + 1) * NC + c) * 64];
+                const int b1 = lane_base(i + 1 < 8 ? i + 1 : 7);
+#pragma unroll
+                for (int v = 0; v < NV; ++v) af[(i + 1) & 1][v] = *reinterpret_cast<const uint4*>(lds + b1 + v * ROWB);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int v = 0; v < NV; ++v)
+#pragma unroll
+                for (int c = 0; c < NC; ++c) mma16<T>(acc[v][c], wf[i & 1][c], af[i & 1][v]);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+}
+
+// epilogue with an output coordinate map  u = os * (tile voxel) + p   (os = 1: plain; os = 2: scatter into the fine grid)
+template <typename T, typename G, int NC, int NV>
+__device__ __forceinline__ void cls_epilogue(const f32x4 (&acc)[NV][NC], const ClsArgs& ca, int n, int chunk, int oz0, int oy0, int ox0,
+                                             int os, int pz, int py, int px, int cwave, int lane) {
+    constexpr int EPL = DT<T>::EPL;
+    const ConvArgs& a = ca.c;
+    const int lx = lane & 15, q = lane >> 4;
+    const int cbase = chunk * NC * 16 + q * NC * 4;
+    float badd[NC * 4];
+#pragma unroll
+    for (int j = 0; j < NC * 4; ++j) badd[j] = (a.bias && cbase + j < a.Cout) ? a.bias[cbase + j] : 0.f;
+    const bool vec_ok = (a.Cout % (NC * 4) == 0) && (cbase + NC * 4 <= a.Cout);
+    T* out = reinterpret_cast<T*>(a.out);
+    const T* res = reinterpret_cast<const T*>(a.res);
+#pragma unroll
+    for (int v = 0; v < NV; ++v) {
+        const int r = cwave * NV + v;
+        const int cz = oz0 + r / G::TY, cy = oy0 + r % G::TY, cx = ox0 + lx;
+        if (cz >= a.Dz || cy >= a.Dy || cx >= a.Dx) continue;
+        const size_t vo = ((((size_t)n * ca.oDz + (os * cz + pz)) * ca.oDy + (os * cy + py)) * ca.oDx + (os * cx + px)) * a.Cout + cbase;
+        float val[NC * 4];
+#pragma unroll
+        for (int c = 0; c < NC; ++c)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) val[c * 4 + j] = acc[v][c][j] + badd[c * 4 + j];
+#pragma unroll
+        for (int j = 0; j < NC * 4; ++j) {
+            if (vec_ok || cbase + j < a.Cout) {
+                if (res) val[j] += ld_elem<T>(res + vo + j);
+            }
+        }
+        if (vec_ok && sizeof(T) == 2 && NC >= 2) {
+            uint16_t* o16 = reinterpret_cast<uint16_t*>(out) + vo;
+#pragma unroll
+            for (int i = 0; i < NC / 2; ++i)
+                *reinterpret_cast<uint4*>(o16 + i * 8) =
+                    make_uint4(pack_bf16x2(val[i * 8], val[i * 8 + 1]), pack_bf16x2(val[i * 8 + 2], val[i * 8 + 3]),
+                               pack_bf16x2(val[i * 8 + 4], val[i * 8 + 5]), pack_bf16x2(val[i * 8 + 6], val[i * 8 + 7]));
+        } else if (vec_ok && sizeof(T) == 4) {
+#pragma unroll
+            for (int c = 0; c < NC; ++c)
+                *reinterpret_cast<float4*>(reinterpret_cast<float*>(out) + vo + c * 4) =
+                    make_float4(val[c * 4], val[c * 4 + 1], val[c * 4 + 2], val[c * 4 + 3]);
+        } else {
+#pragma unroll
+            for (int j = 0; j < NC * 4; ++j)
+                if (cbase + j < a.Cout) st_elem<T>(out + vo + j, val[j]);
+        }
+    }
+    (void)EPL;
+}
+
+template <typename T, int NC, int MODE_B>
+__global__ void __launch_bounds__(256, 2) conv_cls_kernel(const ClsArgs ca) {
+    using G = Geo<3, 1, 4, 8>;
+    constexpr int NV = G::NV;
+    extern __shared__ __attribute__((aligned(16))) char lds[];
+    const ConvArgs& a = ca.c;
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+
+    int b = xcd_remap(blockIdx.x, gridDim.x);
+    int cls = 0;
+    if (!MODE_B) { cls = b & 7; b >>= 3; }
+    const int tx = b % a.ntx; b /= a.ntx;
+    const int ty = b % a.nty; b /= a.nty;
+    const int tz = b % a.ntz; b /= a.ntz;
+    const int n = b % a.N;
+    const int chunk = b / a.N;
+    const int oz0 = tz * G::TZ, oy0 = ty * G::TY, ox0 = tx * 16;
+
+    f32x4 acc[NV][NC];
+#pragma unroll
+    for (int v = 0; v < NV; ++v)
+#pragma unroll
+        for (int c = 0; c < NC; ++c) acc[v][c] = f32x4{0.f, 0.f, 0.f, 0.f};
+    int lanex[3];
+    operand_lane_offsets<G, NV>(lanex, wave, lane);
+    const T* x = reinterpret_cast<const T*>(a.x);
+    const uint4* wbase = reinterpret_cast<const uint4*>(a.w) + (size_t)chunk * a.nkb * 64 * NC * 64 + lane;
+
+    const int ncls = MODE_B ? 8 : 1;
+    bool first = true;
+    for (int ci = 0; ci < ncls; ++ci) {
+        const int cl = MODE_B ? ci : cls;
+        const int pz = (cl >> 2) & 1, py = (cl >> 1) & 1, px = cl & 1;
+        for (int kb = 0; kb < a.nkb; ++kb) {
+            if (!first) __syncthreads();
+            first = false;
+            if (MODE_B)
+                stage_halo_dma_sub<T, G>(lds, x, ca, n, oz0, oy0, ox0, kb, 2, pz, py, px, wave, lane);
+            else
+                stage_halo_dma_sub<T, G>(lds, x, ca, n, oz0, oy0, ox0, kb, 1, 0, 0, 0, wave, lane);
+            __syncthreads();
+            const uint4* wk = wbase + ((size_t)kb * 64 + cl * 8) * NC * 64;
+            taps_list<T, G, NC, NV>(acc, lds, wk, ca.t.n[cl], ca.t.e[cl], lanex);
+        }
+    }
+    if (MODE_B)
+        cls_epilogue<T, G, NC, NV>(acc, ca, n, chunk, oz0, oy0, ox0, 1, 0, 0, 0, wave, lane);
+    else
+        cls_epilogue<T, G, NC, NV>(acc, ca, n, chunk, oz0, oy0, ox0, 2, (cls >> 2) & 1, (cls >> 1) & 1, cls & 1, wave, lane);
+}
+
+// packed[chunk][kb][slot 0..63][ct][lane][EPL] = sum over the master taps in mask[slot] of W (transpose: W[t][k][o]).
+struct ClsMasks { unsigned m[64]; };
+template <typename T>
+__global__ void pack_weights_cls_kernel(const float* __restrict__ w, T* __restrict__ p, int cout_m, int cin_m, int nc, int nchunks,
+                                        int nkb, int transpose, const ClsMasks masks) {
+    constexpr int EPL = DT<T>::EPL, KB = DT<T>::KB;
+    const size_t total = (size_t)nchunks * nkb * 64 * nc * 64 * EPL;
+    const int O = transpose ? cin_m : cout_m, K = transpose ? cout_m : cin_m;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        size_t r = i;
+        const int j = r % EPL; r /= EPL;
+        const int lane = r % 64; r /= 64;
+        const int ct = r % nc; r /= nc;
+        const int slot = r % 64; r /= 64;
+        const int kb = r % nkb; r /= nkb;
+        const int chunk = (int)r;
+        const int m = lane & 15, q = lane >> 4;
+        const int o = chunk * nc * 16 + nc * 4 * (m >> 2) + 4 * ct + (m & 3);
+        const int k = kb * KB + q * EPL + j;
+        float v = 0.f;
+        if (o < O && k < K) {
+            const unsigned mask = masks.m[slot];
+            for (int t = 0; t < 27; ++t)
+                if ((mask >> t) & 1u) v += transpose ? w[((size_t)t * cout_m + k) * cin_m + o] : w[((size_t)t * cout_m + o) * cin_m + k];
+        }
+        st_elem<T>(p + i, v);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
 // wgrad kernel
 // ---------------------------------------------------------------------------------------------
 struct WgradArgs {
@@ -680,15 +908,26 @@ __global__ void __launch_bounds__(256) wgrad_reduce_kernel(const float* __restri
     }
 }
 
-// dbias[co] (+)= sum over the P workgroups of bslab[co / CL][p][co % CL]   (fixed order: deterministic)
+// dbias[co] (+)= sum over the P workgroups of bslab[co / CL][p][co % CL]   (fixed order: deterministic).
+// Block = 16 channels x 16 partial groups: every thread sums P/16 partials (independent loads), then an LDS tree.
 __global__ void __launch_bounds__(256) wgrad_bias_reduce_kernel(const float* __restrict__ bslabs, float* __restrict__ dbias, int cout,
                                                                int CL, int P, int accumulate) {
-    const int co = blockIdx.x * 256 + threadIdx.x;
-    if (co >= cout) return;
-    const float* s = bslabs + (size_t)(co / CL) * P * CL + co % CL;
+    const int c = threadIdx.x & 15, gp = threadIdx.x >> 4;
+    const int co = blockIdx.x * 16 + c;
+    __shared__ float part[16][17];
     float sum = 0.f;
-    for (int p = 0; p < P; ++p) sum += s[(size_t)p * CL];
-    dbias[co] = accumulate ? dbias[co] + sum : sum;
+    if (co < cout) {
+        const float* s = bslabs + (size_t)(co / CL) * P * CL + co % CL;
+        for (int p = gp; p < P; p += 16) sum += s[(size_t)p * CL];
+    }
+    part[gp][c] = sum;
+    __syncthreads();
+    if (gp == 0 && co < cout) {
+        float tot = 0.f;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) tot += part[k][c];
+        dbias[co] = accumulate ? dbias[co] + tot : tot;
+    }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -872,7 +1111,7 @@ static int launch_wgrad_cfg(WgradArgs w, float* dw, float* dbias, int accumulate
                        (const float*)w.slabs, dw, G::TAPS, cout, cin, w.ncb, w.nkb, CL, P * per_wg, accumulate);
     VDM_LAUNCH_CHECK("wgrad_reduce_kernel");
     if (dbias) {
-        hipLaunchKernelGGL(wgrad_bias_reduce_kernel, dim3(cdiv(cout, 256)), dim3(256), 0, s, (const float*)w.bslabs, dbias, cout, CL, P, accumulate);
+        hipLaunchKernelGGL(wgrad_bias_reduce_kernel, dim3(cdiv(cout, 16)), dim3(256), 0, s, (const float*)w.bslabs, dbias, cout, CL, P, accumulate);
         VDM_LAUNCH_CHECK("wgrad_bias_reduce_kernel");
     }
     return VDM_OK;
@@ -885,6 +1124,114 @@ static int launch_wgrad(const WgradArgs& w, float* dw, float* db, int acc, int c
     if (stride == 2) return launch_wgrad_cfg<T, 3, 2, 0, 2, 4>(w, dw, db, acc, cout, cin, ws, s);
     if (ups) return launch_wgrad_cfg<T, 3, 1, 1, 2, 8>(w, dw, db, acc, cout, cin, ws, s);
     return launch_wgrad_cfg<T, 3, 1, 0, 2, 8>(w, dw, db, acc, cout, cin, ws, s);
+}
+
+// ---- class-conv tables -----------------------------------------------------------------------
+enum ClsKind { CLS_UP_FWD = 0, CLS_UP_DGRAD = 1, CLS_S2_DGRAD = 2 };
+
+// per-dimension entries of parity p: (coarse offset o, set of master taps merged into the entry)
+static int cls_dim_entries(int kind, int p, int o[2], unsigned tapset[2]) {
+    if (kind == CLS_S2_DGRAD) {
+        if (p == 0) { o[0] = 0; tapset[0] = 1u << 1; return 1; }
+        o[0] = +1; tapset[0] = 1u << 0; o[1] = 0; tapset[1] = 1u << 2; return 2;
+    }
+    if (p == 0) { o[0] = -1; tapset[0] = 1u << 0; o[1] = 0; tapset[1] = (1u << 1) | (1u << 2); return 2; }
+    o[0] = 0; tapset[0] = (1u << 0) | (1u << 1); o[1] = +1; tapset[1] = 1u << 2; return 2;
+}
+
+static void build_cls(int kind, ClsTable& tab, ClsMasks& masks) {
+    using G = Geo<3, 1, 4, 8>;
+    for (int i = 0; i < 64; ++i) masks.m[i] = 0;
+    for (int cl = 0; cl < 8; ++cl) {
+        const int p[3] = {(cl >> 2) & 1, (cl >> 1) & 1, cl & 1};
+        int o[3][2];
+        unsigned ts[3][2];
+        int cnt[3];
+        for (int d = 0; d < 3; ++d) cnt[d] = cls_dim_entries(kind, p[d], o[d], ts[d]);
+        int ne = 0;
+        for (int iz = 0; iz < cnt[0]; ++iz)
+            for (int iy = 0; iy < cnt[1]; ++iy)
+                for (int ix = 0; ix < cnt[2]; ++ix) {
+                    // halo coordinate read by this entry: forward-type kernels read c + o (halo origin -1 -> o + 1);
+                    // the up-conv input gradient reads the class sub-grid at c - o (-> 1 - o)
+                    const int hz = kind == CLS_UP_DGRAD ? 1 - o[0][iz] : o[0][iz] + 1;
+                    const int hy = kind == CLS_UP_DGRAD ? 1 - o[1][iy] : o[1][iy] + 1;
+                    const int hx = kind == CLS_UP_DGRAD ? 1 - o[2][ix] : o[2][ix] + 1;
+                    tab.e[cl][ne].lds_off = (hz * G::HY + hy) * G::HX * 64;
+                    tab.e[cl][ne].dx = hx;
+                    unsigned m = 0;
+                    for (int tz = 0; tz < 3; ++tz)
+                        for (int ty = 0; ty < 3; ++ty)
+                            for (int tx = 0; tx < 3; ++tx)
+                                if (((ts[0][iz] >> tz) & 1) && ((ts[1][iy] >> ty) & 1) && ((ts[2][ix] >> tx) & 1)) m |= 1u << ((tz * 3 + ty) * 3 + tx);
+                    masks.m[cl * 8 + ne] = m;
+                    ++ne;
+                }
+        tab.n[cl] = ne;
+        for (int i = ne; i < 8; ++i) tab.e[cl][i] = tab.e[cl][0];
+    }
+}
+
+static bool uses_cls(const vdm_conv_desc* d, int dgrad) { return d->ksize == 3 && (d->upsample || (dgrad && d->stride == 2)); }
+static int cls_kind(const vdm_conv_desc* d, int dgrad) { return d->upsample ? (dgrad ? CLS_UP_DGRAD : CLS_UP_FWD) : CLS_S2_DGRAD; }
+
+template <typename T, int NC, int MODE_B>
+static int launch_cls_cfg(const ClsArgs& ca0, hipStream_t s) {
+    using G = Geo<3, 1, 4, 8>;
+    ClsArgs ca = ca0;
+    ConvArgs& a = ca.c;
+    a.ntz = cdiv(a.Dz, G::TZ); a.nty = cdiv(a.Dy, G::TY); a.ntx = cdiv(a.Dx, 16);
+    const size_t lds = (size_t)((G::HVOX + 15) / 16) * 1024;
+    auto kern = conv_cls_kernel<T, NC, MODE_B>;
+    static bool attr_done = false;
+    if (!attr_done) {
+        int e = set_lds(kern, lds);
+        if (e) return e;
+        attr_done = true;
+    }
+    const long long nwg = (long long)a.N * a.ntz * a.nty * a.ntx * a.nchunks * (MODE_B ? 1 : 8);
+    if (nwg > 0x7fffffffLL) { set_error("conv(class): grid too large"); return VDM_ERR_ARG; }
+    hipLaunchKernelGGL(kern, dim3((unsigned)nwg), dim3(256), lds, s, ca);
+    VDM_LAUNCH_CHECK("conv_cls_kernel");
+    return VDM_OK;
+}
+
+template <typename T>
+static int launch_cls(const ClsArgs& ca, int nc, int mode_b, hipStream_t s) {
+    if (mode_b) {
+        switch (nc) {
+            case 1: return launch_cls_cfg<T, 1, 1>(ca, s);
+            case 2: return launch_cls_cfg<T, 2, 1>(ca, s);
+            default: return launch_cls_cfg<T, 4, 1>(ca, s);
+        }
+    }
+    switch (nc) {
+        case 1: return launch_cls_cfg<T, 1, 0>(ca, s);
+        case 2: return launch_cls_cfg<T, 2, 0>(ca, s);
+        default: return launch_cls_cfg<T, 4, 0>(ca, s);
+    }
+}
+
+// x: staged tensor (K channels), out: O channels.  cd/ch/cw: coarse dims.
+static int run_cls(const vdm_conv_desc* d, int kind, const void* x, const void* w, const float* bias, const void* res, void* out,
+                   int cd, int ch, int cw, hipStream_t s) {
+    const int dgrad = kind != CLS_UP_FWD;
+    const Plan p = plan_of(d, dgrad);
+    ClsArgs ca{};
+    ClsMasks masks;
+    build_cls(kind, ca.t, masks);
+    ConvArgs& a = ca.c;
+    a.x = x; a.w = w; a.bias = bias; a.res = res; a.out = out;
+    a.N = d->n; a.Dz = cd; a.Dy = ch; a.Dx = cw;
+    a.Iz = cd; a.Iy = ch; a.Ix = cw;
+    a.circular = d->pad_mode == VDM_PAD_CIRCULAR;
+    a.Cin = p.K; a.CinStride = cpad(p.K, d->dtype); a.Cout = p.O;
+    a.nchunks = p.nchunks; a.nkb = p.nkb;
+    const int mode_b = kind == CLS_UP_DGRAD;
+    ca.sDz = mode_b ? 2 * cd : cd; ca.sDy = mode_b ? 2 * ch : ch; ca.sDx = mode_b ? 2 * cw : cw;
+    ca.oDz = mode_b ? cd : 2 * cd; ca.oDy = mode_b ? ch : 2 * ch; ca.oDx = mode_b ? cw : 2 * cw;
+    if (d->dtype == VDM_F32) return launch_cls<float>(ca, p.nc, mode_b, s);
+    return launch_cls<bf16_t>(ca, p.nc, mode_b, s);
 }
 
 static void fill_dims(ConvArgs& a, const vdm_conv_desc* d) {
@@ -901,6 +1248,7 @@ using namespace vdm;
 extern "C" size_t vdm_conv_packed_bytes(const vdm_conv_desc* d, int pack_mode) {
     if (validate(d) != VDM_OK) return 0;
     const Plan p = plan_of(d, pack_mode == VDM_PACK_DGRAD);
+    if (uses_cls(d, pack_mode == VDM_PACK_DGRAD)) return (size_t)p.nchunks * p.nkb * 64 * p.nc * 64 * 16;      // 64 (class, entry) slots
     return (size_t)p.nchunks * p.nkb * p.taps * p.nc * 64 * 16;
 }
 
@@ -914,6 +1262,19 @@ extern "C" int vdm_conv_pack_weights(const vdm_conv_desc* d, int pack_mode, cons
     const size_t elems = vdm_conv_packed_bytes(d, pack_mode) / (d->dtype == VDM_F32 ? 4 : 2);
     const unsigned grid = (unsigned)((elems + 255) / 256 < 2048 ? (elems + 255) / 256 : 2048);
     hipStream_t s = (hipStream_t)stream;
+    if (uses_cls(d, dg)) {
+        ClsTable tab;
+        ClsMasks masks;
+        build_cls(cls_kind(d, dg), tab, masks);
+        if (d->dtype == VDM_F32)
+            hipLaunchKernelGGL(pack_weights_cls_kernel<float>, dim3(grid), dim3(256), 0, s, w_master, (float*)w_packed, d->cout, d->cin, p.nc,
+                               p.nchunks, p.nkb, dg, masks);
+        else
+            hipLaunchKernelGGL(pack_weights_cls_kernel<bf16_t>, dim3(grid), dim3(256), 0, s, w_master, (bf16_t*)w_packed, d->cout, d->cin,
+                               p.nc, p.nchunks, p.nkb, dg, masks);
+        VDM_LAUNCH_CHECK("pack_weights_cls_kernel");
+        return VDM_OK;
+    }
     if (d->dtype == VDM_F32)
         hipLaunchKernelGGL(pack_weights_kernel<float>, dim3(grid), dim3(256), 0, s, w_master, (float*)w_packed, p.taps, d->cout, d->cin,
                            p.nc, p.nchunks, p.nkb, dg);
@@ -929,6 +1290,10 @@ extern "C" int vdm_conv_fwd(const vdm_conv_desc* d, const void* x, const void* w
     int e = validate(d);
     if (e) return e;
     VDM_REQUIRE(x && w_packed && out, "conv_fwd: NULL pointer");
+    if (uses_cls(d, 0)) {
+        VDM_REQUIRE(!nbias && !d->out_f32, "conv_fwd: the up-sampling conv takes no per-sample bias / fp32 output");
+        return run_cls(d, CLS_UP_FWD, x, w_packed, bias, residual, out, d->od / 2, d->oh / 2, d->ow / 2, (hipStream_t)stream);
+    }
     const Plan p = plan_of(d, 0);
     ConvArgs a{};
     a.x = x; a.w = w_packed; a.bias = bias; a.nbias = nbias; a.nbias_stride = nbias_stride; a.res = residual; a.out = out;
@@ -943,7 +1308,11 @@ extern "C" int vdm_conv_dgrad(const vdm_conv_desc* d, const void* dout, const vo
     int e = validate(d);
     if (e) return e;
     VDM_REQUIRE(dout && w_packed_dgrad && dx, "conv_dgrad: NULL pointer");
-    VDM_REQUIRE(d->stride == 1, "conv_dgrad: stride-2 convs are differentiated via vdm_dilate2 + a stride-1 dgrad");
+    if (uses_cls(d, 1)) {
+        // up-sampling conv: dout is (od,oh,ow), dx is the coarse input (od/2,..);  stride-2 conv: dout is (od,oh,ow), dx is (2od,..)
+        if (d->upsample) return run_cls(d, CLS_UP_DGRAD, dout, w_packed_dgrad, nullptr, residual, dx, d->od / 2, d->oh / 2, d->ow / 2, (hipStream_t)stream);
+        return run_cls(d, CLS_S2_DGRAD, dout, w_packed_dgrad, nullptr, residual, dx, d->od, d->oh, d->ow, (hipStream_t)stream);
+    }
     const Plan p = plan_of(d, 1);
     ConvArgs a{};
     a.x = dout; a.w = w_packed_dgrad; a.res = residual; a.out = dx;

@@ -117,22 +117,25 @@ __global__ void __launch_bounds__(256) gn_stats_kernel(const T* __restrict__ x, 
     for (int i = threadIdx.x; i < 2 * G; i += 256) partial[((size_t)n * blocks_per_n + bn) * 2 * G + i] = sh[i];
 }
 
-// stats[n][g][0..1] = sum over blocks of partial, groups [g0, g0+gc) only.  One block per sample.
+// stats[n][g][0..1] = sum over blocks of partial, groups [g0, g0+gc) only.  One block per sample; thread (entry e, part k)
+// sums every 256/NE-th block partial of its entry, then a fixed-order LDS fold over the parts (deterministic).
 __global__ void __launch_bounds__(256) gn_stats_finalize_kernel(const float* __restrict__ partial, int G, int g0, int gc,
                                                                int blocks_per_n, float* __restrict__ stats) {
     const int n = blockIdx.x;
+    const int NE = 2 * gc;                                   // entries to produce (<= 128)
+    int parts = 256 / NE;
+    if (parts < 1) parts = 1;
+    const int e = threadIdx.x % NE, k = threadIdx.x / NE;
     __shared__ float sm[256];
-    for (int e = 2 * g0; e < 2 * (g0 + gc); ++e) {
-        float s = 0.f;
-        for (int b = threadIdx.x; b < blocks_per_n; b += 256) s += partial[((size_t)n * blocks_per_n + b) * 2 * G + e];
-        sm[threadIdx.x] = s;
-        __syncthreads();
-        for (int o = 128; o > 0; o >>= 1) {
-            if ((int)threadIdx.x < o) sm[threadIdx.x] += sm[threadIdx.x + o];
-            __syncthreads();
-        }
-        if (threadIdx.x == 0) stats[(size_t)n * 2 * G + e] = sm[0];
-        __syncthreads();
+    float s = 0.f;
+    if (k < parts)
+        for (int b = k; b < blocks_per_n; b += parts) s += partial[((size_t)n * blocks_per_n + b) * 2 * G + 2 * g0 + e];
+    sm[threadIdx.x] = s;
+    __syncthreads();
+    if (k == 0 && (int)threadIdx.x < NE) {
+        float tot = 0.f;
+        for (int j = 0; j < parts; ++j) tot += sm[j * NE + e];
+        stats[(size_t)n * 2 * G + 2 * g0 + e] = tot;
     }
 }
 

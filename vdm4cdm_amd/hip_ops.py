@@ -123,7 +123,7 @@ class Conv:
     def pack(self, w_master, dtype, need_dgrad):
         """w_master: fp32 [taps, cout, cin] (a view into the flat parameter vector)."""
         L = _lib.lib()
-        d = self.desc(1, 2, 2, 2, dtype, stride=1 if self.stride == 2 else None)
+        d = self.desc(1, 2, 2, 2, dtype)
         assert w_master.dtype == torch.float32 and w_master.is_contiguous()
         assert w_master.numel() == self.ksize ** 3 * self.cout * self.cin
         if self.wf is None or self.wf.device != w_master.device or self._packed_dtype != dtype:
@@ -165,27 +165,35 @@ class Conv:
         if ev is not None:
             nvox = shp[0] * shp[1] * shp[2] * shp[3]
             es = x.element_size()
-            _pe(ev, f"conv_fwd_kernel<{_tname(x.dtype)},k{self.ksize},s{self.stride},u{self.upsample},NC{_nc_for(self.cout)}>",
+            kname = "conv_cls_kernel" if (self.ksize == 3 and self.upsample) else "conv_fwd_kernel"
+            _pe(ev, f"{kname}<{_tname(x.dtype)},k{self.ksize},s{self.stride},u{self.upsample},NC{_nc_for(self.cout)}>",
                 2.0 * nvox * self.ksize ** 3 * self.cin * self.cout,
                 x.numel() * es + out.numel() * out.element_size() + (residual.numel() * es if residual is not None else 0))
         return out
 
     def dgrad(self, dout, residual=None, out=None):
-        """Gradient w.r.t. the conv input grid at OUTPUT resolution for stride 1 (up-sampling convs: pool
-        afterwards).  For the stride-2 conv, `dout` must already be zero-dilated to the fine grid."""
+        """Gradient w.r.t. the conv input (stride 2: twice the dout dims; up-sampling conv: half)."""
         L = _lib.lib()
         _contig(dout, residual)
         n, od, oh, ow, c = dout.shape
         assert c == cpad(self.cout, dout.dtype)
+        if self.stride == 2:
+            ishape = (n, 2 * od, 2 * oh, 2 * ow, self.cin)
+        elif self.upsample:
+            ishape = (n, od // 2, oh // 2, ow // 2, self.cin)
+        else:
+            ishape = (n, od, oh, ow, self.cin)
         if out is None:
-            out = torch.empty((n, od, oh, ow, self.cin), dtype=dout.dtype, device=dout.device)
-        d = self.desc(n, od, oh, ow, dout.dtype, stride=1)
+            out = torch.empty(ishape, dtype=dout.dtype, device=dout.device)
+        assert tuple(out.shape) == ishape and (residual is None or tuple(residual.shape) == ishape)
+        d = self.desc(n, od, oh, ow, dout.dtype)
         ev = _pb()
         check(L.vdm_conv_dgrad(d, _p(dout), _p(self.wd), _p(residual), _p(out), _s()), "vdm_conv_dgrad")
         if ev is not None:
-            nvox = n * od * oh * ow // (8 if self.stride == 2 else 1)         # algorithmic: only the non-dilated taps count
+            nvox = n * od * oh * ow
             es = dout.element_size()
-            _pe(ev, f"conv_fwd_kernel<{_tname(dout.dtype)},k{self.ksize},s1,u0,NC{_nc_for(self.cin)}>",
+            kname = "conv_cls_kernel" if (self.ksize == 3 and (self.stride == 2 or self.upsample)) else "conv_fwd_kernel"
+            _pe(ev, f"{kname}<{_tname(dout.dtype)},k{self.ksize},s{self.stride},u{self.upsample},dgrad,NC{_nc_for(self.cin)}>",
                 2.0 * nvox * self.ksize ** 3 * self.cin * self.cout,
                 dout.numel() * es + out.numel() * es + (residual.numel() * es if residual is not None else 0))
         return out

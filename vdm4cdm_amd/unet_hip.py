@@ -173,17 +173,14 @@ class HipUNet:
         for i in range(L - 1):
             du, dskips[i] = self.res[f"ups.{i}.block"].bwd(P, GP, dh, dtable)
             self.up[i].wgrad(coarse[i], du, GP(f"ups.{i}.up.weight"), GP(f"ups.{i}.up.bias"))
-            dfine = self.up[i].dgrad(du)
-            dh = ops.pool2_sum(dfine)
-            del dfine, du
+            dh = self.up[i].dgrad(du)              # gradient w.r.t. the coarse source (per-parity-class conv, no pooling pass)
+            del du
         for j in reversed(range(2)):
             dh, _ = self.res[f"mid.{j}"].bwd(P, GP, dh, dtable)
         for i in reversed(range(L)):
             if i != L - 1:
                 self.down[i].wgrad(skips[i], dh, GP(f"downs.{i}.down.weight"), GP(f"downs.{i}.down.bias"))
-                dfine = ops.dilate2(dh)
-                dh = self.down[i].dgrad(dfine, residual=dskips[i])
-                del dfine
+                dh = self.down[i].dgrad(dh, residual=dskips[i])      # per-parity-class conv: no zero-dilated intermediate
             dh, _ = self.res[f"downs.{i}.block"].bwd(P, GP, dh, dtable)
         self.conv_in.wgrad(xin, dh, GP("conv_in.weight"), GP("conv_in.bias"))
         # conv1 biases: column sums of the conditioning-table gradient (same additive broadcast)
