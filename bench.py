@@ -32,6 +32,7 @@ CONFIGS = {
     "c3": (128, 2, [32, 64, 128, 256], "bf16"),
     "c4": (192, 2, [32, 64, 128, 256], "bf16"),
     "c224": (224, 2, [16, 32, 64, 128], "bf16"),
+    "c256": (256, 2, [16, 32, 64, 128], "bf16"),          # circular padding (configs.yaml VDM_Mstar_Mcdm_c_c_256)
     "tiny": (32, 2, [16, 32, 64], "bf16"),
 }
 # algorithmic work per voxel per forward at chs [32,64,128,256]: 720 kFLOP, 1.53 kB (bf16) / 3.05 kB (fp32);
@@ -47,8 +48,8 @@ def build_model(D, chs, precision, device, seed=42):
     from vdm4cdm_amd.vdm_model import LightVDM
     torch.manual_seed(seed)                                     # [REF trainVDM3D128...py:54] seed_everything(42)
     net = CUNet(shape=(1, D, D, D), chs=chs, s_conditioning_channels=1, v_conditioning_dims=[6], t_conditioning=True,
-                norm_groups=8, mid_attn=False, dropout_prob=0.1, conv_padding_mode="zeros", n_attention_heads=4,
-                backend="hip", precision=precision)
+                norm_groups=8, mid_attn=False, dropout_prob=0.1, conv_padding_mode="circular" if D == 256 else "zeros",
+                n_attention_heads=4, backend="hip", precision=precision)
     g = torch.Generator().manual_seed(seed)
     net.reset_parameters(generator=g, zero_init_std=0.02)       # zero-init convs -> N(0, 0.02): non-trivial gradients
     return LightVDM(score_model=net, draw_figure=None, gamma_max=13.3, learning_rate=3.0e-4).to(device)

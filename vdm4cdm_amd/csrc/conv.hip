@@ -475,10 +475,15 @@ __device__ __forceinline__ void taps_list(f32x4 (&acc)[NV][NC], const char* lds,
                                           const int nent, const ClsEntry (&ent)[8], const int (&lanex)[3]) {
     constexpr int ROWB = G::HX * 64;
     auto lane_base = [&](int i) { return (ent[i].dx == 0 ? lanex[0] : (ent[i].dx == 1 ? lanex[1] : lanex[2])) + ent[i].lds_off; };
-    uint4 wf[2][NC];
+    constexpr int WPD = (NC <= 2) ? 3 : 1;                  // weight prefetch depth (entries); ring of WPD + 1 register sets
+    uint4 wf[WPD + 1][NC];
     uint4 af[2][NV];
 #pragma unroll
-    for (int c = 0; c < NC; ++c) wf[0][c] = wk[c * 64];
+    for (int p = 0; p < WPD; ++p)
+        if (p < nent) {
+#pragma unroll
+            for (int c = 0; c < NC; ++c) wf[p][c] = wk[(p * NC + c) * 64];
+        }
     {
         const int b0 = lane_base(0);
 #pragma unroll
@@ -487,9 +492,11 @@ __device__ __forceinline__ void taps_list(f32x4 (&acc)[NV][NC], const char* lds,
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
         if (i < nent) {
-            if (i + 1 < nent) {
+            if (i + WPD < nent) {
 #pragma unroll
-                for (int c = 0; c < NC; ++c) wf[(i + 1) & 1][c] = wk[((i + 1) * NC + c) * 64];
+                for (int c = 0; c < NC; ++c) wf[(i + WPD) % (WPD + 1)][c] = wk[((i + WPD) * NC + c) * 64];
+            }
+            if (i + 1 < nent) {
                 const int b1 = lane_base(i + 1 < 8 ? i + 1 : 7);
 #pragma unroll
                 for (int v = 0; v < NV; ++v) af[(i + 1) & 1][v] = *reinterpret_cast<const uint4*>(lds + b1 + v * ROWB);
@@ -498,7 +505,7 @@ __device__ __forceinline__ void taps_list(f32x4 (&acc)[NV][NC], const char* lds,
 #pragma unroll
             for (int v = 0; v < NV; ++v)
 #pragma unroll
-                for (int c = 0; c < NC; ++c) mma16<T>(acc[v][c], wf[i & 1][c], af[i & 1][v]);
+                for (int c = 0; c < NC; ++c) mma16<T>(acc[v][c], wf[i % (WPD + 1)][c], af[i & 1][v]);
             __builtin_amdgcn_sched_barrier(0);
         }
     }
@@ -529,10 +536,19 @@ __device__ __forceinline__ void cls_epilogue(const f32x4 (&acc)[NV][NC], const C
         for (int c = 0; c < NC; ++c)
 #pragma unroll
             for (int j = 0; j < 4; ++j) val[c * 4 + j] = acc[v][c][j] + badd[c * 4 + j];
+        if (res) {
+            if (vec_ok && NC * 4 >= EPL) {
 #pragma unroll
-        for (int j = 0; j < NC * 4; ++j) {
-            if (vec_ok || cbase + j < a.Cout) {
-                if (res) val[j] += ld_elem<T>(res + vo + j);
+                for (int i = 0; i < NC * 4 / EPL; ++i) {
+                    Piece<T> pr;
+                    pr.load(*reinterpret_cast<const uint4*>(res + vo + i * EPL));
+#pragma unroll
+                    for (int j = 0; j < EPL; ++j) val[i * EPL + j] += pr.f[j];
+                }
+            } else {
+#pragma unroll
+                for (int j = 0; j < NC * 4; ++j)
+                    if (vec_ok || cbase + j < a.Cout) val[j] += ld_elem<T>(res + vo + j);
             }
         }
         if (vec_ok && sizeof(T) == 2 && NC >= 2) {
@@ -556,7 +572,9 @@ __device__ __forceinline__ void cls_epilogue(const f32x4 (&acc)[NV][NC], const C
     (void)EPL;
 }
 
-template <typename T, int NC, int MODE_B>
+// MODE: 0 = F (coarse -> fine, one class per workgroup), 1 = B (fine -> coarse, loops over the classes, accumulates).
+// (A stage-once-for-all-classes variant of F was measured and was not faster: one workgroup per CU, cold restarts per class.)
+template <typename T, int NC, int MODE>
 __global__ void __launch_bounds__(256, 2) conv_cls_kernel(const ClsArgs ca) {
     using G = Geo<3, 1, 4, 8>;
     constexpr int NV = G::NV;
@@ -568,7 +586,7 @@ __global__ void __launch_bounds__(256, 2) conv_cls_kernel(const ClsArgs ca) {
 
     int b = xcd_remap(blockIdx.x, gridDim.x);
     int cls = 0;
-    if (!MODE_B) { cls = b & 7; b >>= 3; }
+    if (MODE == 0) { cls = b & 7; b >>= 3; }
     const int tx = b % a.ntx; b /= a.ntx;
     const int ty = b % a.nty; b /= a.nty;
     const int tz = b % a.ntz; b /= a.ntz;
@@ -577,24 +595,27 @@ __global__ void __launch_bounds__(256, 2) conv_cls_kernel(const ClsArgs ca) {
     const int oz0 = tz * G::TZ, oy0 = ty * G::TY, ox0 = tx * 16;
 
     f32x4 acc[NV][NC];
+    auto zero_acc = [&]() {
 #pragma unroll
-    for (int v = 0; v < NV; ++v)
+        for (int v = 0; v < NV; ++v)
 #pragma unroll
-        for (int c = 0; c < NC; ++c) acc[v][c] = f32x4{0.f, 0.f, 0.f, 0.f};
+            for (int c = 0; c < NC; ++c) acc[v][c] = f32x4{0.f, 0.f, 0.f, 0.f};
+    };
+    zero_acc();
     int lanex[3];
     operand_lane_offsets<G, NV>(lanex, wave, lane);
     const T* x = reinterpret_cast<const T*>(a.x);
     const uint4* wbase = reinterpret_cast<const uint4*>(a.w) + (size_t)chunk * a.nkb * 64 * NC * 64 + lane;
 
-    const int ncls = MODE_B ? 8 : 1;
+    const int ncls = (MODE == 1) ? 8 : 1;
     bool first = true;
     for (int ci = 0; ci < ncls; ++ci) {
-        const int cl = MODE_B ? ci : cls;
+        const int cl = (MODE == 1) ? ci : cls;
         const int pz = (cl >> 2) & 1, py = (cl >> 1) & 1, px = cl & 1;
         for (int kb = 0; kb < a.nkb; ++kb) {
             if (!first) __syncthreads();
             first = false;
-            if (MODE_B)
+            if (MODE == 1)
                 stage_halo_dma_sub<T, G>(lds, x, ca, n, oz0, oy0, ox0, kb, 2, pz, py, px, wave, lane);
             else
                 stage_halo_dma_sub<T, G>(lds, x, ca, n, oz0, oy0, ox0, kb, 1, 0, 0, 0, wave, lane);
@@ -603,7 +624,7 @@ __global__ void __launch_bounds__(256, 2) conv_cls_kernel(const ClsArgs ca) {
             taps_list<T, G, NC, NV>(acc, lds, wk, ca.t.n[cl], ca.t.e[cl], lanex);
         }
     }
-    if (MODE_B)
+    if (MODE == 1)
         cls_epilogue<T, G, NC, NV>(acc, ca, n, chunk, oz0, oy0, ox0, 1, 0, 0, 0, wave, lane);
     else
         cls_epilogue<T, G, NC, NV>(acc, ca, n, chunk, oz0, oy0, ox0, 2, (cls >> 2) & 1, (cls >> 1) & 1, cls & 1, wave, lane);
@@ -1175,21 +1196,21 @@ static void build_cls(int kind, ClsTable& tab, ClsMasks& masks) {
 static bool uses_cls(const vdm_conv_desc* d, int dgrad) { return d->ksize == 3 && (d->upsample || (dgrad && d->stride == 2)); }
 static int cls_kind(const vdm_conv_desc* d, int dgrad) { return d->upsample ? (dgrad ? CLS_UP_DGRAD : CLS_UP_FWD) : CLS_S2_DGRAD; }
 
-template <typename T, int NC, int MODE_B>
+template <typename T, int NC, int MODE>
 static int launch_cls_cfg(const ClsArgs& ca0, hipStream_t s) {
     using G = Geo<3, 1, 4, 8>;
     ClsArgs ca = ca0;
     ConvArgs& a = ca.c;
     a.ntz = cdiv(a.Dz, G::TZ); a.nty = cdiv(a.Dy, G::TY); a.ntx = cdiv(a.Dx, 16);
     const size_t lds = (size_t)((G::HVOX + 15) / 16) * 1024;
-    auto kern = conv_cls_kernel<T, NC, MODE_B>;
+    auto kern = conv_cls_kernel<T, NC, MODE>;
     static bool attr_done = false;
     if (!attr_done) {
         int e = set_lds(kern, lds);
         if (e) return e;
         attr_done = true;
     }
-    const long long nwg = (long long)a.N * a.ntz * a.nty * a.ntx * a.nchunks * (MODE_B ? 1 : 8);
+    const long long nwg = (long long)a.N * a.ntz * a.nty * a.ntx * a.nchunks * (MODE == 0 ? 8 : 1);
     if (nwg > 0x7fffffffLL) { set_error("conv(class): grid too large"); return VDM_ERR_ARG; }
     hipLaunchKernelGGL(kern, dim3((unsigned)nwg), dim3(256), lds, s, ca);
     VDM_LAUNCH_CHECK("conv_cls_kernel");
