@@ -261,25 +261,39 @@ __device__ __forceinline__ void taps_pipelined(f32x4 (&acc)[NV][NC], const char*
     }
 }
 
-// fp32: MFMA-bound (4 x 32-cycle MFMAs per fragment pair); rolled tap loop keeps registers low.
+// fp32 (exact v_mfma_f32_16x16x4_f32, 1/16 of the bf16 rate): MFMA-bound.  Rolled tap loop (low register pressure), the
+// next tap's weights are loaded before this tap's MFMAs, and the 4 k-steps of a fragment pair are issued STEP-MAJOR over the
+// NV x NC independent accumulators (a dependent fp32 MFMA has 40 cycles of latency vs 32 of issue).
 template <typename T, typename G, int NC, int NV>
 __device__ __forceinline__ void taps_rolled(f32x4 (&acc)[NV][NC], const char* lds, const uint4* wk, const int (&lanex)[G::KS]) {
     constexpr int TAPS = G::TAPS, KS = G::KS;
     constexpr int ROWB = G::STRIDE * G::HX * 64;
+    uint4 wn[NC];
+#pragma unroll
+    for (int c = 0; c < NC; ++c) wn[c] = wk[c * 64];
 #pragma unroll 1
     for (int tap = 0; tap < TAPS; ++tap) {
         const int dz = tap / (KS * KS), dy = (tap / KS) % KS, dx = tap % KS;
         const int toff = (dz * G::HY + dy) * G::HX * 64;
         const int lx0 = (dx == 0) ? lanex[0] : ((dx == 1) ? lanex[KS > 1 ? 1 : 0] : lanex[KS > 2 ? 2 : 0]);
-        uint4 wf[NC];
+        uint4 wf[NC], af[NV];
 #pragma unroll
-        for (int c = 0; c < NC; ++c) wf[c] = wk[(tap * NC + c) * 64];
+        for (int c = 0; c < NC; ++c) wf[c] = wn[c];
+        const int tn = tap + 1 < TAPS ? tap + 1 : tap;
 #pragma unroll
-        for (int v = 0; v < NV; ++v) {
-            const uint4 af = *reinterpret_cast<const uint4*>(lds + lx0 + v * ROWB + toff);
+        for (int c = 0; c < NC; ++c) wn[c] = wk[(tn * NC + c) * 64];
 #pragma unroll
-            for (int c = 0; c < NC; ++c) mma16<T>(acc[v][c], wf[c], af);
-        }
+        for (int v = 0; v < NV; ++v) af[v] = *reinterpret_cast<const uint4*>(lds + lx0 + v * ROWB + toff);
+#pragma unroll
+        for (int st = 0; st < 4; ++st)
+#pragma unroll
+            for (int v = 0; v < NV; ++v)
+#pragma unroll
+                for (int c = 0; c < NC; ++c) {
+                    const uint32_t aw = st == 0 ? wf[c].x : (st == 1 ? wf[c].y : (st == 2 ? wf[c].z : wf[c].w));
+                    const uint32_t bw = st == 0 ? af[v].x : (st == 1 ? af[v].y : (st == 2 ? af[v].z : af[v].w));
+                    acc[v][c] = __builtin_amdgcn_mfma_f32_16x16x4f32(__builtin_bit_cast(float, aw), __builtin_bit_cast(float, bw), acc[v][c], 0, 0, 0);
+                }
     }
 }
 
@@ -988,7 +1002,9 @@ __global__ void pack_weights_kernel(const float* __restrict__ w, T* __restrict__
 // ---------------------------------------------------------------------------------------------
 // host side
 // ---------------------------------------------------------------------------------------------
-static int nc_for(int cout) { return cout <= 16 ? 1 : (cout <= 32 ? 2 : 4); }
+// output-channel tiles (of 16) per workgroup.  fp32 is MFMA-bound (weight reuse is irrelevant) and its deep-level grids are
+// small: cap at 2 so that twice as many workgroups exist.
+static int nc_for(int cout, int dtype) { return cout <= 16 ? 1 : ((cout <= 32 || dtype == VDM_F32) ? 2 : 4); }
 static int epl_of(int dtype) { return dtype == VDM_F32 ? 4 : 8; }
 static int kb_of(int dtype) { return dtype == VDM_F32 ? 16 : 32; }
 static int cpad(int c, int dtype) { const int e = epl_of(dtype); return (c + e - 1) / e * e; }
@@ -1015,7 +1031,7 @@ static Plan plan_of(const vdm_conv_desc* d, int dgrad) {
     p.taps = d->ksize * d->ksize * d->ksize;
     p.O = dgrad ? d->cin : d->cout;
     p.K = dgrad ? d->cout : d->cin;
-    p.nc = nc_for(p.O);
+    p.nc = nc_for(p.O, d->dtype);
     p.nchunks = cdiv(p.O, p.nc * 16);
     p.nkb = cdiv(p.K, kb_of(d->dtype));
     return p;

@@ -55,8 +55,8 @@ def _pe(ev, key, flops=0.0, nbytes=0.0):
         PROFILER.end(ev, key, flops, nbytes)
 
 
-def _nc_for(cout):
-    return 1 if cout <= 16 else (2 if cout <= 32 else 4)
+def _nc_for(cout, dtype=None):
+    return 1 if cout <= 16 else (2 if (cout <= 32 or dtype == torch.float32) else 4)
 
 
 def _tname(dtype):
@@ -166,7 +166,7 @@ class Conv:
             nvox = shp[0] * shp[1] * shp[2] * shp[3]
             es = x.element_size()
             kname = "conv_cls_kernel" if (self.ksize == 3 and self.upsample) else "conv_fwd_kernel"
-            _pe(ev, f"{kname}<{_tname(x.dtype)},k{self.ksize},s{self.stride},u{self.upsample},NC{_nc_for(self.cout)}>",
+            _pe(ev, f"{kname}<{_tname(x.dtype)},k{self.ksize},s{self.stride},u{self.upsample},NC{_nc_for(self.cout, x.dtype)}>",
                 2.0 * nvox * self.ksize ** 3 * self.cin * self.cout,
                 x.numel() * es + out.numel() * out.element_size() + (residual.numel() * es if residual is not None else 0))
         return out
@@ -193,7 +193,7 @@ class Conv:
             nvox = n * od * oh * ow
             es = dout.element_size()
             kname = "conv_cls_kernel" if (self.ksize == 3 and (self.stride == 2 or self.upsample)) else "conv_fwd_kernel"
-            _pe(ev, f"{kname}<{_tname(dout.dtype)},k{self.ksize},s{self.stride},u{self.upsample},dgrad,NC{_nc_for(self.cin)}>",
+            _pe(ev, f"{kname}<{_tname(dout.dtype)},k{self.ksize},s{self.stride},u{self.upsample},dgrad,NC{_nc_for(self.cin, dout.dtype)}>",
                 2.0 * nvox * self.ksize ** 3 * self.cin * self.cout,
                 dout.numel() * es + out.numel() * es + (residual.numel() * es if residual is not None else 0))
         return out
