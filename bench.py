@@ -173,14 +173,20 @@ def main():
         roof = {}
         if prof is not None:
             agg = prof.summary()
-            conv = {k: v for k, v in agg.items() if k.startswith("conv_fwd_kernel") and ",k3," in k}
+            conv = {k: v for k, v in agg.items() if k.startswith("conv_fwd_kernel") and ",k3,s1," in k}
             dom_key = max(conv, key=lambda k: conv[k]["ms"]) if conv else None
             total_ms = sum(v["ms"] for v in agg.values())
             if dom_key:
                 d = conv[dom_key]
                 ach = d["flops"] / (d["ms"] * 1e-3)
+                traffic = None                        # HBM bytes per launch from separate rocprofv3 --pmc passes (tools/pmc_traffic.py)
+                tpath = os.path.join(ROOT, "profiles", "r01_pmc_bench_traffic.json")
+                if args.config == "c3" and os.path.exists(tpath):
+                    t = json.load(open(tpath))["kernels"].get(dom_key)
+                    traffic = t["hbm_bytes_per_launch"] if t else None
                 roof = {"bound": "mfma", "kernel": dom_key, "achieved": ach / 1e12, "peak": MFMA_PEAK[precision] / 1e12,
-                        "unit": "TFLOP/s", "frac": ach / MFMA_PEAK[precision], "traffic": None,
+                        "unit": "TFLOP/s", "frac": ach / MFMA_PEAK[precision], "traffic": traffic,
+                        "algorithmic_flop_per_launch": d["flops"] / d["launches"],
                         "launches": d["launches"], "avg_launch_ms": d["ms"] / d["launches"],
                         "share_of_kernel_time": d["ms"] / total_ms}
             out["kernels"] = {k: {"launches": v["launches"], "ms_per_step": v["ms"] / args.steps,

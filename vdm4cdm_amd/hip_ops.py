@@ -165,8 +165,11 @@ class Conv:
         if ev is not None:
             nvox = shp[0] * shp[1] * shp[2] * shp[3]
             es = x.element_size()
-            kname = "conv_cls_kernel" if (self.ksize == 3 and self.upsample) else "conv_fwd_kernel"
-            _pe(ev, f"{kname}<{_tname(x.dtype)},k{self.ksize},s{self.stride},u{self.upsample},NC{_nc_for(self.cout, x.dtype)}>",
+            if self.ksize == 3 and self.upsample:
+                key = f"conv_cls_kernel<{_tname(x.dtype)},NC{_nc_for(self.cout, x.dtype)},F>"
+            else:
+                key = f"conv_fwd_kernel<{_tname(x.dtype)},k{self.ksize},s{self.stride},NC{_nc_for(self.cout, x.dtype)}>"
+            _pe(ev, key,
                 2.0 * nvox * self.ksize ** 3 * self.cin * self.cout,
                 x.numel() * es + out.numel() * out.element_size() + (residual.numel() * es if residual is not None else 0))
         return out
@@ -192,8 +195,11 @@ class Conv:
         if ev is not None:
             nvox = n * od * oh * ow
             es = dout.element_size()
-            kname = "conv_cls_kernel" if (self.ksize == 3 and (self.stride == 2 or self.upsample)) else "conv_fwd_kernel"
-            _pe(ev, f"{kname}<{_tname(dout.dtype)},k{self.ksize},s{self.stride},u{self.upsample},dgrad,NC{_nc_for(self.cin, dout.dtype)}>",
+            if self.ksize == 3 and (self.stride == 2 or self.upsample):
+                key = f"conv_cls_kernel<{_tname(dout.dtype)},NC{_nc_for(self.cin, dout.dtype)},{'B' if self.upsample else 'F'}>"
+            else:
+                key = f"conv_fwd_kernel<{_tname(dout.dtype)},k{self.ksize},s1,NC{_nc_for(self.cin, dout.dtype)}>"
+            _pe(ev, key,
                 2.0 * nvox * self.ksize ** 3 * self.cin * self.cout,
                 dout.numel() * es + out.numel() * es + (residual.numel() * es if residual is not None else 0))
         return out
