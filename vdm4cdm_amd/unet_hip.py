@@ -13,6 +13,31 @@ from . import hip_ops as ops
 from .hip_ops import Conv
 
 
+class SideStream:
+    """Weight-gradient kernels run on a side HIP stream: their results are needed only by the optimiser, so they overlap
+    with the (HBM-bound) GroupNorm kernels and the dgrad chain on the main stream.  `run(fn, *tensors)` makes the side
+    stream wait for everything issued so far on the main stream, runs fn on it and marks the tensors as in use there."""
+
+    def __init__(self, device, enabled=True):
+        self.enabled = enabled and torch.cuda.is_available()
+        self.side = torch.cuda.Stream(device=device) if self.enabled else None
+
+    def run(self, fn, *tensors):
+        if not self.enabled:
+            return fn()
+        main = torch.cuda.current_stream()
+        self.side.wait_stream(main)
+        with torch.cuda.stream(self.side):
+            fn()
+        for t in tensors:
+            if t is not None:
+                t.record_stream(self.side)
+
+    def join(self):
+        if self.enabled:
+            torch.cuda.current_stream().wait_stream(self.side)
+
+
 class _Res:
     """ResNetBlock (D4) on HIP kernels; input may be two tensors (skip concat, never materialised)."""
 
@@ -54,30 +79,35 @@ class _Res:
             self.saved = (x1, x2, st1, a1, h, st2, a2, p, seed)
         return out
 
-    def bwd(self, P, GP, dout, dtable):
-        """dout: gradient of the block output.  Returns (dx1, dx2).  Fills parameter grads via GP(name)."""
+    def bwd(self, P, GP, dout, dtable, ss):
+        """dout: gradient of the block output.  Returns (dx1, dx2).  Fills parameter grads via GP(name).
+        ss: SideStream for the weight-gradient kernels."""
         i, G, n = self.i, self.net.norm_groups, self.i.name
         x1, x2, st1, a1, h, st2, a2, p, seed = self.saved
         self.saved = None
-        # conv2 (+ residual path shares dout)
-        self.conv2.wgrad(a2, dout, GP(n + ".conv2.weight"), GP(n + ".conv2.bias"))      # bias grad fused (column sums of dout)
+
+        def side_conv2():                      # conv2 (+ the 1x1 skip convs share dout)
+            self.conv2.wgrad(a2, dout, GP(n + ".conv2.weight"), GP(n + ".conv2.bias"))      # bias grad fused (column sums of dout)
+            if self.skip1 is not None:
+                self.skip1.wgrad(x1, dout, GP(n + ".skip.weight"))
+                GP(n + ".skip.bias").copy_(GP(n + ".conv2.bias"))          # same column sums of dout
+                if self.skip2 is not None:
+                    self.skip2.wgrad(x2, dout, GP(n + ".skip2.weight"))
+        ss.run(side_conv2, a2, dout, x1, x2)
         da2 = self.conv2.dgrad(dout)
         dh, _ = ops.gn_silu_bwd(h, None, G, st2, P(n + ".norm2.weight"), P(n + ".norm2.bias"), da2,
                                 GP(n + ".norm2.weight"), GP(n + ".norm2.bias"),
                                 colsum=dtable[:, i.table_off:i.table_off + i.cout], dropout_p=p, seed=seed, dx1=da2)
         del a2
         # conv1
-        self.conv1.wgrad(a1, dh, GP(n + ".conv1.weight"))
+        ss.run(lambda: self.conv1.wgrad(a1, dh, GP(n + ".conv1.weight")), a1, dh)
         da1 = self.conv1.dgrad(dh)
         del a1, dh
         # skip path
         add1 = add2 = None
         if self.skip1 is not None:
-            self.skip1.wgrad(x1, dout, GP(n + ".skip.weight"))
             add1 = self.skip1.dgrad(dout)
-            GP(n + ".skip.bias").copy_(GP(n + ".conv2.bias"))          # same column sums of dout
             if self.skip2 is not None:
-                self.skip2.wgrad(x2, dout, GP(n + ".skip2.weight"))
                 add2 = self.skip2.dgrad(dout)
         else:
             add1 = dout
@@ -99,6 +129,7 @@ class HipUNet:
         self.res = {b.name: _Res(net, b) for b in net.blocks}
         self._packed_key = None
         self.saved = None
+        self._ss = None
 
     def _all_convs(self):
         L = len(self.net.chs)
@@ -163,26 +194,33 @@ class HipUNet:
         P = lambda name: net.view(name, flat)
         GP = lambda name: net.view(name, gflat)
 
+        import os
+        if self._ss is None or (self._ss.enabled and self._ss.side.device != flat.device):
+            self._ss = SideStream(flat.device, enabled=os.environ.get("VDM4CDM_WGRAD_STREAM", "1") != "0")
+        ss = self._ss
+        ss.run(lambda: None, gflat)                   # (orders the side stream after the zero-fill of gflat)
         dpad = ops.pack_input(d_eps.contiguous(), None, dtype)
-        self.conv_out.wgrad(a, dpad, GP("conv_out.weight"))
+        ss.run(lambda: self.conv_out.wgrad(a, dpad, GP("conv_out.weight")), a, dpad)
         GP("conv_out.bias").copy_(d_eps.sum().reshape(1))
         da = self.conv_out.dgrad(dpad)
         dh, _ = ops.gn_silu_bwd(h_last, None, net.norm_groups, st, P("norm_out.weight"), P("norm_out.bias"), da,
                                 GP("norm_out.weight"), GP("norm_out.bias"), dx1=da)
         dskips = [None] * (L - 1)
         for i in range(L - 1):
-            du, dskips[i] = self.res[f"ups.{i}.block"].bwd(P, GP, dh, dtable)
-            self.up[i].wgrad(coarse[i], du, GP(f"ups.{i}.up.weight"), GP(f"ups.{i}.up.bias"))
+            du, dskips[i] = self.res[f"ups.{i}.block"].bwd(P, GP, dh, dtable, ss)
+            ss.run(lambda i=i, du=du: self.up[i].wgrad(coarse[i], du, GP(f"ups.{i}.up.weight"), GP(f"ups.{i}.up.bias")), coarse[i], du)
             dh = self.up[i].dgrad(du)              # gradient w.r.t. the coarse source (per-parity-class conv, no pooling pass)
             del du
         for j in reversed(range(2)):
-            dh, _ = self.res[f"mid.{j}"].bwd(P, GP, dh, dtable)
+            dh, _ = self.res[f"mid.{j}"].bwd(P, GP, dh, dtable, ss)
         for i in reversed(range(L)):
             if i != L - 1:
-                self.down[i].wgrad(skips[i], dh, GP(f"downs.{i}.down.weight"), GP(f"downs.{i}.down.bias"))
+                ss.run(lambda i=i, dh=dh: self.down[i].wgrad(skips[i], dh, GP(f"downs.{i}.down.weight"), GP(f"downs.{i}.down.bias")),
+                       skips[i], dh)
                 dh = self.down[i].dgrad(dh, residual=dskips[i])      # per-parity-class conv: no zero-dilated intermediate
-            dh, _ = self.res[f"downs.{i}.block"].bwd(P, GP, dh, dtable)
-        self.conv_in.wgrad(xin, dh, GP("conv_in.weight"), GP("conv_in.bias"))
+            dh, _ = self.res[f"downs.{i}.block"].bwd(P, GP, dh, dtable, ss)
+        ss.run(lambda: self.conv_in.wgrad(xin, dh, GP("conv_in.weight"), GP("conv_in.bias")), xin, dh)
+        ss.join()
         # conv1 biases: column sums of the conditioning-table gradient (same additive broadcast)
         net.conv1_bias_all(gflat).copy_(dtable.sum(0))
         return gflat, dtable
