@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define VDM_ABI_VERSION 1
+#define VDM_ABI_VERSION 2
 
 typedef enum { VDM_OK = 0, VDM_ERR_ARG = -1, VDM_ERR_HIP = -2, VDM_ERR_UNSUPPORTED = -3 } vdm_status;
 typedef enum { VDM_F32 = 0, VDM_BF16 = 1 } vdm_dtype;
@@ -65,8 +65,12 @@ int vdm_conv_pack_weights(const vdm_conv_desc* d, int pack_mode, const float* w_
 /* out = conv(x, w) + bias[c] + nbias[n*nbias_stride + c] + residual   (bias, nbias, residual may be NULL).
  * nbias is the per-sample conditioning bias table (sum_k Linear_k(cond_k)); nbias_stride is the
  * element distance between samples (the table of all blocks is one [n][sum cout] matrix). */
+/* gn_partials (may be NULL): the epilogue also reduces the GroupNorm statistics of the output it stores, per spatial tile:
+ * gn_partials[n][tile][cout][2] = (sum, sum of squares) fp32, tile < vdm_conv_gn_tiles(d); feed them to vdm_gn_stats instead of
+ * a separate pass over the tensor.  vdm_conv_gn_tiles() == 0: this conv cannot (the up-sampling conv). */
+int vdm_conv_gn_tiles(const vdm_conv_desc* d);
 int vdm_conv_fwd(const vdm_conv_desc* d, const void* x, const void* w_packed_fwd, const float* bias,
-                 const float* nbias, int64_t nbias_stride, const void* residual, void* out, void* stream);
+                 const float* nbias, int64_t nbias_stride, const void* residual, void* out, float* gn_partials, void* stream);
 /* dx = gradient w.r.t. the conv INPUT: the descriptor is the FORWARD conv's; dout has cout channels and the output
  * dims (od,oh,ow); dx gets cin channels and the input dims (stride 1: same; stride 2: 2x; up-sampling conv: the
  * coarse source grid od/2...).  Stride-2 and up-sampling convs run as per-parity-class convs (no dilated /
@@ -76,6 +80,14 @@ int vdm_conv_dgrad(const vdm_conv_desc* d, const void* dout, const void* w_packe
 /* dw[taps][cout][cin] (fp32) = sum over voxels; workspace holds per-workgroup partial slabs.
  * dbias (optional, ksize 3 only): dbias[cout] = sum over samples and voxels of dout (the conv bias gradient), computed
  * from the dOut tiles the kernel stages anyway.  accumulate != 0 adds to dw / dbias instead of overwriting. */
+/* Which kernel family vdm_conv_fwd (dgrad = 0) / vdm_conv_dgrad (dgrad = 1) launches for this descriptor (profiling keys,
+ * tests): generic implicit-GEMM kernel, per-parity-class kernel (up-sampling conv and its gradients, stride-2 dgrad), or the
+ * resident-weight persistent kernel (bf16 32->32, 3x3x3, stride 1, whole 4x8x16 tiles, >= 4 tiles per CU).  < 0: bad descriptor. */
+#define VDM_CONV_VARIANT_GENERIC 0
+#define VDM_CONV_VARIANT_CLASS 1
+#define VDM_CONV_VARIANT_RESIDENT 2
+int vdm_conv_kernel_variant(const vdm_conv_desc* d, int dgrad);
+
 size_t vdm_conv_wgrad_workspace_bytes(const vdm_conv_desc* d);
 int vdm_conv_wgrad(const vdm_conv_desc* d, const void* x, const void* dout, float* dw, float* dbias, int accumulate,
                    void* workspace, size_t workspace_bytes, void* stream);
@@ -87,8 +99,11 @@ int vdm_conv_wgrad(const vdm_conv_desc* d, const void* x, const void* dout, floa
  * workspace: VDM_GN_STATS_WS_BYTES of scratch for the per-workgroup partials (two-stage, fixed-order
  * reduction: the forward pass is bit-reproducible). */
 #define VDM_GN_STATS_WS_BYTES (2048 * 2 * 64 * 4)
+/* part1 / part2 (may be NULL): per-tile channel partials of that source written by vdm_conv_fwd (tilesK tiles per sample);
+ * the source's groups are then summed from them and xK is not read (xK may be NULL). */
 int vdm_gn_stats(const void* x1, int c1, const void* x2, int c2, int n, int64_t voxels, int groups,
-                 int dtype, float* stats, float* workspace, void* stream);
+                 int dtype, float* stats, float* workspace, const float* part1, int tiles1, const float* part2, int tiles2,
+                 void* stream);
 /* y[n][v][c1+c2] = dropout(silu(gn(concat(x1,x2)))) ; keep-mask from Philox(seed, element index). */
 int vdm_gn_silu_fwd(const void* x1, int c1, const void* x2, int c2, int n, int64_t voxels, int groups,
                     int dtype, const float* stats, const float* gamma, const float* beta, float eps,

@@ -220,7 +220,7 @@ def test_cabi_exports_every_declared_symbol(hip_lib):
     for name in sorted(declared):
         assert hasattr(hip_lib, name), f"libvdm4cdm_hip.so does not export {name}"
     assert declared == set(_lib.SIGNATURES), f"ctypes table out of sync: {declared ^ set(_lib.SIGNATURES)}"
-    assert hip_lib.vdm_abi_version() == 1
+    assert hip_lib.vdm_abi_version() == 2
 
 
 def test_cabi_argument_errors_do_not_need_a_gpu(hip_lib):
@@ -230,7 +230,8 @@ def test_cabi_argument_errors_do_not_need_a_gpu(hip_lib):
     assert b"ksize" in hip_lib.vdm_last_error()
     d.ksize = 3
     assert hip_lib.vdm_conv_packed_bytes(d, 0) == 27 * 2 * 64 * 16 * 2     # 2 K-blocks (fp32: 16 ch) x 27 taps x NC=2 x 1 KiB
-    assert hip_lib.vdm_conv_fwd(d, None, None, None, None, 0, None, None, None) == -1   # VDM_ERR_ARG, no launch
+    assert hip_lib.vdm_conv_fwd(d, None, None, None, None, 0, None, None, None, None) == -1   # VDM_ERR_ARG, no launch
+    assert hip_lib.vdm_conv_gn_tiles(d) == 1 and hip_lib.vdm_conv_kernel_variant(d, 0) == 0     # host-side planning only
 
 
 def test_synthetic_datamodule_contract():

@@ -178,6 +178,46 @@ def test_conv_resident(case):
         assert err_a <= conv_tol(dtype, xr.grad + acc_in), f"{name}: dgrad+residual err {err_a}"
 
 
+GN_FUSED_CASES = [c for c in CONV_CASES if c[0] in ("k3_32_32", "k3_32_32_ragged", "k3_64_32", "k3_128_256", "k3_cin2pad", "k3_circ_small",
+                                                      "k3_s2", "k3_s2_ragged", "k1_64_32", "k3_16_16", "k3_48_96")] + RES_CASES[:2]
+
+
+@pytest.mark.parametrize("dtype", DTYPES, ids=["f32", "bf16"])
+@pytest.mark.parametrize("case", GN_FUSED_CASES, ids=[c[0] for c in GN_FUSED_CASES])
+def test_conv_fused_gn_stats(case, dtype):
+    """GroupNorm statistics reduced in the conv epilogue (from the fp32 results) vs a separate gn_stats pass over the stored
+    output, alone and as either half of a two-source GroupNorm."""
+    ops, conv, x, w, xd = _conv_setup(case, dtype, seed=40)
+    name, N, (D, H, W), cin, cout, ks, stride, ups, circ = case
+    if cout % 8:
+        pytest.skip("GroupNorm needs channels divisible by the group count")
+    G = 8
+    bias = rnd((cout,), 41)
+    res = rnd((N, D, H, W, cout), 42, dtype)
+    out = conv.fwd(xd, bias.to(DEV), None, to_dev(res, dtype), gn=True)
+    assert out.gn_partials is not None and out.gn_partials.shape[0] == N and out.gn_partials.shape[2:] == (cout, 2)
+    fused = ops.gn_stats(out, None, G)
+    plain_t = out.clone()                                  # (no gn_partials attribute: full pass)
+    plain = ops.gn_stats(plain_t, None, G)
+    ref = out.float().cpu().reshape(N, -1, G, cout // G)
+    ref = torch.stack([ref.sum(dim=(1, 3)), (ref * ref).sum(dim=(1, 3))], dim=-1)
+    tol = 2e-5 * ref.abs().max().item() + 1e-4
+    assert (plain.cpu() - ref).abs().max().item() <= tol
+    # fused: moments of the fp32 results before the storage rounding (zero-mean errors of 2^-9 relative per element)
+    if dtype == torch.float32:
+        ftol = torch.full_like(ref, tol)
+    else:                                                  # worst case: every element off by half a bf16 ulp in the same direction
+        xa = out.float().cpu().reshape(N, -1, G, cout // G)
+        ftol = torch.stack([2.0 ** -8 * xa.abs().sum(dim=(1, 3)), 2.0 ** -7 * (xa * xa).sum(dim=(1, 3))], dim=-1) + tol
+    assert ((fused.cpu() - ref).abs() <= ftol).all(), f"{name}: fused stats differ from the stored tensor's"
+    assert torch.equal(fused, ops.gn_stats(out, None, G))                      # deterministic
+    other = to_dev(rnd((N, D, H, W, cout), 43, dtype), dtype)
+    for a, b in ((out, other), (other, out)):
+        two = ops.gn_stats(a, b, G)
+        two_plain = ops.gn_stats(a.clone(), b.clone(), G)
+        assert (two - two_plain).abs().max().item() <= ftol.max().item(), f"{name}: two-source stats"
+
+
 GRAD_CASES = [c for c in CONV_CASES if c[0] in ("k3_32_32", "k3_32_32_ragged", "k3_64_32", "k3_32_64", "k3_128_256", "k3_cin2pad",
                                                   "k3_cout1", "k3_circ", "k3_s2", "k3_s2_circ", "k3_ups", "k3_ups_circ", "k3_ups_ragged", "k3_ups_128_64",
                                                   "k3_s2_ragged", "k3_s2_128", "k1_64_32",

@@ -26,6 +26,7 @@ class ConvDesc(C.Structure):
 
 _p, _i, _i64, _u64, _f, _sz = C.c_void_p, C.c_int, C.c_int64, C.c_uint64, C.c_float, C.c_size_t
 _D = C.POINTER(ConvDesc)
+ABI_VERSION = 2                      # VDM_ABI_VERSION of include/vdm4cdm_hip.h this binding was written for
 
 # name -> (restype, argtypes); mirrors include/vdm4cdm_hip.h one to one
 SIGNATURES = {
@@ -34,11 +35,13 @@ SIGNATURES = {
     "vdm_device_info": (_i, [_i, C.POINTER(_i), C.POINTER(_i), C.c_char_p]),
     "vdm_conv_packed_bytes": (_sz, [_D, _i]),
     "vdm_conv_pack_weights": (_i, [_D, _i, _p, _p, _p]),
-    "vdm_conv_fwd": (_i, [_D, _p, _p, _p, _p, _i64, _p, _p, _p]),
+    "vdm_conv_gn_tiles": (_i, [_D]),
+    "vdm_conv_fwd": (_i, [_D, _p, _p, _p, _p, _i64, _p, _p, _p, _p]),
     "vdm_conv_dgrad": (_i, [_D, _p, _p, _p, _p, _p]),
+    "vdm_conv_kernel_variant": (_i, [_D, _i]),
     "vdm_conv_wgrad_workspace_bytes": (_sz, [_D]),
     "vdm_conv_wgrad": (_i, [_D, _p, _p, _p, _p, _i, _p, _sz, _p]),
-    "vdm_gn_stats": (_i, [_p, _i, _p, _i, _i, _i64, _i, _i, _p, _p, _p]),
+    "vdm_gn_stats": (_i, [_p, _i, _p, _i, _i, _i64, _i, _i, _p, _p, _p, _i, _p, _i, _p]),
     "vdm_gn_silu_fwd": (_i, [_p, _i, _p, _i, _i, _i64, _i, _i, _p, _p, _p, _f, _f, _u64, _p, _p]),
     "vdm_gn_silu_bwd": (_i, [_p, _i, _p, _i, _i, _i64, _i, _i, _p, _p, _p, _f, _f, _u64, _p, _p, _p, _p, _p, _p, _p, _p, _i64, _p, _p]),
     "vdm_colsum": (_i, [_p, _i, _i64, _i, _i, _p, _i64, _p]),
@@ -85,8 +88,8 @@ def lib():
         fn.restype = res
         fn.argtypes = args
     ver = handle.vdm_abi_version()
-    if ver != 1:
-        raise VdmError(f"libvdm4cdm_hip.so ABI version {ver} != 1")
+    if ver != ABI_VERSION:
+        raise VdmError(f"libvdm4cdm_hip.so ABI version {ver} != {ABI_VERSION}")
     _lib = handle
     return _lib
 

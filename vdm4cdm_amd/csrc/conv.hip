@@ -26,6 +26,7 @@
 namespace vdm {
 
 static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
+static constexpr int GN_SCRATCH_BYTES = 4 * 64 * 2 * 4;      // 4 waves x (NC <= 4) * 16 channels x (sum, sumsq) floats
 
 // ---------------------------------------------------------------------------------------------
 // geometry
@@ -61,6 +62,7 @@ struct ConvArgs {
     int Cout;            // output channels (exact stride of out / res)
     int circular;
     int ntz, nty, ntx, nchunks, nkb;
+    float* gnp;          // optional GroupNorm partials of the output: [N][ntz*nty*ntx][Cout][2] = (sum, sum of squares) per tile
 };
 
 // halo voxel index -> LDS byte offset of piece pc
@@ -299,11 +301,57 @@ __device__ __forceinline__ void taps_rolled(f32x4 (&acc)[NV][NC], const char* ld
     }
 }
 
+// GroupNorm statistics fused into the producing conv: per-channel (sum, sum of squares) of the output values of one tile, taken
+// from the fp32 results before they are rounded for storage (the rounding errors are zero-mean: the moments of the stored tensor
+// differ by ~2^-9 / sqrt(#voxels) relative).  Lane sums over its rows -> xor-butterfly over the 16 voxel lanes -> the four waves fold through a small LDS
+// scratch in a fixed order (deterministic) -> one partial per (sample, tile, channel).  vdm_gn_stats_from_partials sums the
+// tiles and the channels of a group.  `sm` = NC*16*2*4 floats of LDS that no wave still reads as operand image.
+// sum over the 16 lanes of a DPP row (= the 16 voxels of an MFMA column block), result in every lane: 4 x v_add_f32 with a
+// rotated second operand (row_ror:8/4/2/1) - no LDS crossbar traffic
+__device__ __forceinline__ float row16_sum(float v) {
+#define VDM_ROR_ADD(n)                                                                                                          \
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x120 + (n), 0xf, 0xf, false))
+    VDM_ROR_ADD(8);
+    VDM_ROR_ADD(4);
+    VDM_ROR_ADD(2);
+    VDM_ROR_ADD(1);
+#undef VDM_ROR_ADD
+    return v;
+}
+
+template <int NC>
+__device__ __forceinline__ void gn_partials_reduce(float (&gs)[NC * 4], float (&gq)[NC * 4], float* sm, float* dst /* [Cout][2] of this tile */,
+                                                   int cout0, int Cout, int wave, int lane) {
+    const int lx = lane & 15, q = lane >> 4;
+#pragma unroll
+    for (int j = 0; j < NC * 4; ++j) {
+        gs[j] = row16_sum(gs[j]);
+        gq[j] = row16_sum(gq[j]);
+    }
+    if (lx == 0) {
+#pragma unroll
+        for (int j = 0; j < NC * 4; ++j) {
+            sm[((wave * NC * 16) + q * NC * 4 + j) * 2] = gs[j];
+            sm[((wave * NC * 16) + q * NC * 4 + j) * 2 + 1] = gq[j];
+        }
+    }
+    __syncthreads();
+    const int t = wave * 64 + lane;
+    if (t < NC * 16 * 2) {
+        const int c = t >> 1;
+        const float tot = (sm[t] + sm[NC * 16 * 2 + t]) + (sm[2 * NC * 16 * 2 + t] + sm[3 * NC * 16 * 2 + t]);
+        if (cout0 + c < Cout) dst[(size_t)(cout0 + c) * 2 + (t & 1)] = tot;
+    }
+}
+
 // epilogue: + bias + per-sample conditioning bias + residual, cast, 16-byte NDHWC stores
 template <typename T, typename TO, typename G, int NC, int NV>
 __device__ __forceinline__ void conv_epilogue(const f32x4 (&acc)[NV][NC], const ConvArgs& a, int n, int chunk, int oz0, int oy0,
-                                              int ox0, int cwave, int lane) {
+                                              int ox0, int cwave, int lane, float* gn_sm = nullptr, int tile = 0) {
     constexpr int EPL = DT<T>::EPL;
+    float gs[NC * 4], gq[NC * 4];
+#pragma unroll
+    for (int j = 0; j < NC * 4; ++j) gs[j] = gq[j] = 0.f;
     const int lx = lane & 15, q = lane >> 4;
     const int cbase = chunk * NC * 16 + q * NC * 4;     // first of this lane's NC*4 consecutive couts
     float badd[NC * 4];
@@ -330,6 +378,14 @@ __device__ __forceinline__ void conv_epilogue(const f32x4 (&acc)[NV][NC], const 
         for (int c = 0; c < NC; ++c)
 #pragma unroll
             for (int j = 0; j < 4; ++j) val[c * 4 + j] = acc[v][c][j] + badd[c * 4 + j];
+        if (a.gnp && !vec_ok) {                           // (scalar tail path: residual is added below, element by element)
+#pragma unroll
+            for (int j = 0; j < NC * 4; ++j)
+                if (cbase + j < a.Cout) {
+                    const float r = val[j] + (res ? ld_elem<T>(res + vo + j) : 0.f);
+                    gs[j] += r; gq[j] += r * r;
+                }
+        }
         if (vec_ok) {
             if (res) {
                 constexpr int RP = NC * 4 / EPL > 0 ? NC * 4 / EPL : 1;    // 16-B pieces (bf16 NC=1: half piece)
@@ -345,6 +401,10 @@ __device__ __forceinline__ void conv_epilogue(const f32x4 (&acc)[NV][NC], const 
 #pragma unroll
                     for (int j = 0; j < NC * 4; ++j) val[j] += ld_elem<T>(res + vo + j);
                 }
+            }
+            if (a.gnp) {
+#pragma unroll
+                for (int j = 0; j < NC * 4; ++j) { gs[j] += val[j]; gq[j] += val[j] * val[j]; }
             }
             if (sizeof(TO) == 4) {
 #pragma unroll
@@ -374,6 +434,9 @@ __device__ __forceinline__ void conv_epilogue(const f32x4 (&acc)[NV][NC], const 
             }
         }
     }
+    if (a.gnp)                                            // workgroup-uniform
+        gn_partials_reduce<NC>(gs, gq, gn_sm, a.gnp + ((size_t)n * (a.ntz * a.nty * a.ntx) + tile) * a.Cout * 2, chunk * NC * 16, a.Cout,
+                               cwave, lane);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -423,7 +486,9 @@ __global__ void __launch_bounds__(256, (TZ * TY <= 16 && NC <= 2) ? 3 : 2) conv_
             taps_rolled<T, G, NC, NV>(acc, lds, wk, lanex);
         }
     }
-    conv_epilogue<T, TO, G, NC, NV>(acc, a, n, chunk, oz0, oy0, ox0, wave, lane);
+    constexpr int IMG = ((G::HVOX + 15) / 16) * 1024;     // the GN scratch sits behind the operand image
+    conv_epilogue<T, TO, G, NC, NV>(acc, a, n, chunk, oz0, oy0, ox0, wave, lane, reinterpret_cast<float*>(lds + IMG),
+                                    (tz * a.nty + ty) * a.ntx + tx);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -654,6 +719,18 @@ __global__ void __launch_bounds__(256, 1) conv_res_kernel(const ConvArgs a, cons
             }
             prev[v] = make_uint4(pack_bf16x2(acc[v][0][0], acc[v][0][1]), pack_bf16x2(acc[v][0][2], acc[v][0][3]),
                                  pack_bf16x2(acc[v][1][0], acc[v][1][1]), pack_bf16x2(acc[v][1][2], acc[v][1][3]));
+        }
+        if (a.gnp) {                                      // GroupNorm partials of this tile
+            float gs[NC * 4], gq[NC * 4];
+#pragma unroll
+            for (int j = 0; j < NC * 4; ++j) gs[j] = gq[j] = 0.f;
+#pragma unroll
+            for (int v = 0; v < NV; ++v)
+#pragma unroll
+                for (int j = 0; j < NC * 4; ++j) { gs[j] += acc[v][j >> 2][j & 3]; gq[j] += acc[v][j >> 2][j & 3] * acc[v][j >> 2][j & 3]; }
+            const int tps = a.ntz * a.nty * a.ntx;
+            gn_partials_reduce<NC>(gs, gq, reinterpret_cast<float*>(lds + 2 * BUF), a.gnp + ((size_t)cur.n * tps + it % tps) * a.Cout * 2, 0, a.Cout,
+                                   wave, lane);
         }
         prev_row0 = cur_row0;
         cur_row0 = nxt_row0;
@@ -1297,7 +1374,7 @@ static int launch_fwd_cfg(const ConvArgs& a0, hipStream_t s) {
     using G = Geo<KS, STRIDE, TZ, TY>;
     ConvArgs a = a0;
     a.ntz = cdiv(a.Dz, TZ); a.nty = cdiv(a.Dy, TY); a.ntx = cdiv(a.Dx, 16);
-    const size_t lds = (size_t)((G::HVOX + 15) / 16) * 1024;
+    const size_t lds = (size_t)((G::HVOX + 15) / 16) * 1024 + GN_SCRATCH_BYTES;
     auto kern = conv_fwd_kernel<T, TO, KS, STRIDE, UPS, NC, TZ, TY>;
     static bool attr_done = false;
     if (!attr_done) {
@@ -1367,7 +1444,7 @@ static int launch_res(const ConvArgs& a0, hipStream_t s) {
     ConvArgs a = a0;
     a.ntz = a.Dz / G::TZ; a.nty = a.Dy / G::TY; a.ntx = a.Dx / 16;
     const int ntiles = a.N * a.ntz * a.nty * a.ntx;
-    const size_t lds = (size_t)2 * ((G::HVOX + 15) / 16) * 1024;
+    const size_t lds = (size_t)2 * ((G::HVOX + 15) / 16) * 1024 + GN_SCRATCH_BYTES;
     static const float* zeros = nullptr;                  // stands in for absent bias terms (the kernel is branch-free there)
     if (!zeros) {
         void* zp = nullptr;
@@ -1566,6 +1643,17 @@ static void fill_dims(ConvArgs& a, const vdm_conv_desc* d) {
     a.circular = d->pad_mode == VDM_PAD_CIRCULAR;
 }
 
+// spatial tile (TZ, TY; TX = 16) that vdm_conv_fwd will use for this conv - mirrors launch_fwd / launch_fwd_geo
+static void fwd_tile_shape(const ConvArgs& a, int dtype, int out_f32, int ks, int stride, int ups, int& tz, int& ty) {
+    tz = 4; ty = 8;
+    if (uses_res(a, dtype, out_f32, ks, stride, ups)) return;
+    if (stride == 2) { tz = 2; ty = 4; return; }
+    if (ks == 3 && dtype == VDM_BF16) {
+        const long long tiles48 = (long long)a.nchunks * a.N * cdiv(a.Dz, 4) * cdiv(a.Dy, 8) * cdiv(a.Dx, 16);
+        if (tiles48 < 2LL * cu_count()) tz = 2;
+    }
+}
+
 }  // namespace vdm
 
 using namespace vdm;
@@ -1610,21 +1698,37 @@ extern "C" int vdm_conv_pack_weights(const vdm_conv_desc* d, int pack_mode, cons
     return VDM_OK;
 }
 
+static void fwd_args(ConvArgs& a, const vdm_conv_desc* d) {
+    const Plan p = plan_of(d, 0);
+    fill_dims(a, d);
+    a.Cin = d->cin; a.CinStride = cpad(d->cin, d->dtype); a.Cout = d->cout;
+    a.nchunks = p.nchunks; a.nkb = p.nkb;
+}
+
+extern "C" int vdm_conv_gn_tiles(const vdm_conv_desc* d) {
+    if (validate(d) != VDM_OK || uses_cls(d, 0)) return 0;
+    ConvArgs a{};
+    fwd_args(a, d);
+    int tz, ty;
+    fwd_tile_shape(a, d->dtype, d->out_f32, d->ksize, d->stride, d->upsample, tz, ty);
+    return cdiv(a.Dz, tz) * cdiv(a.Dy, ty) * cdiv(a.Dx, 16);
+}
+
 extern "C" int vdm_conv_fwd(const vdm_conv_desc* d, const void* x, const void* w_packed, const float* bias, const float* nbias,
-                            int64_t nbias_stride, const void* residual, void* out, void* stream) {
+                            int64_t nbias_stride, const void* residual, void* out, float* gn_partials, void* stream) {
     int e = validate(d);
     if (e) return e;
     VDM_REQUIRE(x && w_packed && out, "conv_fwd: NULL pointer");
     if (uses_cls(d, 0)) {
+        VDM_REQUIRE(!gn_partials, "conv_fwd: the up-sampling conv does not produce GroupNorm partials (vdm_conv_gn_tiles() == 0)");
         VDM_REQUIRE(!nbias && !d->out_f32, "conv_fwd: the up-sampling conv takes no per-sample bias / fp32 output");
         return run_cls(d, CLS_UP_FWD, x, w_packed, bias, residual, out, d->od / 2, d->oh / 2, d->ow / 2, (hipStream_t)stream);
     }
     const Plan p = plan_of(d, 0);
     ConvArgs a{};
     a.x = x; a.w = w_packed; a.bias = bias; a.nbias = nbias; a.nbias_stride = nbias_stride; a.res = residual; a.out = out;
-    fill_dims(a, d);
-    a.Cin = d->cin; a.CinStride = cpad(d->cin, d->dtype); a.Cout = d->cout;
-    a.nchunks = p.nchunks; a.nkb = p.nkb;
+    a.gnp = gn_partials;
+    fwd_args(a, d);
     return launch_fwd(a, d->dtype, d->out_f32, d->ksize, d->stride, d->upsample, p.nc, (hipStream_t)stream);
 }
 
@@ -1647,6 +1751,25 @@ extern "C" int vdm_conv_dgrad(const vdm_conv_desc* d, const void* dout, const vo
     a.Cin = d->cout; a.CinStride = cpad(d->cout, d->dtype); a.Cout = d->cin;
     a.nchunks = p.nchunks; a.nkb = p.nkb;
     return launch_fwd(a, d->dtype, 0, d->ksize, 1, 0, p.nc, (hipStream_t)stream);
+}
+
+extern "C" int vdm_conv_kernel_variant(const vdm_conv_desc* d, int dgrad) {
+    if (validate(d)) return -1;
+    if (uses_cls(d, dgrad)) return VDM_CONV_VARIANT_CLASS;
+    if (dgrad && d->stride == 2) return VDM_CONV_VARIANT_GENERIC;
+    const Plan p = plan_of(d, dgrad);
+    ConvArgs a{};
+    if (dgrad) {
+        a.N = d->n; a.Dz = d->od; a.Dy = d->oh; a.Dx = d->ow;
+        a.Iz = a.Sz = d->od; a.Iy = a.Sy = d->oh; a.Ix = a.Sx = d->ow;
+        a.Cin = d->cout; a.CinStride = cpad(d->cout, d->dtype); a.Cout = d->cin;
+    } else {
+        fill_dims(a, d);
+        a.Cin = d->cin; a.CinStride = cpad(d->cin, d->dtype); a.Cout = d->cout;
+    }
+    a.nchunks = p.nchunks; a.nkb = p.nkb;
+    return uses_res(a, d->dtype, dgrad ? 0 : d->out_f32, d->ksize, dgrad ? 1 : d->stride, dgrad ? 0 : d->upsample) ? VDM_CONV_VARIANT_RESIDENT
+                                                                                                                 : VDM_CONV_VARIANT_GENERIC;
 }
 
 extern "C" size_t vdm_conv_wgrad_workspace_bytes(const vdm_conv_desc* d) {

@@ -139,6 +139,31 @@ __global__ void __launch_bounds__(256) gn_stats_finalize_kernel(const float* __r
     }
 }
 
+// Same, from the per-tile channel partials a conv epilogue wrote (conv.hip, gn_partials_reduce): part[n][tile][C][2].
+// stats[n][g0 + g][k] = sum over tiles and over the gs channels of group g.  One block per (sample, group); thread t takes
+// the (tile, channel) pairs t, t+256, ... and a fixed LDS tree folds the 256 partial sums (deterministic).
+__global__ void __launch_bounds__(256) gn_stats_from_partials_kernel(const float* __restrict__ part, int tiles, int C, int gs, int G,
+                                                                     int g0, float* __restrict__ stats) {
+    const int gc = C / gs;
+    const int n = blockIdx.x / gc, g = blockIdx.x % gc;
+    const float2* p2 = reinterpret_cast<const float2*>(part) + (size_t)n * tiles * C + (size_t)g * gs;
+    float s0 = 0.f, s1 = 0.f;
+    const int total = tiles * gs;
+    for (int i = threadIdx.x; i < total; i += 256) {
+        const int b = i / gs, c = i - b * gs;
+        const float2 v = p2[(size_t)b * C + c];
+        s0 += v.x; s1 += v.y;
+    }
+    __shared__ float sm[2][256];
+    sm[0][threadIdx.x] = s0; sm[1][threadIdx.x] = s1;
+    __syncthreads();
+    for (int w = 128; w > 0; w >>= 1) {
+        if ((int)threadIdx.x < w) { sm[0][threadIdx.x] += sm[0][threadIdx.x + w]; sm[1][threadIdx.x] += sm[1][threadIdx.x + w]; }
+        __syncthreads();
+    }
+    if (threadIdx.x < 2) stats[((size_t)n * G + g0 + g) * 2 + threadIdx.x] = sm[threadIdx.x][0];
+}
+
 // per-(n, channel) affine of GN: y = x * A + B with A = rstd*gamma, B = beta - mean*rstd*gamma
 __device__ __forceinline__ void gn_affine(const float* __restrict__ stats, int n, int G, int g, float cnt, float eps, float gamma,
                                           float beta, float& A, float& B, float& mean, float& rstd) {
@@ -649,18 +674,27 @@ static int gn_common_check(int c1, int c2, int n, int64_t voxels, int groups, in
 }
 
 extern "C" int vdm_gn_stats(const void* x1, int c1, const void* x2, int c2, int n, int64_t voxels, int groups, int dtype, float* stats,
-                            float* workspace, void* stream) {
+                            float* workspace, const float* part1, int tiles1, const float* part2, int tiles2, void* stream) {
     int e = gn_common_check(c1, c2, n, voxels, groups, dtype, "gn_stats");
     if (e) return e;
-    VDM_REQUIRE(x1 && stats && workspace && (c2 == 0 || x2), "gn_stats: NULL pointer");
+    VDM_REQUIRE(stats && workspace && (x1 || part1) && (c2 == 0 || x2 || part2), "gn_stats: NULL pointer");
+    VDM_REQUIRE((!part1 || tiles1 > 0) && (!part2 || tiles2 > 0), "gn_stats: partials need a positive tile count");
     hipStream_t s = (hipStream_t)stream;
     const int epl = dtype == VDM_F32 ? 4 : 8;
     const int gs = (c1 + c2) / groups;
     const void* xs[2] = {x1, x2};
     const int cs[2] = {c1, c2};
+    const float* parts[2] = {part1, part2};
+    const int tiles[2] = {tiles1, tiles2};
     int g0 = 0;
     for (int k = 0; k < 2; ++k) {
         if (cs[k] == 0) continue;
+        if (parts[k]) {                                   // statistics already reduced per tile by the producing conv
+            hipLaunchKernelGGL(gn_stats_from_partials_kernel, dim3(n * (cs[k] / gs)), dim3(256), 0, s, parts[k], tiles[k], cs[k], gs, groups, g0, stats);
+            VDM_LAUNCH_CHECK("gn_stats_from_partials_kernel");
+            g0 += cs[k] / gs;
+            continue;
+        }
         const int ppv = cs[k] / epl;
         const int bpn = blocks_per_sample(voxels * ppv, ppv, n);
         if (dtype == VDM_F32)

@@ -144,7 +144,7 @@ class Conv:
             return (n, 2 * d, 2 * h, 2 * w, self.cout)
         return (n, d, h, w, self.cout)
 
-    def fwd(self, x, bias=None, nbias=None, residual=None, out=None):
+    def fwd(self, x, bias=None, nbias=None, residual=None, out=None, gn=False):
         """out = conv(x) + bias + nbias[n] + residual.  nbias: fp32 [N, >=cout] view (row stride honoured)."""
         L = _lib.lib()
         _contig(x, bias, residual)
@@ -160,13 +160,21 @@ class Conv:
         if residual is not None:
             assert residual.shape == out.shape and residual.dtype == x.dtype
         d = self.desc(shp[0], shp[1], shp[2], shp[3], x.dtype)
+        part = None
+        if gn:                    # GroupNorm statistics of `out`, reduced per tile by the epilogue; consumed by gn_stats(out, ...)
+            tiles = L.vdm_conv_gn_tiles(d)
+            if tiles > 0:
+                part = torch.empty((shp[0], tiles, self.cout, 2), dtype=torch.float32, device=x.device)
         ev = _pb()
-        check(L.vdm_conv_fwd(d, _p(x), _p(self.wf), _p(bias), _p(nbias), nstride, _p(residual), _p(out), _s()), "vdm_conv_fwd")
+        check(L.vdm_conv_fwd(d, _p(x), _p(self.wf), _p(bias), _p(nbias), nstride, _p(residual), _p(out), _p(part), _s()), "vdm_conv_fwd")
+        out.gn_partials = part
         if ev is not None:
             nvox = shp[0] * shp[1] * shp[2] * shp[3]
             es = x.element_size()
             if self.ksize == 3 and self.upsample:
                 key = f"conv_cls_kernel<{_tname(x.dtype)},NC{_nc_for(self.cout, x.dtype)},F>"
+            elif L.vdm_conv_kernel_variant(d, 0) == 2:
+                key = "conv_res_kernel"
             else:
                 key = f"conv_fwd_kernel<{_tname(x.dtype)},k{self.ksize},s{self.stride},NC{_nc_for(self.cout, x.dtype)}>"
             _pe(ev, key,
@@ -197,6 +205,8 @@ class Conv:
             es = dout.element_size()
             if self.ksize == 3 and (self.stride == 2 or self.upsample):
                 key = f"conv_cls_kernel<{_tname(dout.dtype)},NC{_nc_for(self.cin, dout.dtype)},{'B' if self.upsample else 'F'}>"
+            elif L.vdm_conv_kernel_variant(d, 1) == 2:
+                key = "conv_res_kernel"
             else:
                 key = f"conv_fwd_kernel<{_tname(dout.dtype)},k{self.ksize},s1,NC{_nc_for(self.cin, dout.dtype)}>"
             _pe(ev, key,
@@ -243,9 +253,13 @@ def gn_stats(x1, x2, groups, out=None):
     if ws is None:
         ws = _gn_ws[x1.device] = torch.empty(_lib.GN_STATS_WS_BYTES // 4, dtype=torch.float32, device=x1.device)
     c2 = 0 if x2 is None else x2.shape[-1]
+    p1 = getattr(x1, "gn_partials", None)       # set by Conv.fwd(..., gn=True): that source needs no pass over the tensor
+    p2 = getattr(x2, "gn_partials", None) if x2 is not None else None
     ev = _pb()
-    check(L.vdm_gn_stats(_p(x1), x1.shape[-1], _p(x2), c2, n, v, groups, dt_id(x1.dtype), _p(out), _p(ws), _s()), "vdm_gn_stats")
-    _pe(ev, "gn_stats", 0.0, x1.numel() * x1.element_size() + (x2.numel() * x2.element_size() if x2 is not None else 0))
+    check(L.vdm_gn_stats(_p(x1), x1.shape[-1], _p(x2), c2, n, v, groups, dt_id(x1.dtype), _p(out), _p(ws),
+                         _p(p1), 0 if p1 is None else p1.shape[1], _p(p2), 0 if p2 is None else p2.shape[1], _s()), "vdm_gn_stats")
+    _pe(ev, "gn_stats", 0.0, (x1.numel() * x1.element_size() if p1 is None else 0)
+        + (x2.numel() * x2.element_size() if (x2 is not None and p2 is None) else 0))
     return out
 
 

@@ -9,8 +9,13 @@ Backward returns the gradient of the flat parameter vector and of the conditioni
 """
 import torch
 
+import os
+
 from . import hip_ops as ops
 from .hip_ops import Conv
+
+# GroupNorm statistics from the producing conv's epilogue (VDM4CDM_FUSED_GN=0: separate gn_stats passes, for A/B timing)
+FUSED_GN = os.environ.get("VDM4CDM_FUSED_GN", "1") != "0"
 
 
 class SideStream:
@@ -64,7 +69,7 @@ class _Res:
         i, G, n = self.i, self.net.norm_groups, self.i.name
         st1 = ops.gn_stats(x1, x2, G)
         a1 = ops.gn_silu_fwd(x1, x2, G, st1, P(n + ".norm1.weight"), P(n + ".norm1.bias"))
-        h = self.conv1.fwd(a1, P(n + ".conv1.bias"), table[:, i.table_off:i.table_off + i.cout])
+        h = self.conv1.fwd(a1, P(n + ".conv1.bias"), table[:, i.table_off:i.table_off + i.cout], gn=FUSED_GN)
         st2 = ops.gn_stats(h, None, G)
         p = self.net.dropout_prob if train else 0.0
         a2 = ops.gn_silu_fwd(h, None, G, st2, P(n + ".norm2.weight"), P(n + ".norm2.bias"), p, seed)
@@ -74,7 +79,7 @@ class _Res:
                 s = self.skip2.fwd(x2, None, None, s)
         else:
             s = x1
-        out = self.conv2.fwd(a2, P(n + ".conv2.bias"), None, s)
+        out = self.conv2.fwd(a2, P(n + ".conv2.bias"), None, s, gn=FUSED_GN)     # (every block output feeds a GroupNorm)
         if train:
             self.saved = (x1, x2, st1, a1, h, st2, a2, p, seed)
         return out
@@ -161,13 +166,13 @@ class HipUNet:
         P = lambda name: net.view(name, flat)
         L = len(net.chs)
         xin = ops.pack_input(z, s_cond, dtype)
-        h = self.conv_in.fwd(xin, P("conv_in.bias"))
+        h = self.conv_in.fwd(xin, P("conv_in.bias"), gn=FUSED_GN)
         skips = []
         for i in range(L):
             h = self.res[f"downs.{i}.block"].fwd(P, h, None, table, train, seed + 2 * i)
             if i != L - 1:
                 skips.append(h)
-                h = self.down[i].fwd(h, P(f"downs.{i}.down.bias"))
+                h = self.down[i].fwd(h, P(f"downs.{i}.down.bias"), gn=FUSED_GN)
         for j in range(2):
             h = self.res[f"mid.{j}"].fwd(P, h, None, table, train, seed + 100 + j)
         coarse = []
