@@ -81,11 +81,10 @@ int vdm_conv_dgrad(const vdm_conv_desc* d, const void* dout, const void* w_packe
  * dbias (optional, ksize 3 only): dbias[cout] = sum over samples and voxels of dout (the conv bias gradient), computed
  * from the dOut tiles the kernel stages anyway.  accumulate != 0 adds to dw / dbias instead of overwriting. */
 /* Which kernel family vdm_conv_fwd (dgrad = 0) / vdm_conv_dgrad (dgrad = 1) launches for this descriptor (profiling keys,
- * tests): generic implicit-GEMM kernel, per-parity-class kernel (up-sampling conv and its gradients, stride-2 dgrad), or the
- * resident-weight persistent kernel (bf16 32->32, 3x3x3, stride 1, whole 4x8x16 tiles, >= 4 tiles per CU).  < 0: bad descriptor. */
+ * tests): the generic implicit-GEMM kernel or the per-parity-class kernel (up-sampling conv and its gradients, stride-2
+ * dgrad).  < 0: bad descriptor. */
 #define VDM_CONV_VARIANT_GENERIC 0
 #define VDM_CONV_VARIANT_CLASS 1
-#define VDM_CONV_VARIANT_RESIDENT 2
 int vdm_conv_kernel_variant(const vdm_conv_desc* d, int dgrad);
 
 size_t vdm_conv_wgrad_workspace_bytes(const vdm_conv_desc* d);

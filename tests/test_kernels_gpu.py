@@ -135,9 +135,8 @@ def test_conv_out_f32():
     assert (out.cpu() - ref).abs().max().item() <= 1e-4 * ref.abs().max().item() + 1e-5
 
 
-RES_CASES = [
-    # large level-0 shapes.  bf16 32 -> 32 on whole 4x8x16 tiles with >= 4 tiles per CU takes the resident-weight persistent
-    # kernel (the first three cases); the others stay on the generic kernel at the same sizes.
+LARGE_CASES = [
+    # large level-0 shapes (thousands of workgroups: several rounds per CU, uneven XCD split, volume boundaries of every kind)
     ("res_32_32", 2, (64, 64, 64), 32, 32, 3, 1, 0, False),
     ("res_uneven", 3, (52, 56, 64), 32, 32, 3, 1, 0, True),      # 1092 tiles: uneven split over XCDs and workgroups
     ("res_ragged_24_32", 3, (50, 60, 70), 24, 32, 3, 1, 0, False),
@@ -147,9 +146,9 @@ RES_CASES = [
 ]
 
 
-@pytest.mark.parametrize("case", RES_CASES, ids=[c[0] for c in RES_CASES])
-def test_conv_resident(case):
-    """Level-0 shapes: forward (all epilogue terms) and input gradient through the persistent resident-weight kernel."""
+@pytest.mark.parametrize("case", LARGE_CASES, ids=[c[0] for c in LARGE_CASES])
+def test_conv_large(case):
+    """Level-0 sized grids: forward (all epilogue terms), input gradient and gradient accumulation."""
     dtype = torch.bfloat16
     ops, conv, x, w, xd = _conv_setup(case, dtype, seed=30)
     name, N, (D, H, W), cin, cout, ks, stride, ups, circ = case
@@ -179,7 +178,7 @@ def test_conv_resident(case):
 
 
 GN_FUSED_CASES = [c for c in CONV_CASES if c[0] in ("k3_32_32", "k3_32_32_ragged", "k3_64_32", "k3_128_256", "k3_cin2pad", "k3_circ_small",
-                                                      "k3_s2", "k3_s2_ragged", "k1_64_32", "k3_16_16", "k3_48_96")] + RES_CASES[:2]
+                                                      "k3_s2", "k3_s2_ragged", "k1_64_32", "k3_16_16", "k3_48_96")] + LARGE_CASES[:2]
 
 
 @pytest.mark.parametrize("dtype", DTYPES, ids=["f32", "bf16"])

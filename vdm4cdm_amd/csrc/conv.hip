@@ -19,7 +19,6 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
-#include <type_traits>
 
 #include "common.h"
 
@@ -489,263 +488,6 @@ __global__ void __launch_bounds__(256, (TZ * TY <= 16 && NC <= 2) ? 3 : 2) conv_
     constexpr int IMG = ((G::HVOX + 15) / 16) * 1024;     // the GN scratch sits behind the operand image
     conv_epilogue<T, TO, G, NC, NV>(acc, a, n, chunk, oz0, oy0, ox0, wave, lane, reinterpret_cast<float*>(lds + IMG),
                                     (tz * a.nty + ty) * a.ntx + tx);
-}
-
-// ---------------------------------------------------------------------------------------------
-// Resident-weight persistent kernel (bf16, 3x3x3, stride 1, Cin <= 32 = one K-block, Cout <= 32): the level-0 convs, where
-// the per-tile HBM time (read 1 tile + write 1 tile) about equals the per-tile MFMA time, so the two MUST overlap.
-// The vector L1 (TCP) returns in order per CU: in the generic kernel a tap's weight load queues behind the halo loads of
-// the co-resident workgroup, which serialises one workgroup's MFMA phase with the other's staging phase.  Here the tap loop
-// never touches the TCP:
-//   * all 27 x NC weight fragments live in registers for the whole kernel (one workgroup per CU, 512 registers per lane);
-//   * the halo image is double-buffered in LDS (2 x 68 KiB); the LDS-DMA loads of tile i+1 are issued one per tap inside
-//     the tap loop of tile i (inline asm, so the compiler neither counts them in vmcnt nor orders LDS reads after them);
-//   * one s_waitcnt vmcnt(0) + barrier per tile, after the tap loop (by then the DMA of tile i+1 and the stores of tile
-//     i-1 have long retired), then the epilogue of tile i.
-// ---------------------------------------------------------------------------------------------
-__device__ __forceinline__ void lds_dma16(const void* src, unsigned lds_addr) {
-    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(src), "s"(lds_addr) : "memory");
-}
-
-struct ResTile { int n, oz0, oy0, ox0; };
-
-typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
-
-// v_mfma with the A operand (resident weights) in AGPRs and the accumulator in VGPRs.  Inline asm: the compiler sees neither
-// the MFMA latency nor its hazards - see the explicit s_nop before the accumulators are read.
-__device__ __forceinline__ void mfma_agpr_a(f32x4& acc, const u32x4& a_agpr, const u32x4& b) {
-    asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+v"(acc) : "a"(a_agpr), "v"(b));
-}
-
-template <bool HAS_RES>
-__global__ void __launch_bounds__(256, 1) conv_res_kernel(const ConvArgs a, const int ntiles) {
-    using T = bf16_t;
-    using G = Geo<3, 1, 4, 8>;
-    constexpr int NC = 2, NV = G::NV, TAPS = G::TAPS, EPL = DT<T>::EPL;
-    constexpr int NCHUNK = (G::HVOX + 15) / 16;          // 1-KiB DMA chunks (16 voxels) per halo image
-    constexpr int NDMA = NCHUNK / 4;                     // per wave
-    constexpr int BUF = NCHUNK * 1024;
-    constexpr int ROWB = G::HX * 64;
-    constexpr int INVALID = (int)0x80000000;
-    static_assert(NCHUNK % 4 == 0 && 2 * 9 >= NDMA && NV == 8 && G::TY == NV, "schedule below assumes 17 DMA chunks and 8 rows per wave");
-    extern __shared__ __attribute__((aligned(16))) char lds[];
-
-    const int tid = threadIdx.x;
-    const int lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int lx = lane & 15, q = lane >> 4;
-    const unsigned lds_base = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)lds;
-
-    // tiles of this workgroup: XCD x (blocks x, x+8, ...) owns a contiguous eighth of the tiles, each of its workgroups a
-    // contiguous run inside it (x fastest: every workgroup gets the same share of volume-boundary tiles, and consecutive
-    // tiles share halo columns in L2)
-    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3, nslot = gridDim.x >> 3;
-    const int x_begin = (int)((long long)ntiles * xcd / 8), x_end = (int)((long long)ntiles * (xcd + 1) / 8);
-    const int t_begin = x_begin + (int)((long long)(x_end - x_begin) * slot / nslot);
-    const int t_end = x_begin + (int)((long long)(x_end - x_begin) * (slot + 1) / nslot);
-    constexpr int per = 1;
-    auto decode = [&](int t) {
-        ResTile r;
-        r.ox0 = (t % a.ntx) * 16; t /= a.ntx;
-        r.oy0 = (t % a.nty) * G::TY; t /= a.nty;
-        r.oz0 = (t % a.ntz) * G::TZ;
-        r.n = t / a.ntz;
-        return r;
-    };
-
-    // resident weights: 27 taps x 2 cout tiles x 4 dwords = 216 AGPRs
-    u32x4 wreg[TAPS][NC];
-    {
-        const u32x4* wk = reinterpret_cast<const u32x4*>(a.w) + lane;
-#pragma unroll
-        for (int tap = 0; tap < TAPS; ++tap)
-#pragma unroll
-            for (int c = 0; c < NC; ++c) wreg[tap][c] = wk[(tap * NC + c) * 64];
-        // pin them (and make the compiler wait for the loads here, not inside the persistent loop where its vmcnt
-        // bookkeeping would also wait for the asm LDS-DMA loads it does not know about)
-#pragma unroll
-        for (int tap = 0; tap < TAPS; ++tap)
-#pragma unroll
-            for (int c = 0; c < NC; ++c) asm volatile("" : "+a"(wreg[tap][c]));
-    }
-    float bias8[NC * 4];                                  // this lane's 8 consecutive couts: q*8 .. q*8+7
-#pragma unroll
-    for (int j = 0; j < NC * 4; ++j) bias8[j] = a.bias[q * NC * 4 + j];
-
-    // per-lane constants of this wave's DMA chunks (chunk c = wave + 4k, lane -> halo voxel c*16 + lane/4, piece pc):
-    //   rel[k] element offset from the tile's first halo voxel (enough when the whole halo is inside the volume);
-    //   pk[k]  byte indices into the per-tile coordinate tables (below), the piece's channel offset, the never-valid flag
-    int rel[NDMA], pk[NDMA];
-#pragma unroll
-    for (int k = 0; k < NDMA; ++k) {
-        const int hv = (wave + 4 * k) * 16 + (lane >> 2);
-        const int hx = hv % G::HX;
-        const int t = hv / G::HX;
-        const int hy = t % G::HY;
-        const int hz = t / G::HY;
-        const int pc = (lane & 3) ^ ((hx >> 1) & 3);
-        const bool ok = hv < G::HVOX;                     // (the image is padded to whole chunks; the pad is never read)
-        rel[k] = ok ? ((hz * a.Sy + hy) * a.Sx + hx) * a.CinStride + pc * EPL : 0;
-        pk[k] = (hz * 4) | ((hy * 4) << 8) | ((hx * 4) << 16) | ((pc * EPL) << 24) | (ok ? 0 : INVALID);
-    }
-    // Per-tile coordinate tables for tiles whose halo leaves the volume, one entry per LANE (lane j <-> halo plane / row /
-    // column j): element offset of the wrapped input coordinate, or INVALID for zero padding.  A DMA lane fetches its three
-    // entries with ds_bpermute.
-    const int wz = a.circular ? a.Iz : 0, wy = a.circular ? a.Iy : 0, wx = a.circular ? a.Ix : 0;
-    const int sy = a.Sx * a.CinStride, sz = a.Sy * sy;
-    const size_t sample_elems = (size_t)a.Sz * sz;
-    struct Stage { int tz, ty, tx; const T* sample; const T* base; bool interior; };
-    auto tables = [&](const ResTile& r) {
-        Stage s;
-        const int iz0 = r.oz0 - 1, iy0 = r.oy0 - 1, ix0 = r.ox0 - 1;
-        int c = iz0 + lane; c += (c >> 31) & wz; c -= ((a.Iz - 1 - c) >> 31) & wz;
-        s.tz = (unsigned)c < (unsigned)a.Iz ? c * sz : INVALID;
-        c = iy0 + lane; c += (c >> 31) & wy; c -= ((a.Iy - 1 - c) >> 31) & wy;
-        s.ty = (unsigned)c < (unsigned)a.Iy ? c * sy : INVALID;
-        c = ix0 + lane; c += (c >> 31) & wx; c -= ((a.Ix - 1 - c) >> 31) & wx;
-        s.tx = (unsigned)c < (unsigned)a.Ix ? c * a.CinStride : INVALID;
-        s.sample = reinterpret_cast<const T*>(a.x) + (size_t)r.n * sample_elems;
-        s.interior = iz0 >= 0 && iy0 >= 0 && ix0 >= 0 && iz0 + G::HZ <= a.Iz && iy0 + G::HY <= a.Iy && ix0 + G::HX <= a.Ix;
-        s.base = s.sample + (iz0 * sz + iy0 * sy + ix0 * a.CinStride);
-        return s;
-    };
-    auto issue = [&](auto interior_c, int k, const Stage& s, int buf) {
-        const void* src;
-        if constexpr (decltype(interior_c)::value) {
-            src = s.base + rel[k];
-        } else {
-            int p = pk[k];
-            asm volatile("" : "+v"(p));           // keep the field extraction here (hoisted out of the tile loop it costs 4 registers per chunk)
-            const int oz = __builtin_amdgcn_ds_bpermute(p & 0xff, s.tz);
-            const int oy = __builtin_amdgcn_ds_bpermute((p >> 8) & 0xff, s.ty);
-            const int ox = __builtin_amdgcn_ds_bpermute((p >> 16) & 0xff, s.tx);
-            const bool inv = (oz | oy | ox | p) < 0;
-            const unsigned off = (unsigned)(oz + oy + ox + ((p >> 24) & 63));
-            src = inv ? static_cast<const void*>(g_zero_page) : static_cast<const void*>(s.sample + off);
-        }
-        lds_dma16(src, lds_base + buf * BUF + (wave + 4 * k) * 1024);
-    };
-    // first output row (v = 0) of this lane in a tile; rows v are Dx voxels apart
-    const size_t row_elems = (size_t)a.Dx * a.Cout;
-    auto row0 = [&](const ResTile& r) {
-        return ((((size_t)r.n * a.Dz + r.oz0 + wave) * a.Dy + r.oy0) * a.Dx + r.ox0 + lx) * a.Cout + q * NC * 4;
-    };
-
-    int lanex[3];
-    operand_lane_offsets<G, NV>(lanex, wave, lane);
-
-    int it = t_begin;
-    if (it >= t_end) return;                                                  // whole workgroup
-    ResTile cur = decode(it);
-    {
-        const Stage s0 = tables(cur);
-#pragma unroll
-        for (int k = 0; k < NDMA; ++k) issue(std::false_type{}, k, s0, 0);
-    }
-    ResTile nxt = it + per < t_end ? decode(it + per) : cur;
-    Stage sn = tables(nxt);
-    uint16_t* const out = reinterpret_cast<uint16_t*>(a.out);
-    const T* const res = reinterpret_cast<const T*>(a.res);
-
-    // accumulator start values of the first tile: bias + per-sample bias (+ residual)
-    float nb8[NC * 4];                // per-sample bias of the NEXT tile
-    size_t cur_row0 = row0(cur);
-#pragma unroll
-    for (int j = 0; j < NC * 4; ++j) nb8[j] = a.nbias[(size_t)cur.n * a.nbias_stride + q * NC * 4 + j];
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-
-    uint4 prev[NV];                   // finished tile (packed bf16), stored during the next tile's taps
-    size_t prev_row0 = 0;
-    int buf = 0;
-
-    // one tile: 27 taps with, interleaved in the same straight-line code (so that they issue in the shadow of the MFMAs):
-    //   taps 0..8   the 17 LDS-DMA chunks of the NEXT tile          taps 9..16  the 8 row stores of the PREVIOUS tile
-    //   taps 17..24 the residual rows of THIS tile                   tap 19      next per-sample bias; tile after next + tables
-    auto tile = [&](auto first_c, auto interior_c) {
-        constexpr bool FIRST = decltype(first_c)::value;
-        f32x4 acc[NV][NC];
-#pragma unroll
-        for (int v = 0; v < NV; ++v)
-#pragma unroll
-            for (int c = 0; c < NC; ++c)
-                acc[v][c] = f32x4{bias8[c * 4] + nb8[c * 4], bias8[c * 4 + 1] + nb8[c * 4 + 1], bias8[c * 4 + 2] + nb8[c * 4 + 2],
-                                  bias8[c * 4 + 3] + nb8[c * 4 + 3]};
-        uint4 resv[NV];               // residual rows of this tile: loaded late in the taps (the registers of prev[] are free by then)
-        const char* ldsb = lds + buf * BUF;
-        const size_t nxt_row0 = row0(nxt);
-        ResTile nn = cur;
-        Stage s2 = sn;
-        // B fragments: one register set refilled in place - row v of tap t+1 is read right after the MFMAs of row v of tap t
-        u32x4 af[NV];
-#pragma unroll
-        for (int v = 0; v < NV; ++v) af[v] = *reinterpret_cast<const u32x4*>(ldsb + lanex[0] + v * ROWB);
-#pragma unroll
-        for (int tap = 0; tap < TAPS; ++tap) {
-            if (2 * tap < NDMA) issue(interior_c, 2 * tap, sn, buf ^ 1);
-            if (2 * tap + 1 < NDMA) issue(interior_c, 2 * tap + 1, sn, buf ^ 1);
-            if (!FIRST && tap >= 9 && tap < 9 + NV)
-                *reinterpret_cast<uint4*>(out + prev_row0 + (size_t)(tap - 9) * row_elems) = prev[tap - 9];
-            if (HAS_RES && tap >= 17 && tap < 17 + NV)
-                resv[tap - 17] = *reinterpret_cast<const uint4*>(res + cur_row0 + (size_t)(tap - 17) * row_elems);
-            if (tap == 19) {
-#pragma unroll
-                for (int j = 0; j < NC * 4; ++j) nb8[j] = a.nbias[(size_t)nxt.n * a.nbias_stride + q * NC * 4 + j];
-                const int it2 = it + 2 * per < t_end ? it + 2 * per : it;
-                nn = decode(it2);
-                s2 = tables(nn);
-            }
-            const int t1 = tap + 1;
-            const int dz = t1 / 9, dy = (t1 / 3) % 3, dx = t1 % 3;
-            const int toff = (dz * G::HY + dy) * G::HX * 64;
-#pragma unroll
-            for (int v = 0; v < NV; ++v) {
-#pragma unroll
-                for (int c = 0; c < NC; ++c) mfma_agpr_a(acc[v][c], wreg[tap][c], af[v]);
-                if (t1 < TAPS) af[v] = *reinterpret_cast<const u32x4*>(ldsb + lanex[dx] + v * ROWB + toff);
-            }
-            __builtin_amdgcn_sched_barrier(0);
-        }
-        // DMA of the next tile landed; MFMA results architecturally visible (the compiler does not know the asm is an MFMA)
-        asm volatile("s_waitcnt vmcnt(0)\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15" ::: "memory");
-        __syncthreads();
-#pragma unroll
-        for (int v = 0; v < NV; ++v) {
-            if (HAS_RES) {
-                Piece<T> pr;
-                pr.load(resv[v]);
-#pragma unroll
-                for (int j = 0; j < EPL; ++j) acc[v][j >> 2][j & 3] += pr.f[j];
-            }
-            prev[v] = make_uint4(pack_bf16x2(acc[v][0][0], acc[v][0][1]), pack_bf16x2(acc[v][0][2], acc[v][0][3]),
-                                 pack_bf16x2(acc[v][1][0], acc[v][1][1]), pack_bf16x2(acc[v][1][2], acc[v][1][3]));
-        }
-        if (a.gnp) {                                      // GroupNorm partials of this tile
-            float gs[NC * 4], gq[NC * 4];
-#pragma unroll
-            for (int j = 0; j < NC * 4; ++j) gs[j] = gq[j] = 0.f;
-#pragma unroll
-            for (int v = 0; v < NV; ++v)
-#pragma unroll
-                for (int j = 0; j < NC * 4; ++j) { gs[j] += acc[v][j >> 2][j & 3]; gq[j] += acc[v][j >> 2][j & 3] * acc[v][j >> 2][j & 3]; }
-            const int tps = a.ntz * a.nty * a.ntx;
-            gn_partials_reduce<NC>(gs, gq, reinterpret_cast<float*>(lds + 2 * BUF), a.gnp + ((size_t)cur.n * tps + it % tps) * a.Cout * 2, 0, a.Cout,
-                                   wave, lane);
-        }
-        prev_row0 = cur_row0;
-        cur_row0 = nxt_row0;
-        // rotate: (cur, nxt) <- (nxt, tile after next)
-        const bool more = it + per < t_end;
-        cur = nxt; nxt = nn; sn = s2;
-        it += per;
-        buf ^= 1;
-        return more;
-    };
-
-    bool more = sn.interior ? tile(std::true_type{}, std::true_type{}) : tile(std::true_type{}, std::false_type{});
-    while (more) more = sn.interior ? tile(std::false_type{}, std::true_type{}) : tile(std::false_type{}, std::false_type{});
-#pragma unroll
-    for (int v = 0; v < NV; ++v) *reinterpret_cast<uint4*>(out + prev_row0 + (size_t)v * row_elems) = prev[v];
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1429,47 +1171,8 @@ static int launch_fwd_variant(const ConvArgs& a, int ks, int stride, int ups, in
     return launch_fwd_nc<T, TO, 3, 1, 0>(a, nc, s);
 }
 
-// resident-weight persistent kernel: bf16 3x3x3 stride-1 convs with one K-block (Cin <= 32) and exactly 32 output channels, on
-// grids of whole 4x8x16 tiles with enough tiles to keep every CU busy for several rounds
-static bool uses_res(const ConvArgs& a, int dtype, int out_f32, int ks, int stride, int ups) {
-    if (dtype != VDM_BF16 || out_f32 || ks != 3 || stride != 1 || ups || a.Cin != 32 || a.CinStride != 32 || a.Cout != 32) return false;
-    if (a.Dz % 4 || a.Dy % 8 || a.Dx % 16 || a.Iz < 6 || a.Iy < 10 || a.Ix < 18) return false;
-    if ((long long)a.Sz * a.Sy * a.Sx * a.CinStride >= (1LL << 30)) return false;       // 32-bit element offsets inside a sample
-    const long long tiles = (long long)a.N * (a.Dz / 4) * (a.Dy / 8) * (a.Dx / 16);
-    return tiles >= 4LL * cu_count() && tiles < 0x7fffffffLL && getenv("VDM4CDM_NO_RES") == nullptr;
-}
-
-static int launch_res(const ConvArgs& a0, hipStream_t s) {
-    using G = Geo<3, 1, 4, 8>;
-    ConvArgs a = a0;
-    a.ntz = a.Dz / G::TZ; a.nty = a.Dy / G::TY; a.ntx = a.Dx / 16;
-    const int ntiles = a.N * a.ntz * a.nty * a.ntx;
-    const size_t lds = (size_t)2 * ((G::HVOX + 15) / 16) * 1024 + GN_SCRATCH_BYTES;
-    static const float* zeros = nullptr;                  // stands in for absent bias terms (the kernel is branch-free there)
-    if (!zeros) {
-        void* zp = nullptr;
-        int e = check_hip(hipGetSymbolAddress(&zp, HIP_SYMBOL(g_zero_page)), "hipGetSymbolAddress(g_zero_page)");
-        if (e) return e;
-        zeros = static_cast<const float*>(zp);
-    }
-    if (!a.bias) a.bias = zeros;
-    if (!a.nbias) { a.nbias = zeros; a.nbias_stride = 0; }
-    auto kern = a.res ? conv_res_kernel<true> : conv_res_kernel<false>;
-    static bool attr_done[2] = {false, false};
-    if (!attr_done[a.res ? 1 : 0]) {
-        int e = set_lds(kern, lds);
-        if (e) return e;
-        attr_done[a.res ? 1 : 0] = true;
-    }
-    const int grid = cu_count() / 8 * 8;                  // one workgroup per CU, a multiple of the 8 XCDs
-    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(256), lds, s, a, ntiles);
-    VDM_LAUNCH_CHECK("conv_res_kernel");
-    return VDM_OK;
-}
-
 static int launch_fwd(const ConvArgs& a, int dtype, int out_f32, int ks, int stride, int ups, int nc, hipStream_t s) {
     if (dtype == VDM_F32) return launch_fwd_variant<float, float>(a, ks, stride, ups, nc, s);
-    if (uses_res(a, dtype, out_f32, ks, stride, ups)) return launch_res(a, s);
     if (out_f32) {
         if (!(ks == 3 && stride == 1 && !ups && nc == 1)) {
             set_error("conv: out_f32 with bf16 input is only built for ksize 3, stride 1, cout <= 16");
@@ -1646,7 +1349,6 @@ static void fill_dims(ConvArgs& a, const vdm_conv_desc* d) {
 // spatial tile (TZ, TY; TX = 16) that vdm_conv_fwd will use for this conv - mirrors launch_fwd / launch_fwd_geo
 static void fwd_tile_shape(const ConvArgs& a, int dtype, int out_f32, int ks, int stride, int ups, int& tz, int& ty) {
     tz = 4; ty = 8;
-    if (uses_res(a, dtype, out_f32, ks, stride, ups)) return;
     if (stride == 2) { tz = 2; ty = 4; return; }
     if (ks == 3 && dtype == VDM_BF16) {
         const long long tiles48 = (long long)a.nchunks * a.N * cdiv(a.Dz, 4) * cdiv(a.Dy, 8) * cdiv(a.Dx, 16);
@@ -1755,21 +1457,7 @@ extern "C" int vdm_conv_dgrad(const vdm_conv_desc* d, const void* dout, const vo
 
 extern "C" int vdm_conv_kernel_variant(const vdm_conv_desc* d, int dgrad) {
     if (validate(d)) return -1;
-    if (uses_cls(d, dgrad)) return VDM_CONV_VARIANT_CLASS;
-    if (dgrad && d->stride == 2) return VDM_CONV_VARIANT_GENERIC;
-    const Plan p = plan_of(d, dgrad);
-    ConvArgs a{};
-    if (dgrad) {
-        a.N = d->n; a.Dz = d->od; a.Dy = d->oh; a.Dx = d->ow;
-        a.Iz = a.Sz = d->od; a.Iy = a.Sy = d->oh; a.Ix = a.Sx = d->ow;
-        a.Cin = d->cout; a.CinStride = cpad(d->cout, d->dtype); a.Cout = d->cin;
-    } else {
-        fill_dims(a, d);
-        a.Cin = d->cin; a.CinStride = cpad(d->cin, d->dtype); a.Cout = d->cout;
-    }
-    a.nchunks = p.nchunks; a.nkb = p.nkb;
-    return uses_res(a, d->dtype, dgrad ? 0 : d->out_f32, d->ksize, dgrad ? 1 : d->stride, dgrad ? 0 : d->upsample) ? VDM_CONV_VARIANT_RESIDENT
-                                                                                                                 : VDM_CONV_VARIANT_GENERIC;
+    return uses_cls(d, dgrad) ? VDM_CONV_VARIANT_CLASS : VDM_CONV_VARIANT_GENERIC;
 }
 
 extern "C" size_t vdm_conv_wgrad_workspace_bytes(const vdm_conv_desc* d) {
