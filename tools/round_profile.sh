@@ -7,7 +7,7 @@ out=$PWD/gpurun_out
 mkdir -p "$out"
 python bench.py > "$out/${tag}_bench_c3.json" 2> "$out/${tag}_bench_c3.err"
 export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d "$out/${tag}_stats" -- python3 bench.py --steps 10 --warmup 3 --no-cpu-baseline > "$out/${tag}_stats_bench.json" 2> "$out/${tag}_stats.err"
+rocprofv3 --kernel-trace --stats --output-format csv -d "$out/${tag}_stats" -- python3 bench.py --steps 10 --warmup 3 --no-cpu-baseline --all-kernel-events > "$out/${tag}_stats_bench.json" 2> "$out/${tag}_stats.err"
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d "$out/${tag}_pmc_f" -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-kernel-events > /dev/null 2> "$out/${tag}_pmc_f.err"
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d "$out/${tag}_pmc_w" -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-kernel-events > /dev/null 2> "$out/${tag}_pmc_w.err"
 python tools/pmc_traffic.py "$out/${tag}_pmc_f" "$out/${tag}_pmc_w" "$out/${tag}_pmc_bench_traffic.json"

@@ -18,8 +18,9 @@ class KernelProfiler:
     """Optional per-launch HIP-event timing (bench.py): events are recorded on the launch stream around each
     C-ABI call; `summary()` aggregates per kernel key after a synchronize."""
 
-    def __init__(self):
+    def __init__(self, tags=None):
         self.records = []          # (key, start, end, flops, bytes)
+        self.tags = tags           # None: every launch; else only launches whose tag is in this set (event records cost time too)
 
     def begin(self):
         e = torch.cuda.Event(enable_timing=True)
@@ -46,8 +47,10 @@ class KernelProfiler:
 PROFILER = None        # set to a KernelProfiler by bench.py
 
 
-def _pb():
-    return PROFILER.begin() if PROFILER is not None else None
+def _pb(tag="other"):
+    if PROFILER is None or (PROFILER.tags is not None and tag not in PROFILER.tags):
+        return None
+    return PROFILER.begin()
 
 
 def _pe(ev, key, flops=0.0, nbytes=0.0):
@@ -165,7 +168,7 @@ class Conv:
             tiles = L.vdm_conv_gn_tiles(d)
             if tiles > 0:
                 part = torch.empty((shp[0], tiles, self.cout, 2), dtype=torch.float32, device=x.device)
-        ev = _pb()
+        ev = _pb("conv3" if self.ksize == 3 else "other")
         check(L.vdm_conv_fwd(d, _p(x), _p(self.wf), _p(bias), _p(nbias), nstride, _p(residual), _p(out), _p(part), _s()), "vdm_conv_fwd")
         out.gn_partials = part
         if ev is not None:
@@ -196,7 +199,7 @@ class Conv:
             out = torch.empty(ishape, dtype=dout.dtype, device=dout.device)
         assert tuple(out.shape) == ishape and (residual is None or tuple(residual.shape) == ishape)
         d = self.desc(n, od, oh, ow, dout.dtype)
-        ev = _pb()
+        ev = _pb("conv3" if self.ksize == 3 else "other")
         check(L.vdm_conv_dgrad(d, _p(dout), _p(self.wd), _p(residual), _p(out), _s()), "vdm_conv_dgrad")
         if ev is not None:
             nvox = n * od * oh * ow
