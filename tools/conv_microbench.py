@@ -22,6 +22,8 @@ SHAPES = [  # name, N, D (output), cin, cout, ks, stride, ups
     ("L3_256_256", 2, 16, 256, 256, 3, 1, 0),
     ("L0_down_32_32", 2, 64, 32, 32, 3, 2, 0),
     ("L0_skip_64_32", 2, 128, 64, 32, 1, 1, 0),
+    ("L0_in_2_32", 2, 128, 2, 32, 3, 1, 0),
+    ("L0_out_32_1", 2, 128, 32, 1, 3, 1, 0),
 ]
 
 
@@ -41,8 +43,8 @@ def main():
         w = torch.randn(ks ** 3, cout, cin, device=dev) * 0.05
         conv.pack(w, dt, need_dgrad=True)
         iD = D * 2 if stride == 2 else (D // 2 if ups else D)
-        x = torch.randn(N, iD, iD, iD, cin, device=dev).to(dt)
-        dout = torch.randn(N, D, D, D, cout, device=dev).to(dt)
+        x = torch.randn(N, iD, iD, iD, ops.cpad(cin, dt), device=dev).to(dt)
+        dout = torch.randn(N, D, D, D, ops.cpad(cout, dt), device=dev).to(dt)
         dw = torch.zeros(ks ** 3, cout, cin, device=dev)
         flops = 2.0 * N * D ** 3 * ks ** 3 * cin * cout
         res = []

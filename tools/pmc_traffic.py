@@ -21,6 +21,8 @@ def simplify(name):
     m = re.search(r"conv_fwd_kernel<vdm::(\w+), (?:vdm::)?(\w+), (\d), (\d), (\d), (\d), \d, \d>", name)
     if m:
         return f"conv_fwd_kernel<{m.group(1)},k{m.group(3)},s{m.group(4)},NC{m.group(6)}>"
+    if "conv_kpack_kernel" in name:
+        return "conv_kpack_kernel"
     m = re.search(r"conv_cls_kernel<vdm::(\w+), (\d), (\d)>", name)
     if m:
         return f"conv_cls_kernel<{m.group(1)},NC{m.group(2)},{'B' if m.group(3) == '1' else 'F'}>"

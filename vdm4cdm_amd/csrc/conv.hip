@@ -491,6 +491,96 @@ __global__ void __launch_bounds__(256, (TZ * TY <= 16 && NC <= 2) ? 3 : 2) conv_
 }
 
 // ---------------------------------------------------------------------------------------------
+// Tap-packed kernel for the convs with <= 8 input channels (conv_in: 2 -> 32; input gradient of conv_out: 1 -> 32), bf16.
+// One 16-byte piece holds ALL channels of a voxel, so the 32-deep K of an MFMA is filled with 4 TAPS x 8 channels instead of
+// one tap x 32 channels of which 24..31 are padding: 7 tap groups instead of 27 taps (3.9x fewer MFMAs), an LDS image of
+// 16 B per halo voxel (17 KB), one LDS-DMA lane per voxel.  Lane (voxel lx, k-chunk q) reads the voxel shifted by tap 4g+q;
+// the packed weights hold W[tap 4g+q][cout][ci] in the matching A-fragment slot (zero for tap >= 27, ci >= Cin).
+// These convs are bound by writing / reading the 32-channel tensor (HBM), not by MFMA.
+// ---------------------------------------------------------------------------------------------
+template <typename TO, int NC>
+__global__ void __launch_bounds__(256, 4) conv_kpack_kernel(const ConvArgs a) {
+    using T = bf16_t;
+    using G = Geo<3, 1, 4, 8>;
+    constexpr int NV = G::NV, NG = (G::TAPS + 3) / 4;
+    constexpr int NCH = (G::HVOX + 63) / 64;               // DMA chunks of 64 voxels (1 KiB)
+    constexpr int ROWB = G::HX * 16;
+    extern __shared__ __attribute__((aligned(16))) char lds[];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+
+    int b = xcd_remap(blockIdx.x, gridDim.x);
+    const int tx = b % a.ntx; b /= a.ntx;
+    const int ty = b % a.nty; b /= a.nty;
+    const int tz = b % a.ntz; b /= a.ntz;
+    const int n = b % a.N;
+    const int chunk = b / a.N;
+    const int oz0 = tz * G::TZ, oy0 = ty * G::TY, ox0 = tx * 16;
+
+    // stage the halo: one lane per voxel
+    const T* x = reinterpret_cast<const T*>(a.x);
+    for (int c = wave; c < NCH; c += 4) {
+        const int hv = c * 64 + lane;
+        const int hx = hv % G::HX;
+        const int t = hv / G::HX;
+        const int hy = t % G::HY;
+        const int hz = t / G::HY;
+        int iz = oz0 - 1 + hz, iy = oy0 - 1 + hy, ix = ox0 - 1 + hx;
+        bool ok = hv < G::HVOX;
+        if (a.circular) {
+            iz = wrap(iz, a.Iz); iy = wrap(iy, a.Iy); ix = wrap(ix, a.Ix);
+        } else {
+            ok = ok && (unsigned)iz < (unsigned)a.Iz && (unsigned)iy < (unsigned)a.Iy && (unsigned)ix < (unsigned)a.Ix;
+        }
+        const size_t off = ((((size_t)n * a.Sz + iz) * a.Sy + iy) * a.Sx + ix) * a.CinStride;
+        const void* src = ok ? static_cast<const void*>(x + off) : static_cast<const void*>(g_zero_page);
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                         (__attribute__((address_space(3))) void*)(lds + c * 1024), 16, 0, 0);
+    }
+    // weights of this cout chunk: NG x NC fragments
+    uint4 wf[NG][NC];
+    {
+        const uint4* wk = reinterpret_cast<const uint4*>(a.w) + (size_t)chunk * NG * NC * 64 + lane;
+#pragma unroll
+        for (int g = 0; g < NG; ++g)
+#pragma unroll
+            for (int c = 0; c < NC; ++c) wf[g][c] = wk[(g * NC + c) * 64];
+    }
+    // operand addresses: wave's first row + this lane's voxel + the shift of tap 4g + q
+    const int lx = lane & 15, q = lane >> 4;
+    const int r0 = wave * NV;
+    const int base = (((r0 / G::TY) * G::HY + (r0 % G::TY)) * G::HX + lx) * 16;
+    int goff[NG];
+#pragma unroll
+    for (int g = 0; g < NG; ++g) {
+        const int tap = 4 * g + q;
+        const int dz = tap / 9, dy = (tap / 3) % 3, dx = tap % 3;
+        goff[g] = tap < G::TAPS ? base + ((dz * G::HY + dy) * G::HX + dx) * 16 : base;      // (tap 27: zero weights)
+    }
+    f32x4 acc[NV][NC];
+#pragma unroll
+    for (int v = 0; v < NV; ++v)
+#pragma unroll
+        for (int c = 0; c < NC; ++c) acc[v][c] = f32x4{0.f, 0.f, 0.f, 0.f};
+    __syncthreads();
+#pragma unroll
+    for (int g = 0; g < NG; ++g) {
+        uint4 af[NV];
+#pragma unroll
+        for (int v = 0; v < NV; ++v) af[v] = *reinterpret_cast<const uint4*>(lds + goff[g] + v * ROWB);
+#pragma unroll
+        for (int v = 0; v < NV; ++v)
+#pragma unroll
+            for (int c = 0; c < NC; ++c) mma16<T>(acc[v][c], wf[g][c], af[v]);
+    }
+    constexpr int IMG = NCH * 1024;
+    conv_epilogue<T, TO, G, NC, NV>(acc, a, n, chunk, oz0, oy0, ox0, wave, lane, reinterpret_cast<float*>(lds + IMG),
+                                    (tz * a.nty + ty) * a.ntx + tx);
+}
+
+// ---------------------------------------------------------------------------------------------
 // "Class" convolutions: the convs that couple a coarse grid c and the 2x finer grid u = 2c + p, p in {0,1}^3.
 // For a fixed parity class p only a subset of the 27 taps (possibly merged) touches a given coarse offset, so these
 // convs are run per class on the COARSE index space with a short tap list (<= 8 entries) instead of 27 taps on the fine
@@ -842,7 +932,9 @@ template <> struct TrFetch<float> {
     }
 };
 
-template <typename T, int KS, int STRIDE, int UPS, int TZ, int TY>
+// NTA / NTB: 16-channel tiles of the 64-byte cout / cin block that hold real channels (conv_out has 1 output channel, conv_in 2
+// input channels: half of the MFMAs and transposed reads of the block would multiply padding).
+template <typename T, int KS, int STRIDE, int UPS, int TZ, int TY, int NTA = WG<T>::NT, int NTB = WG<T>::NT>
 __global__ void __launch_bounds__(256, 2) conv_wgrad_kernel(const WgradArgs w) {
     using G = Geo<KS, STRIDE, TZ, TY>;
     using TF = TrFetch<T>;
@@ -873,18 +965,18 @@ __global__ void __launch_bounds__(256, 2) conv_wgrad_kernel(const WgradArgs w) {
     const int cb = pr / w.nkb, kb = pr % w.nkb;            // cout block, cin block
     const int pz = (cls >> 2) & 1, py = (cls >> 1) & 1, px = cls & 1;
 
-    f32x4 acc[TPW][NT][NT];
+    f32x4 acc[TPW][NTA][NTB];
 #pragma unroll
     for (int t = 0; t < TPW; ++t)
 #pragma unroll
-        for (int i = 0; i < NT; ++i)
+        for (int i = 0; i < NTA; ++i)
 #pragma unroll
-            for (int j = 0; j < NT; ++j) acc[t][i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+            for (int j = 0; j < NTB; ++j) acc[t][i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
     // KS=3: wave owns taps wave, wave+4, ... over all rows.  KS=1: all waves own tap 0, rows split.
     int tap_u[TPW];                       // wave-uniform byte offset of the tap's (dz, dy) shift
-    int lo_in[TPW][NT][NOFF];             // per-lane offsets (depend on the tap's dx through the x-swizzle)
-    int lo_do[NT][NOFF];
+    int lo_in[TPW][NTB][NOFF];             // per-lane offsets (depend on the tap's dx through the x-swizzle)
+    int lo_do[NTA][NOFF];
 #pragma unroll
     for (int t = 0; t < TPW; ++t) {
         int tap = (TAPS > 1) ? wave + 4 * t : 0;
@@ -893,10 +985,10 @@ __global__ void __launch_bounds__(256, 2) conv_wgrad_kernel(const WgradArgs w) {
                   dx = CLS ? (tap & 1) + px : tap % KS;
         tap_u[t] = (dz * G::HY + dy) * G::HX * 64;
 #pragma unroll
-        for (int j = 0; j < NT; ++j) TF::lane_off(lo_in[t][j], j, STRIDE, dx, lane);
+        for (int j = 0; j < NTB; ++j) TF::lane_off(lo_in[t][j], j, STRIDE, dx, lane);
     }
 #pragma unroll
-    for (int i = 0; i < NT; ++i) TF::lane_off(lo_do[i], i, 1, 0, lane);
+    for (int i = 0; i < NTA; ++i) TF::lane_off(lo_do[i], i, 1, 0, lane);
     const int row0 = (TAPS > 1) ? 0 : wave * RSTEP;
     const int rowinc = (TAPS > 1) ? RSTEP : 4 * RSTEP;
 
@@ -923,39 +1015,39 @@ __global__ void __launch_bounds__(256, 2) conv_wgrad_kernel(const WgradArgs w) {
         __syncthreads();                                   // (drains the LDS-DMA: vmcnt(0) + barrier)
         // Software pipeline: while the MFMAs of tap t run, the transposed fragments of tap t+1 (or of the next
         // row's tap 0 and its dOut fragments) are already in flight; sched_barrier(0) pins that order.
-        uint4 af[NT], afn[NT], bfA[NT], bfB[NT];
+        uint4 af[NTA], afn[NTA], bfA[NTB], bfB[NTB];
 #pragma unroll
-        for (int i = 0; i < NT; ++i) af[i] = TF::template get<HI_DO>(lds_do, lo_do[i], row0 * 1024);
+        for (int i = 0; i < NTA; ++i) af[i] = TF::template get<HI_DO>(lds_do, lo_do[i], row0 * 1024);
 #pragma unroll
-        for (int j = 0; j < NT; ++j) bfA[j] = TF::template get<HI_IN>(lds_in, lo_in[0][j], in_base(row0) + tap_u[0]);
+        for (int j = 0; j < NTB; ++j) bfA[j] = TF::template get<HI_IN>(lds_in, lo_in[0][j], in_base(row0) + tap_u[0]);
         for (int r = row0; r < G::ROWS; r += rowinc) {
             const int rn = (r + rowinc < G::ROWS) ? r + rowinc : r;      // clamp: the last prefetch is harmless
             const int i0 = in_base(r), in0 = in_base(rn);
 #pragma unroll
             for (int t = 0; t < TPW; ++t) {
-                uint4 (&cur)[NT] = (t & 1) ? bfB : bfA;
-                uint4 (&nxt)[NT] = (t & 1) ? bfA : bfB;
+                uint4 (&cur)[NTB] = (t & 1) ? bfB : bfA;
+                uint4 (&nxt)[NTB] = (t & 1) ? bfA : bfB;
                 if (t + 1 < TPW) {
 #pragma unroll
-                    for (int j = 0; j < NT; ++j) nxt[j] = TF::template get<HI_IN>(lds_in, lo_in[t + 1 < TPW ? t + 1 : 0][j], i0 + tap_u[t + 1 < TPW ? t + 1 : 0]);
+                    for (int j = 0; j < NTB; ++j) nxt[j] = TF::template get<HI_IN>(lds_in, lo_in[t + 1 < TPW ? t + 1 : 0][j], i0 + tap_u[t + 1 < TPW ? t + 1 : 0]);
                 } else {
 #pragma unroll
-                    for (int i = 0; i < NT; ++i) afn[i] = TF::template get<HI_DO>(lds_do, lo_do[i], rn * 1024);
+                    for (int i = 0; i < NTA; ++i) afn[i] = TF::template get<HI_DO>(lds_do, lo_do[i], rn * 1024);
 #pragma unroll
-                    for (int j = 0; j < NT; ++j) nxt[j] = TF::template get<HI_IN>(lds_in, lo_in[0][j], in0 + tap_u[0]);
+                    for (int j = 0; j < NTB; ++j) nxt[j] = TF::template get<HI_IN>(lds_in, lo_in[0][j], in0 + tap_u[0]);
                 }
                 __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                for (int i = 0; i < NT; ++i)
+                for (int i = 0; i < NTA; ++i)
 #pragma unroll
-                    for (int j = 0; j < NT; ++j) mma16<T>(acc[t][i][j], af[i], cur[j]);
+                    for (int j = 0; j < NTB; ++j) mma16<T>(acc[t][i][j], af[i], cur[j]);
                 __builtin_amdgcn_sched_barrier(0);
             }
 #pragma unroll
-            for (int i = 0; i < NT; ++i) af[i] = afn[i];
+            for (int i = 0; i < NTA; ++i) af[i] = afn[i];
             if (TPW & 1) {
 #pragma unroll
-                for (int j = 0; j < NT; ++j) bfA[j] = bfB[j];
+                for (int j = 0; j < NTB; ++j) bfA[j] = bfB[j];
             }
         }
         // bias gradient: column sums of this dOut tile (already in LDS), by the workgroups with cin block 0; every wave
@@ -1002,7 +1094,7 @@ __global__ void __launch_bounds__(256, 2) conv_wgrad_kernel(const WgradArgs w) {
             for (int j = 0; j < NT; ++j)
 #pragma unroll
                 for (int rg = 0; rg < 4; ++rg)
-                    slab[(tap * CL + i * 16 + gq * 4 + rg) * CL + j * 16 + col] = acc[t][i][j][rg];
+                    slab[(tap * CL + i * 16 + gq * 4 + rg) * CL + j * 16 + col] = (i < NTA && j < NTB) ? acc[t][i < NTA ? i : 0][j < NTB ? j : 0][rg] : 0.f;
     }
 }
 
@@ -1124,6 +1216,32 @@ __global__ void pack_weights_kernel(const float* __restrict__ w, T* __restrict__
     }
 }
 
+// packed weights of conv_kpack_kernel: [chunk][tap group g][cout tile][lane (m, q)][ci 0..7] = W[tap 4g+q][cout][ci]
+__global__ void pack_weights_kpack_kernel(const float* __restrict__ w, bf16_t* __restrict__ p, int cout_m, int cin_m, int nc, int nchunks,
+                                          int dgrad) {
+    const size_t total = (size_t)nchunks * 7 * nc * 64 * 8;
+    const int O = dgrad ? cin_m : cout_m, K = dgrad ? cout_m : cin_m;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        size_t r = i;
+        const int j = r % 8; r /= 8;
+        const int lane = r % 64; r /= 64;
+        const int ct = r % nc; r /= nc;
+        const int g = r % 7; r /= 7;
+        const int chunk = (int)r;
+        const int m = lane & 15, q = lane >> 4;
+        const int o = chunk * nc * 16 + nc * 4 * (m >> 2) + 4 * ct + (m & 3);
+        const int tap = 4 * g + q;
+        float v = 0.f;
+        if (o < O && j < K && tap < 27) {
+            if (dgrad)
+                v = w[((size_t)(26 - tap) * cout_m + j) * cin_m + o];
+            else
+                v = w[((size_t)tap * cout_m + o) * cin_m + j];
+        }
+        st_elem<bf16_t>(p + i, v);
+    }
+}
+
 // ---------------------------------------------------------------------------------------------
 // host side
 // ---------------------------------------------------------------------------------------------
@@ -1230,7 +1348,29 @@ static int launch_fwd_variant(const ConvArgs& a, int ks, int stride, int ups, in
     return launch_fwd_nc<T, TO, 3, 1, 0>(a, nc, s);
 }
 
+// tap-packed kernel: bf16 3x3x3 stride-1 convs whose reduction has <= 8 channels (one 16-byte piece per voxel)
+static bool uses_kpack(int dtype, int ks, int stride, int ups, int K, int O, int out_f32) {
+    return dtype == VDM_BF16 && ks == 3 && stride == 1 && !ups && K <= 8 && O <= 32 && !out_f32 && getenv("VDM4CDM_NO_KPACK") == nullptr;
+}
+static bool uses_kpack(const vdm_conv_desc* d, int dgrad) {
+    return uses_kpack(d->dtype, d->ksize, d->stride, d->upsample, dgrad ? d->cout : d->cin, dgrad ? d->cin : d->cout, dgrad ? 0 : d->out_f32);
+}
+
+template <int NC>
+static int launch_kpack(const ConvArgs& a0, hipStream_t s) {
+    using G = Geo<3, 1, 4, 8>;
+    ConvArgs a = a0;
+    a.ntz = cdiv(a.Dz, G::TZ); a.nty = cdiv(a.Dy, G::TY); a.ntx = cdiv(a.Dx, 16);
+    const size_t lds = (size_t)((G::HVOX + 63) / 64) * 1024 + GN_SCRATCH_BYTES;
+    const long long nwg = (long long)a.N * a.ntz * a.nty * a.ntx * a.nchunks;
+    if (nwg > 0x7fffffffLL) { set_error("conv: grid too large"); return VDM_ERR_ARG; }
+    hipLaunchKernelGGL((conv_kpack_kernel<bf16_t, NC>), dim3((unsigned)nwg), dim3(256), lds, s, a);
+    VDM_LAUNCH_CHECK("conv_kpack_kernel");
+    return VDM_OK;
+}
+
 static int launch_fwd(const ConvArgs& a, int dtype, int out_f32, int ks, int stride, int ups, int nc, hipStream_t s) {
+    if (uses_kpack(dtype, ks, stride, ups, a.Cin, a.Cout, out_f32)) return nc == 1 ? launch_kpack<1>(a, s) : launch_kpack<2>(a, s);
     if (dtype == VDM_F32) return launch_fwd_variant<float, float>(a, ks, stride, ups, nc, s);
     if (out_f32) {
         if (!(ks == 3 && stride == 1 && !ups && nc == 1)) {
@@ -1242,7 +1382,7 @@ static int launch_fwd(const ConvArgs& a, int dtype, int out_f32, int ks, int str
     return launch_fwd_variant<bf16_t, bf16_t>(a, ks, stride, ups, nc, s);
 }
 
-template <typename T, int KS, int STRIDE, int UPS, int TZ, int TY>
+template <typename T, int KS, int STRIDE, int UPS, int TZ, int TY, int NTA = WG<T>::NT, int NTB = WG<T>::NT>
 static int launch_wgrad_cfg(WgradArgs w, float* dw, float* dbias, int accumulate, int cout, int cin, size_t ws_bytes, hipStream_t s) {
     using G = Geo<KS, STRIDE, TZ, TY>;
     constexpr int CL = WG<T>::NT * 16;
@@ -1261,7 +1401,7 @@ static int launch_wgrad_cfg(WgradArgs w, float* dw, float* dbias, int accumulate
     if (dbias != nullptr && G::TAPS == 1) { set_error("conv_wgrad: fused bias gradient is only built for ksize 3"); return VDM_ERR_UNSUPPORTED; }
     w.bslabs = dbias ? reinterpret_cast<float*>(reinterpret_cast<char*>(w.slabs) + slab_bytes) : nullptr;
     const size_t lds = (size_t)((G::HVOX + 15) / 16) * 1024 + (size_t)G::OVOX * 64;
-    auto kern = conv_wgrad_kernel<T, KS, STRIDE, UPS, TZ, TY>;
+    auto kern = conv_wgrad_kernel<T, KS, STRIDE, UPS, TZ, TY, NTA, NTB>;
     static bool attr_done = false;
     if (!attr_done) {
         int e = set_lds(kern, lds);
@@ -1326,6 +1466,10 @@ static int launch_wgrad(const WgradArgs& w, float* dw, float* db, int acc, int c
     if (ks == 1) return launch_wgrad_cfg<T, 1, 1, 0, 4, 8>(w, dw, db, acc, cout, cin, ws, s);
     if (stride == 2) return launch_wgrad_cfg<T, 3, 2, 0, 2, 4>(w, dw, db, acc, cout, cin, ws, s);
     if (ups) return launch_wgrad_cls<T, 2, 8, 512>(w, dw, db, acc, cout, cin, ws, s);      // (2x4x16 tiles with 1024 workgroups: same time)
+    if constexpr (sizeof(T) == 2) {                          // 64-byte blocks with a single real 16-channel tile
+        if (cin <= 16) return launch_wgrad_cfg<T, 3, 1, 0, 2, 8, 2, 1>(w, dw, db, acc, cout, cin, ws, s);
+        if (cout <= 16) return launch_wgrad_cfg<T, 3, 1, 0, 2, 8, 1, 2>(w, dw, db, acc, cout, cin, ws, s);
+    }
     return launch_wgrad_cfg<T, 3, 1, 0, 2, 8>(w, dw, db, acc, cout, cin, ws, s);
 }
 
@@ -1448,6 +1592,7 @@ static void fill_dims(ConvArgs& a, const vdm_conv_desc* d) {
 static void fwd_tile_shape(const ConvArgs& a, int dtype, int out_f32, int ks, int stride, int ups, int& tz, int& ty) {
     tz = 4; ty = 8;
     if (stride == 2) { tz = 2; ty = 4; return; }
+    if (uses_kpack(dtype, ks, stride, ups, a.Cin, a.Cout, out_f32)) return;
     if (ks == 3 && dtype == VDM_BF16) {
         const long long tiles48 = (long long)a.nchunks * a.N * cdiv(a.Dz, 4) * cdiv(a.Dy, 8) * cdiv(a.Dx, 16);
         if (tiles48 < 2LL * cu_count()) tz = 2;
@@ -1462,6 +1607,7 @@ extern "C" size_t vdm_conv_packed_bytes(const vdm_conv_desc* d, int pack_mode) {
     if (validate(d) != VDM_OK) return 0;
     const Plan p = plan_of(d, pack_mode == VDM_PACK_DGRAD);
     if (uses_cls(d, pack_mode == VDM_PACK_DGRAD)) return (size_t)p.nchunks * p.nkb * 64 * p.nc * 64 * 16;      // 64 (class, entry) slots
+    if (uses_kpack(d, pack_mode == VDM_PACK_DGRAD)) return (size_t)p.nchunks * 7 * p.nc * 64 * 16;                       // 7 groups of 4 taps
     return (size_t)p.nchunks * p.nkb * p.taps * p.nc * 64 * 16;
 }
 
@@ -1486,6 +1632,11 @@ extern "C" int vdm_conv_pack_weights(const vdm_conv_desc* d, int pack_mode, cons
             hipLaunchKernelGGL(pack_weights_cls_kernel<bf16_t>, dim3(grid), dim3(256), 0, s, w_master, (bf16_t*)w_packed, d->cout, d->cin,
                                p.nc, p.nchunks, p.nkb, dg, masks);
         VDM_LAUNCH_CHECK("pack_weights_cls_kernel");
+        return VDM_OK;
+    }
+    if (uses_kpack(d, dg)) {
+        hipLaunchKernelGGL(pack_weights_kpack_kernel, dim3(grid), dim3(256), 0, s, w_master, (bf16_t*)w_packed, d->cout, d->cin, p.nc, p.nchunks, dg);
+        VDM_LAUNCH_CHECK("pack_weights_kpack_kernel");
         return VDM_OK;
     }
     if (d->dtype == VDM_F32)
@@ -1555,7 +1706,8 @@ extern "C" int vdm_conv_dgrad(const vdm_conv_desc* d, const void* dout, const vo
 
 extern "C" int vdm_conv_kernel_variant(const vdm_conv_desc* d, int dgrad) {
     if (validate(d)) return -1;
-    return uses_cls(d, dgrad) ? VDM_CONV_VARIANT_CLASS : VDM_CONV_VARIANT_GENERIC;
+    if (uses_cls(d, dgrad)) return VDM_CONV_VARIANT_CLASS;
+    return uses_kpack(d, dgrad) ? VDM_CONV_VARIANT_KPACK : VDM_CONV_VARIANT_GENERIC;
 }
 
 extern "C" size_t vdm_conv_wgrad_workspace_bytes(const vdm_conv_desc* d) {

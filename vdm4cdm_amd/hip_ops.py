@@ -176,6 +176,8 @@ class Conv:
             es = x.element_size()
             if self.ksize == 3 and self.upsample:
                 key = f"conv_cls_kernel<{_tname(x.dtype)},NC{_nc_for(self.cout, x.dtype)},F>"
+            elif L.vdm_conv_kernel_variant(d, 0) == 2:
+                key = "conv_kpack_kernel"
             else:
                 key = f"conv_fwd_kernel<{_tname(x.dtype)},k{self.ksize},s{self.stride},NC{_nc_for(self.cout, x.dtype)}>"
             _pe(ev, key,
@@ -206,6 +208,8 @@ class Conv:
             es = dout.element_size()
             if self.ksize == 3 and (self.stride == 2 or self.upsample):
                 key = f"conv_cls_kernel<{_tname(dout.dtype)},NC{_nc_for(self.cin, dout.dtype)},{'B' if self.upsample else 'F'}>"
+            elif L.vdm_conv_kernel_variant(d, 1) == 2:
+                key = "conv_kpack_kernel"
             else:
                 key = f"conv_fwd_kernel<{_tname(dout.dtype)},k{self.ksize},s1,NC{_nc_for(self.cin, dout.dtype)}>"
             _pe(ev, key,
