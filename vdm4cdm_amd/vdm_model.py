@@ -18,6 +18,7 @@ import math
 
 import torch
 import torch.nn as nn
+import torch.nn.functional as F
 
 DATA_NOISE = 1.0e-3
 
@@ -225,9 +226,29 @@ class VDM(nn.Module):
         seed = int(torch.randint(0, 2 ** 62, (1,)).item()) if seed is None else int(seed)
         noise_buf = torch.empty_like(z) if noises is not None else None
 
+        # The conditioning of every step is known up front: run the (tiny) embedding MLPs once for all n time values and
+        # keep one table row per step; inside the step only a row gather remains (about 20 small launches less per step).
+        net = self.score_model
+        with torch.no_grad():
+            k0 = 0
+            table_t = None
+            if net.t_conditioning:
+                table_t = F.linear(net._mlp2("t_embed", net.sinusoidal_embedding(coef[:, 3].contiguous())), net.cond_matrix(0))
+                k0 = 1
+            table_v = None
+            for k, v in enumerate(list(kwargs.get("v_conditionings") or [])):
+                part = F.linear(net._mlp2(f"v_embeds.{k}", v.to(device=dev, dtype=torch.float32)), net.cond_matrix(k0 + k))
+                table_v = part if table_v is None else table_v + part
+        s_cond = kwargs.get("s_conditioning")
+        from .unet_hip import hip_unet_apply
+
         def one_step():
-            t_norm = coef[:, 3].index_select(0, step.to(torch.int64)).expand(B)
-            eps_hat = self.score_model(z, t=t_norm, **kwargs)
+            if table_t is not None:
+                table = table_t.index_select(0, step).expand(B, -1)
+                table = table + table_v if table_v is not None else table.contiguous()
+            else:
+                table = table_v if table_v is not None else torch.zeros(B, net.table_width, device=dev)
+            eps_hat = hip_unet_apply(net, z, s_cond, table)
             ops.ancestral_step(z, eps_hat.contiguous(), noise_buf, coef, step, seed)
             ops.step_inc(step)
 
