@@ -149,10 +149,17 @@ __global__ void __launch_bounds__(256) gn_stats_from_partials_kernel(const float
     const float2* p2 = reinterpret_cast<const float2*>(part) + (size_t)n * tiles * C + (size_t)g * gs;
     float s0 = 0.f, s1 = 0.f;
     const int total = tiles * gs;
-    for (int i = threadIdx.x; i < total; i += 256) {
-        const int b = i / gs, c = i - b * gs;
-        const float2 v = p2[(size_t)b * C + c];
-        s0 += v.x; s1 += v.y;
+    constexpr int U = 8;                                   // independent loads in flight per thread (the kernel is pure latency)
+    for (int i0 = threadIdx.x; i0 < total; i0 += 256 * U) {
+        float2 v[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int i = i0 + u * 256;
+            const int b = i / gs, c = i - b * gs;
+            v[u] = i < total ? p2[(size_t)b * C + c] : make_float2(0.f, 0.f);
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) { s0 += v[u].x; s1 += v[u].y; }
     }
     __shared__ float sm[2][256];
     sm[0][threadIdx.x] = s0; sm[1][threadIdx.x] = s1;
