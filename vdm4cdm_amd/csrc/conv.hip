@@ -1100,12 +1100,13 @@ __global__ void __launch_bounds__(256, 2) conv_wgrad_kernel(const WgradArgs w) {
 
 // dw[tap][co][ci] (+)= sum over slabs.  Block = 64 outputs x 4 slab groups; each thread sums its slabs with 8
 // independent loads in flight, then the 4 groups are combined through LDS in a fixed order (deterministic).
+constexpr int WRED_OUT = 64, WRED_GRP = 4;                  // outputs per block x slab groups (256 threads); 32 x 8 is not faster
 __global__ void __launch_bounds__(256) wgrad_reduce_kernel(const float* __restrict__ slabs, float* __restrict__ dw, int taps,
                                                           int cout, int cin, int ncb, int nkb, int CL, int nslabs, int accumulate) {
     const int total = taps * cout * cin;
-    const int o = threadIdx.x & 63, sg = threadIdx.x >> 6;
-    const int i = blockIdx.x * 64 + o;
-    __shared__ float part[4][64];
+    const int o = threadIdx.x % WRED_OUT, sg = threadIdx.x / WRED_OUT;
+    const int i = blockIdx.x * WRED_OUT + o;
+    __shared__ float part[WRED_GRP][WRED_OUT];
     float sum = 0.f;
     if (i < total) {
         const int ci = i % cin, co = (i / cin) % cout, tap = i / (cin * cout);
@@ -1113,25 +1114,24 @@ __global__ void __launch_bounds__(256) wgrad_reduce_kernel(const float* __restri
         const size_t slab_elems = (size_t)taps * CL * CL;
         const float* s = slabs + (size_t)pair * nslabs * slab_elems + ((size_t)tap * CL + co % CL) * CL + ci % CL;
         int k = sg;
-        for (; k + 28 < nslabs; k += 32) {
+        for (; k + 7 * WRED_GRP < nslabs; k += 8 * WRED_GRP) {
             float v[8];
 #pragma unroll
-            for (int u = 0; u < 8; ++u) v[u] = s[(size_t)(k + 4 * u) * slab_elems];
+            for (int u = 0; u < 8; ++u) v[u] = s[(size_t)(k + WRED_GRP * u) * slab_elems];
 #pragma unroll
             for (int u = 0; u < 8; ++u) sum += v[u];
         }
-        for (; k < nslabs; k += 4) sum += s[(size_t)k * slab_elems];
+        for (; k < nslabs; k += WRED_GRP) sum += s[(size_t)k * slab_elems];
     }
     part[sg][o] = sum;
     __syncthreads();
     if (sg == 0 && i < total) {
-        const float tot = (part[0][o] + part[1][o]) + (part[2][o] + part[3][o]);
+        float tot = 0.f;
+#pragma unroll
+        for (int g = 0; g < WRED_GRP; ++g) tot += part[g][o];
         dw[i] = accumulate ? dw[i] + tot : tot;
     }
 }
-
-// dbias[co] (+)= sum over the P workgroups of bslab[co / CL][p][co % CL]   (fixed order: deterministic).
-// Block = 16 channels x 16 partial groups: every thread sums P/16 partials (independent loads), then an LDS tree.
 __global__ void __launch_bounds__(256) wgrad_bias_reduce_kernel(const float* __restrict__ bslabs, float* __restrict__ dbias, int cout,
                                                                int CL, int P, int accumulate) {
     const int c = threadIdx.x & 15, gp = threadIdx.x >> 4;
@@ -1411,7 +1411,7 @@ static int launch_wgrad_cfg(WgradArgs w, float* dw, float* dbias, int accumulate
     hipLaunchKernelGGL(kern, dim3(npairs * P), dim3(256), lds, s, w);
     VDM_LAUNCH_CHECK("conv_wgrad_kernel");
     const int total = G::TAPS * cout * cin;
-    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(cdiv(total, 64)), dim3(256), 0, s,
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(cdiv(total, WRED_OUT)), dim3(256), 0, s,
                        (const float*)w.slabs, dw, G::TAPS, cout, cin, w.ncb, w.nkb, CL, P * per_wg, accumulate);
     VDM_LAUNCH_CHECK("wgrad_reduce_kernel");
     if (dbias) {
