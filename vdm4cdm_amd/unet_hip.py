@@ -65,8 +65,16 @@ class _Res:
             out.append((self.skip2, n + ".skip2.weight"))
         return out
 
-    def fwd(self, P, x1, x2, table, train, seed):
+    def fwd(self, P, x1, x2, table, train, seed, ss):
         i, G, n = self.i, self.net.norm_groups, self.i.name
+        skip_out = []
+        if self.skip1 is not None:               # the 1x1 skip convs (HBM-bound) overlap with conv1 on the side stream
+            def side_skip():
+                s = self.skip1.fwd(x1, P(n + ".skip.bias"))
+                if self.skip2 is not None:
+                    s = self.skip2.fwd(x2, None, None, s)
+                skip_out.append(s)
+            ss.run(side_skip, x1, x2)
         st1 = ops.gn_stats(x1, x2, G)
         a1 = ops.gn_silu_fwd(x1, x2, G, st1, P(n + ".norm1.weight"), P(n + ".norm1.bias"))
         h = self.conv1.fwd(a1, P(n + ".conv1.bias"), table[:, i.table_off:i.table_off + i.cout], gn=FUSED_GN)
@@ -74,9 +82,10 @@ class _Res:
         p = self.net.dropout_prob if train else 0.0
         a2 = ops.gn_silu_fwd(h, None, G, st2, P(n + ".norm2.weight"), P(n + ".norm2.bias"), p, seed)
         if self.skip1 is not None:
-            s = self.skip1.fwd(x1, P(n + ".skip.bias"))
-            if self.skip2 is not None:
-                s = self.skip2.fwd(x2, None, None, s)
+            ss.join()
+            s = skip_out[0]
+            if ss.enabled:
+                s.record_stream(torch.cuda.current_stream())
         else:
             s = x1
         out = self.conv2.fwd(a2, P(n + ".conv2.bias"), None, s, gn=FUSED_GN)     # (every block output feeds a GroupNorm)
@@ -157,6 +166,11 @@ class HipUNet:
             conv.pack(self.net.view(name, flat), dtype, need_dgrad)
         self._packed_key = key
 
+    def _side_stream(self, device):
+        if self._ss is None or (self._ss.enabled and self._ss.side.device != device):
+            self._ss = SideStream(device, enabled=os.environ.get("VDM4CDM_WGRAD_STREAM", "1") != "0")
+        return self._ss
+
     # ---------------------------------------------------------------------------------------
     def forward(self, flat, table, z, s_cond, train, seed):
         """z, s_cond: fp32 [N, D, H, W] (single channel).  Returns eps_hat fp32 [N, D, H, W]."""
@@ -165,21 +179,22 @@ class HipUNet:
         self.pack_weights(flat, dtype, train)
         P = lambda name: net.view(name, flat)
         L = len(net.chs)
+        ss = self._side_stream(flat.device)
         xin = ops.pack_input(z, s_cond, dtype)
         h = self.conv_in.fwd(xin, P("conv_in.bias"), gn=FUSED_GN)
         skips = []
         for i in range(L):
-            h = self.res[f"downs.{i}.block"].fwd(P, h, None, table, train, seed + 2 * i)
+            h = self.res[f"downs.{i}.block"].fwd(P, h, None, table, train, seed + 2 * i, ss)
             if i != L - 1:
                 skips.append(h)
                 h = self.down[i].fwd(h, P(f"downs.{i}.down.bias"), gn=FUSED_GN)
         for j in range(2):
-            h = self.res[f"mid.{j}"].fwd(P, h, None, table, train, seed + 100 + j)
+            h = self.res[f"mid.{j}"].fwd(P, h, None, table, train, seed + 100 + j, ss)
         coarse = []
         for i in reversed(range(L - 1)):
             coarse.append(h)
             u = self.up[i].fwd(h, P(f"ups.{i}.up.bias"))
-            h = self.res[f"ups.{i}.block"].fwd(P, u, skips[i], table, train, seed + 200 + i)
+            h = self.res[f"ups.{i}.block"].fwd(P, u, skips[i], table, train, seed + 200 + i, ss)
         st = ops.gn_stats(h, None, net.norm_groups)
         a = ops.gn_silu_fwd(h, None, net.norm_groups, st, P("norm_out.weight"), P("norm_out.bias"))
         eps = self.conv_out.fwd(a, P("conv_out.bias"))
@@ -199,10 +214,7 @@ class HipUNet:
         P = lambda name: net.view(name, flat)
         GP = lambda name: net.view(name, gflat)
 
-        import os
-        if self._ss is None or (self._ss.enabled and self._ss.side.device != flat.device):
-            self._ss = SideStream(flat.device, enabled=os.environ.get("VDM4CDM_WGRAD_STREAM", "1") != "0")
-        ss = self._ss
+        ss = self._side_stream(flat.device)
         ss.run(lambda: None, gflat)                   # (orders the side stream after the zero-fill of gflat)
         dpad = ops.pack_input(d_eps.contiguous(), None, dtype)
         ss.run(lambda: self.conv_out.wgrad(a, dpad, GP("conv_out.weight")), a, dpad)
