@@ -23,9 +23,11 @@ class SideStream:
     with the (HBM-bound) GroupNorm kernels and the dgrad chain on the main stream.  `run(fn, *tensors)` makes the side
     stream wait for everything issued so far on the main stream, runs fn on it and marks the tensors as in use there."""
 
-    def __init__(self, device, enabled=True):
+    def __init__(self, device, enabled=True, with_second=True):
         self.enabled = enabled and torch.cuda.is_available()
         self.side = torch.cuda.Stream(device=device) if self.enabled else None
+        # a second, independent side stream (the skip-path input gradients must not queue behind the weight gradients)
+        self.second = SideStream(device, enabled and os.environ.get("VDM4CDM_SKIP_DGRAD_STREAM", "1") != "0", with_second=False) if with_second else None
 
     def run(self, fn, *tensors):
         if not self.enabled:
@@ -100,6 +102,13 @@ class _Res:
         x1, x2, st1, a1, h, st2, a2, p, seed = self.saved
         self.saved = None
 
+        skip_grads = []
+        if self.skip1 is not None:             # input gradients of the 1x1 skip convs: independent of the main chain until norm1
+            def side_skip_dgrad():
+                skip_grads.append(self.skip1.dgrad(dout))
+                skip_grads.append(self.skip2.dgrad(dout) if self.skip2 is not None else None)
+            ss.second.run(side_skip_dgrad, dout)
+
         def side_conv2():                      # conv2 (+ the 1x1 skip convs share dout)
             self.conv2.wgrad(a2, dout, GP(n + ".conv2.weight"), GP(n + ".conv2.bias"))      # bias grad fused (column sums of dout)
             if self.skip1 is not None:
@@ -120,9 +129,12 @@ class _Res:
         # skip path
         add1 = add2 = None
         if self.skip1 is not None:
-            add1 = self.skip1.dgrad(dout)
-            if self.skip2 is not None:
-                add2 = self.skip2.dgrad(dout)
+            ss.second.join()
+            add1, add2 = skip_grads
+            if ss.second.enabled:
+                for t in (add1, add2):
+                    if t is not None:
+                        t.record_stream(torch.cuda.current_stream())
         else:
             add1 = dout
         dx1, dx2 = ops.gn_silu_bwd(x1, x2, G, st1, P(n + ".norm1.weight"), P(n + ".norm1.bias"), da1,
