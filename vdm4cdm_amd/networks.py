@@ -18,6 +18,7 @@ Backends
   (2D 64^2 on CPU, "plumbing, no GPU") only.  Never selected automatically.
 """
 import math
+import os
 
 import torch
 import torch.nn as nn
@@ -123,6 +124,9 @@ class CUNet(nn.Module):
             sp.add(f"v_embeds.{k}.0.bias", (V_EMB_DIM,), "bias", dv)
             sp.add(f"v_embeds.{k}.2.weight", (V_EMB_DIM, V_EMB_DIM), "linear", V_EMB_DIM)
             sp.add(f"v_embeds.{k}.2.bias", (V_EMB_DIM,), "bias", V_EMB_DIM)
+        # everything the (torch autograd) conditioning MLPs read lies in [0, head_end): forward() slices the flat vector ONCE, so the
+        # backward pass materialises one full-size gradient for these parameters instead of one per parameter view
+        self.head_end = sp.total
         for b in self.blocks:
             cin = b.c1 + b.c2
             sp.add(f"{b.name}.norm1.weight", (cin,), "ones")
@@ -170,7 +174,8 @@ class CUNet(nn.Module):
         return f[off:off + math.prod(shape)].view(shape)
 
     def cond_matrix(self, k, flat=None):
-        """[sum cout, dim_k] projection matrix of conditioning k for all blocks at once."""
+        """[sum cout, dim_k] projection matrix of conditioning k for all blocks at once.  `flat` may be the flat vector or its head
+        slice flat[:head_end]."""
         off = self.spec.items[f"{self.blocks[0].name}.cond.{k}.weight"][0]
         f = self.flat if flat is None else flat
         return f[off:off + self.table_width * self.cond_dims[k]].view(self.table_width, self.cond_dims[k])
@@ -209,26 +214,26 @@ class CUNet(nn.Module):
         args = 1000.0 * t.to(torch.float32)[:, None] * freqs[None, :]
         return torch.cat([torch.sin(args), torch.cos(args)], dim=1)
 
-    def _mlp2(self, prefix, x):
-        x = F.gelu(F.linear(x, self.view(prefix + ".0.weight"), self.view(prefix + ".0.bias")))
-        return F.gelu(F.linear(x, self.view(prefix + ".2.weight"), self.view(prefix + ".2.bias")))
+    def _mlp2(self, prefix, x, head=None):
+        x = F.gelu(F.linear(x, self.view(prefix + ".0.weight", head), self.view(prefix + ".0.bias", head)))
+        return F.gelu(F.linear(x, self.view(prefix + ".2.weight", head), self.view(prefix + ".2.bias", head)))
 
-    def cond_vectors(self, t, v_conditionings):
+    def cond_vectors(self, t, v_conditionings, head=None):
         conds = []
         if self.t_conditioning:
             assert t is not None, "t_conditioning=True needs t"
-            conds.append(self._mlp2("t_embed", self.sinusoidal_embedding(t.reshape(-1))))
+            conds.append(self._mlp2("t_embed", self.sinusoidal_embedding(t.reshape(-1)), head))
         vs = list(v_conditionings or [])
         assert len(vs) == len(self.v_conditioning_dims), "len(v_conditionings) != len(v_conditioning_dims)"
         for k, v in enumerate(vs):
-            conds.append(self._mlp2(f"v_embeds.{k}", v.to(torch.float32)))
+            conds.append(self._mlp2(f"v_embeds.{k}", v.to(torch.float32), head))
         return conds
 
-    def cond_table(self, conds, batch):
+    def cond_table(self, conds, batch, head=None):
         """[B, sum cout]: sum_k cond_k @ W_k^T for every block (D4, additive injection)."""
         table = None
         for k, c in enumerate(conds):
-            part = F.linear(c, self.cond_matrix(k))
+            part = F.linear(c, self.cond_matrix(k, head))
             table = part if table is None else table + part
         if table is None:
             table = torch.zeros(batch, self.table_width, device=self.flat.device)
@@ -241,8 +246,9 @@ class CUNet(nn.Module):
             t = torch.as_tensor(t, dtype=torch.float32, device=x.device).reshape(-1)
             if t.numel() == 1 and B > 1:
                 t = t.expand(B)
-        conds = self.cond_vectors(t, v_conditionings)
-        table = self.cond_table(conds, B)
+        head = self.flat[:self.head_end]
+        conds = self.cond_vectors(t, v_conditionings, head)
+        table = self.cond_table(conds, B, head)
         if self.backend == "torch":
             return self._forward_torch(x, s_conditioning, table)
         if self.dim != 3 or self.in_channels != 1 or self.s_conditioning_channels > 1:
