@@ -255,3 +255,32 @@ def test_sampler_identity_T2_and_api():
         assert out.shape == (1, 1, 16, 16, 16) and out.device.type == "cuda" and torch.isfinite(out).all()
         out_all = vdm.draw_samples(batch_size=1, n_sampling_steps=3, return_all=True, **kw)
         assert out_all.shape == (3, 1, 1, 16, 16, 16)
+
+
+def test_packed_weights_follow_the_optimizer():
+    """Regression: torch's fused AdamW updates the flat parameter vector WITHOUT bumping Tensor._version; the MFMA-packed weight
+    copies must be rebuilt anyway.  After each optimizer step the eval forward has to equal the oracle run on the updated
+    parameters, for the hook-installing configure_optimizers() and for a user-built fused optimizer alike."""
+    from vdm4cdm_amd import vdm_model
+    for own_optimizer in (False, True):
+        net = make_net(D=16, chs=(16, 32), precision="fp32", seed=7).to(DEV)
+        vdm = vdm_model.LightVDM(score_model=net, gamma_max=13.3, learning_rate=1e-2).to(DEV)
+        opt = torch.optim.AdamW(vdm.parameters(), lr=1e-2, fused=True) if own_optimizer else vdm.configure_optimizers()
+        x, t, sc, v = inputs(net, 2, seed=11)
+        batch = {"x": x.to(DEV), "conditioning": sc.to(DEV), "conditioning_values": [a.to(DEV) for a in v]}
+        for step in range(3):
+            vdm.train()
+            loss = vdm.training_step(batch, 0)
+            opt.zero_grad(set_to_none=True)
+            loss.backward()
+            before = net.flat.detach().clone()
+            version = net.flat._version
+            opt.step()
+            assert (net.flat.detach() - before).abs().max().item() > 0
+            vdm.eval()
+            with torch.no_grad():
+                out = hip_forward(net, x, t, sc, v)
+            ref = oracle_forward(net, x, t, sc, v)
+            err = (out.cpu() - ref).abs().max().item()
+            assert err <= 2e-4 * max(ref.abs().max().item(), 1e-3) + 1e-5, \
+                f"own_optimizer={own_optimizer} step {step} (flat._version {version} -> {net.flat._version}): stale packed weights? err {err}"

@@ -82,6 +82,7 @@ class CUNet(nn.Module):
         self.flat = nn.Parameter(torch.zeros(self.spec.total, dtype=torch.float32))
         self.reset_parameters()
         self._exec = None
+        self.weights_epoch = 0            # see mark_weights_dirty()
 
     # ------------------------------------------------------------------ structure
     def _block_list(self):
@@ -172,6 +173,11 @@ class CUNet(nn.Module):
         off, shape, _, _ = self.spec.items[name]
         f = self.flat if flat is None else flat
         return f[off:off + math.prod(shape)].view(shape)
+
+    def mark_weights_dirty(self):
+        """Tell the HIP executor that the parameters changed through an op that does not bump Tensor._version (fused optimizers):
+        the MFMA-packed weight copies are rebuilt at the next forward."""
+        self.weights_epoch += 1
 
     def cond_matrix(self, k, flat=None):
         """[sum cout, dim_k] projection matrix of conditioning k for all blocks at once.  `flat` may be the flat vector or its head

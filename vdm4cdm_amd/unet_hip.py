@@ -169,10 +169,13 @@ class HipUNet:
 
     def pack_weights(self, flat, dtype, need_dgrad):
         """Re-pack master fp32 weights into MFMA fragment order when the parameters changed."""
-        key = (flat.data_ptr(), flat._version, dtype, bool(need_dgrad))
+        # flat._version alone is NOT enough: fused optimizers (torch._fused_adamw_) update the parameters without bumping the
+        # version counter.  net.weights_epoch is bumped by every backward pass of this executor (an optimizer step follows) and by
+        # CUNet.mark_weights_dirty() (the optimizer post-step hook LightVDM.configure_optimizers installs).
+        key = (flat.data_ptr(), flat._version, self.net.weights_epoch, dtype, bool(need_dgrad))
         if self._packed_key == key:
             return
-        if self._packed_key is not None and self._packed_key[:3] == key[:3] and not need_dgrad:
+        if self._packed_key is not None and self._packed_key[:4] == key[:4] and not need_dgrad:
             return                                   # fwd buffers already current
         for conv, name in self._all_convs():
             conv.pack(self.net.view(name, flat), dtype, need_dgrad)
@@ -252,6 +255,7 @@ class HipUNet:
         ss.join()
         # conv1 biases: column sums of the conditioning-table gradient (same additive broadcast)
         net.conv1_bias_all(gflat).copy_(dtable.sum(0))
+        self.net.weights_epoch += 1                  # the caller is about to change the parameters: re-pack at the next forward
         return gflat, dtable
 
 

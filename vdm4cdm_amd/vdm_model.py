@@ -334,7 +334,11 @@ class LightVDM(nn.Module):
 
     def configure_optimizers(self):
         fused = all(p.is_cuda for p in self.parameters())                       # one fused kernel over the flat vector
-        return torch.optim.AdamW(self.parameters(), lr=self.learning_rate, fused=fused)      # D11
+        opt = torch.optim.AdamW(self.parameters(), lr=self.learning_rate, fused=fused)       # D11
+        sm = self.model.score_model
+        if hasattr(sm, "mark_weights_dirty"):      # fused steps do not bump Tensor._version: tell the HIP executor to re-pack
+            opt.register_step_post_hook(lambda *_: sm.mark_weights_dirty())
+        return opt
 
     def draw_samples(self, batch_size, n_sampling_steps=250, verbose=False, return_all=False, **kwargs):
         return self.model.sample(batch_size=batch_size, n_sampling_steps=n_sampling_steps, device=self.device,
