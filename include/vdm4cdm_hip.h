@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define VDM_ABI_VERSION 2
+#define VDM_ABI_VERSION 3
 
 typedef enum { VDM_OK = 0, VDM_ERR_ARG = -1, VDM_ERR_HIP = -2, VDM_ERR_UNSUPPORTED = -3 } vdm_status;
 typedef enum { VDM_F32 = 0, VDM_BF16 = 1 } vdm_dtype;
@@ -62,6 +62,24 @@ int vdm_device_info(int device, int* cu_count, int* lds_bytes, char* arch_name);
  * MFMA fragment order once per optimiser step. */
 size_t vdm_conv_packed_bytes(const vdm_conv_desc* d, int pack_mode);
 int vdm_conv_pack_weights(const vdm_conv_desc* d, int pack_mode, const float* w_master, void* w_packed, void* stream);
+/* All packings of a network in one launch (they are redone after every optimiser step).  vdm_conv_pack_plan fills one work item
+ * per (conv, form) on the host; the caller cuts [0, item.elems) of every item into chunks of <= VDM_PACK_CHUNK elements, uploads the
+ * item and chunk arrays once, and calls vdm_conv_pack_many on them whenever the master weights changed.  All items of one call
+ * share the dtype. */
+#define VDM_PACK_CHUNK 16384
+typedef struct vdm_pack_item {
+    const float* w_master;
+    void* w_packed;
+    int32_t taps, cout, cin, nc, nchunks, nkb, dgrad, variant, cls_kind, dtype;
+    int64_t elems; /* packed elements of this item */
+} vdm_pack_item;
+typedef struct vdm_pack_chunk {
+    int32_t item;  /* index into the item array */
+    int32_t count; /* elements in this chunk */
+    int64_t first; /* first packed element (inside the item) */
+} vdm_pack_chunk;
+int vdm_conv_pack_plan(const vdm_conv_desc* d, int pack_mode, const float* w_master, void* w_packed, vdm_pack_item* item);
+int vdm_conv_pack_many(const vdm_pack_item* items_device, const vdm_pack_chunk* chunks_device, int nchunks, int dtype, void* stream);
 /* out = conv(x, w) + bias[c] + nbias[n*nbias_stride + c] + residual   (bias, nbias, residual may be NULL).
  * nbias is the per-sample conditioning bias table (sum_k Linear_k(cond_k)); nbias_stride is the
  * element distance between samples (the table of all blocks is one [n][sum cout] matrix). */

@@ -449,3 +449,31 @@ def test_philox_normals():
     step = torch.zeros(1, dtype=torch.int32, device=DEV)
     ops.ancestral_step(z, torch.zeros(n, device=DEV), None, coefs, step, 7)
     assert abs(z.std().item() - 2.0) < 0.01
+
+
+@pytest.mark.parametrize("dtype", DTYPES, ids=["f32", "bf16"])
+def test_pack_many_equals_per_conv_packing(dtype):
+    """The one-launch packing of a whole network (vdm_conv_pack_many) writes the same bytes as vdm_conv_pack_weights conv by conv,
+    for every weight layout: generic (fwd / flipped-transposed dgrad), per-parity-class (up-sampling conv, stride-2 dgrad), tap-packed."""
+    ops = _ops()
+    shapes = [(32, 32, 3, 1, 0), (64, 32, 3, 1, 0), (48, 96, 3, 1, 0), (2, 32, 3, 1, 0), (32, 1, 3, 1, 0), (32, 32, 3, 2, 0),
+              (64, 32, 3, 1, 1), (64, 32, 1, 1, 0), (128, 256, 3, 1, 0)]
+    flat = torch.randn(sum(ks ** 3 * co * ci for ci, co, ks, _, _ in shapes), device=DEV)
+    convs, ref, off = [], [], 0
+    for ci, co, ks, st, up in shapes:
+        n = ks ** 3 * co * ci
+        w = flat[off:off + n].view(ks ** 3, co, ci)
+        off += n
+        a = ops.Conv(ci, co, ks, stride=st, upsample=up)
+        b = ops.Conv(ci, co, ks, stride=st, upsample=up)
+        b.pack(w, dtype, need_dgrad=True)
+        convs.append((a, w))
+        ref.append(b)
+    plan = ops.PackPlan(convs, dtype, need_dgrad=True)
+    for a, _ in convs:
+        a.wf.fill_(0xAB)
+        a.wd.fill_(0xAB)
+    plan.run()
+    for (a, _), b, shp in zip(convs, ref, shapes):
+        assert torch.equal(a.wf, b.wf), f"fwd packing differs for {shp}"
+        assert torch.equal(a.wd, b.wd), f"dgrad packing differs for {shp}"

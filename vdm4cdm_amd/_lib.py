@@ -24,9 +24,22 @@ class ConvDesc(C.Structure):
                 ("n", "od", "oh", "ow", "cin", "cout", "ksize", "stride", "upsample", "pad_mode", "dtype", "out_f32")]
 
 
+class PackItem(C.Structure):
+    """vdm_pack_item"""
+    _fields_ = [("w_master", C.c_void_p), ("w_packed", C.c_void_p)] + \
+               [(k, C.c_int32) for k in ("taps", "cout", "cin", "nc", "nchunks", "nkb", "dgrad", "variant", "cls_kind", "dtype")] + \
+               [("elems", C.c_int64)]
+
+
+class PackChunk(C.Structure):
+    """vdm_pack_chunk"""
+    _fields_ = [("item", C.c_int32), ("count", C.c_int32), ("first", C.c_int64)]
+
+
+PACK_CHUNK = 16384                   # VDM_PACK_CHUNK
 _p, _i, _i64, _u64, _f, _sz = C.c_void_p, C.c_int, C.c_int64, C.c_uint64, C.c_float, C.c_size_t
 _D = C.POINTER(ConvDesc)
-ABI_VERSION = 2                      # VDM_ABI_VERSION of include/vdm4cdm_hip.h this binding was written for
+ABI_VERSION = 3                      # VDM_ABI_VERSION of include/vdm4cdm_hip.h this binding was written for
 
 # name -> (restype, argtypes); mirrors include/vdm4cdm_hip.h one to one
 SIGNATURES = {
@@ -35,6 +48,8 @@ SIGNATURES = {
     "vdm_device_info": (_i, [_i, C.POINTER(_i), C.POINTER(_i), C.c_char_p]),
     "vdm_conv_packed_bytes": (_sz, [_D, _i]),
     "vdm_conv_pack_weights": (_i, [_D, _i, _p, _p, _p]),
+    "vdm_conv_pack_plan": (_i, [_D, _i, _p, _p, C.POINTER(PackItem)]),
+    "vdm_conv_pack_many": (_i, [_p, _p, _i, _i, _p]),
     "vdm_conv_gn_tiles": (_i, [_D]),
     "vdm_conv_fwd": (_i, [_D, _p, _p, _p, _p, _i64, _p, _p, _p, _p]),
     "vdm_conv_dgrad": (_i, [_D, _p, _p, _p, _p, _p]),

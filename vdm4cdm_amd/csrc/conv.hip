@@ -1656,6 +1656,103 @@ static void fwd_args(ConvArgs& a, const vdm_conv_desc* d) {
     a.nchunks = p.nchunks; a.nkb = p.nkb;
 }
 
+// ---- all weight packings of a network in ONE launch ---------------------------------------------------------------------
+// The packed copies of every conv (forward and dgrad form) are rebuilt after each optimiser step: ~120 launches of a few
+// microseconds each when done conv by conv.  vdm_conv_pack_plan() fills one work item per (conv, form) on the host; the caller
+// concatenates them, cuts the concatenated element range into chunks of VDM_PACK_CHUNK elements that do not straddle items, uploads
+// both tables once and calls vdm_conv_pack_many() per step.
+__device__ ClsMasks g_cls_masks[3];
+
+template <typename T>
+__device__ __forceinline__ float pack_value(const vdm_pack_item& it, const float* __restrict__ w, size_t i) {
+    constexpr int EPL = DT<T>::EPL, KB = DT<T>::KB;
+    const int dgrad = it.dgrad, cout_m = it.cout, cin_m = it.cin, nc = it.nc;
+    const int O = dgrad ? cin_m : cout_m, K = dgrad ? cout_m : cin_m;
+    size_t r = i;
+    const int j = r % EPL; r /= EPL;
+    const int lane = r % 64; r /= 64;
+    const int ct = r % nc; r /= nc;
+    const int m = lane & 15, q = lane >> 4;
+    if (it.variant == VDM_CONV_VARIANT_KPACK) {
+        const int g = r % 7; r /= 7;
+        const int chunk = (int)r;
+        const int o = chunk * nc * 16 + nc * 4 * (m >> 2) + 4 * ct + (m & 3);
+        const int tap = 4 * g + q;
+        if (!(o < O && j < K && tap < 27)) return 0.f;
+        return dgrad ? w[((size_t)(26 - tap) * cout_m + j) * cin_m + o] : w[((size_t)tap * cout_m + o) * cin_m + j];
+    }
+    if (it.variant == VDM_CONV_VARIANT_CLASS) {
+        const int slot = r % 64; r /= 64;
+        const int kb = r % it.nkb; r /= it.nkb;
+        const int chunk = (int)r;
+        const int o = chunk * nc * 16 + nc * 4 * (m >> 2) + 4 * ct + (m & 3);
+        const int k = kb * KB + q * EPL + j;
+        float v = 0.f;
+        if (o < O && k < K) {
+            const unsigned mask = g_cls_masks[it.cls_kind].m[slot];
+            for (int t = 0; t < 27; ++t)
+                if ((mask >> t) & 1u) v += dgrad ? w[((size_t)t * cout_m + k) * cin_m + o] : w[((size_t)t * cout_m + o) * cin_m + k];
+        }
+        return v;
+    }
+    const int taps = it.taps;
+    const int tap = r % taps; r /= taps;
+    const int kb = r % it.nkb; r /= it.nkb;
+    const int chunk = (int)r;
+    const int o = chunk * nc * 16 + nc * 4 * (m >> 2) + 4 * ct + (m & 3);
+    const int k = kb * KB + q * EPL + j;
+    if (!(o < O && k < K)) return 0.f;
+    return dgrad ? w[((size_t)(taps - 1 - tap) * cout_m + k) * cin_m + o] : w[((size_t)tap * cout_m + o) * cin_m + k];
+}
+
+template <typename T>
+__global__ void __launch_bounds__(256) pack_many_kernel(const vdm_pack_item* __restrict__ items, const vdm_pack_chunk* __restrict__ chunks) {
+    const vdm_pack_chunk c = chunks[blockIdx.x];
+    const vdm_pack_item it = items[c.item];
+    const float* w = it.w_master;
+    T* out = reinterpret_cast<T*>(it.w_packed);
+    const long long end = c.first + c.count;
+    for (long long i = c.first + threadIdx.x; i < end; i += 256) st_elem<T>(out + i, pack_value<T>(it, w, (size_t)i));
+}
+
+extern "C" int vdm_conv_pack_plan(const vdm_conv_desc* d, int pack_mode, const float* w_master, void* w_packed, vdm_pack_item* item) {
+    int e = validate(d);
+    if (e) return e;
+    VDM_REQUIRE(item && w_master && w_packed, "conv_pack_plan: NULL pointer");
+    VDM_REQUIRE(pack_mode == VDM_PACK_FWD || pack_mode == VDM_PACK_DGRAD, "conv_pack_plan: bad mode %d", pack_mode);
+    const int dg = pack_mode == VDM_PACK_DGRAD;
+    const Plan p = plan_of(d, dg);
+    item->w_master = w_master; item->w_packed = w_packed;
+    item->taps = p.taps; item->cout = d->cout; item->cin = d->cin; item->nc = p.nc; item->nchunks = p.nchunks; item->nkb = p.nkb;
+    item->dgrad = dg;
+    item->variant = uses_cls(d, dg) ? VDM_CONV_VARIANT_CLASS : (uses_kpack(d, dg) ? VDM_CONV_VARIANT_KPACK : VDM_CONV_VARIANT_GENERIC);
+    item->cls_kind = item->variant == VDM_CONV_VARIANT_CLASS ? cls_kind(d, dg) : 0;
+    item->dtype = d->dtype;
+    item->elems = (long long)(vdm_conv_packed_bytes(d, pack_mode) / (d->dtype == VDM_F32 ? 4 : 2));
+    return VDM_OK;
+}
+
+extern "C" int vdm_conv_pack_many(const vdm_pack_item* items_dev, const vdm_pack_chunk* chunks_dev, int nchunks, int dtype, void* stream) {
+    VDM_REQUIRE(items_dev && chunks_dev && nchunks > 0, "conv_pack_many: empty work list");
+    VDM_REQUIRE(dtype == VDM_F32 || dtype == VDM_BF16, "conv_pack_many: bad dtype %d", dtype);
+    static bool masks_up = false;
+    if (!masks_up) {
+        ClsMasks h[3];
+        ClsTable tab;
+        for (int k = 0; k < 3; ++k) build_cls(k, tab, h[k]);
+        int e = check_hip(hipMemcpyToSymbol(HIP_SYMBOL(g_cls_masks), h, sizeof(h)), "hipMemcpyToSymbol(g_cls_masks)");
+        if (e) return e;
+        masks_up = true;
+    }
+    hipStream_t s = (hipStream_t)stream;
+    if (dtype == VDM_F32)
+        hipLaunchKernelGGL(pack_many_kernel<float>, dim3(nchunks), dim3(256), 0, s, items_dev, chunks_dev);
+    else
+        hipLaunchKernelGGL(pack_many_kernel<bf16_t>, dim3(nchunks), dim3(256), 0, s, items_dev, chunks_dev);
+    VDM_LAUNCH_CHECK("pack_many_kernel");
+    return VDM_OK;
+}
+
 extern "C" int vdm_conv_gn_tiles(const vdm_conv_desc* d) {
     if (validate(d) != VDM_OK || uses_cls(d, 0)) return 0;
     ConvArgs a{};

@@ -139,6 +139,17 @@ class Conv:
                 self.wd = torch.empty(L.vdm_conv_packed_bytes(d, PACK_DGRAD), dtype=torch.uint8, device=w_master.device)
             check(L.vdm_conv_pack_weights(d, PACK_DGRAD, _p(w_master), _p(self.wd), _s()), "vdm_conv_pack_weights(dgrad)")
 
+    def alloc_packed(self, device, dtype, need_dgrad):
+        """Make sure the packed-weight buffers exist (pack_many fills them)."""
+        L = _lib.lib()
+        d = self.desc(1, 2, 2, 2, dtype)
+        if self.wf is None or self.wf.device != device or self._packed_dtype != dtype:
+            self.wf = torch.empty(L.vdm_conv_packed_bytes(d, PACK_FWD), dtype=torch.uint8, device=device)
+            self.wd = None
+            self._packed_dtype = dtype
+        if need_dgrad and self.wd is None:
+            self.wd = torch.empty(L.vdm_conv_packed_bytes(d, PACK_DGRAD), dtype=torch.uint8, device=device)
+
     def out_shape(self, x):
         n, d, h, w, _ = x.shape
         if self.stride == 2:
@@ -393,3 +404,36 @@ def sumsq(x, out):
     assert x.dtype == torch.float32 and out.dtype == torch.float32
     check(L.vdm_sumsq(_p(x), x.numel(), _p(out), _s()), "vdm_sumsq")
     return out
+
+
+class PackPlan:
+    """All (conv, form) weight packings of a network as one launch (vdm_conv_pack_many): the item and chunk tables are built
+    once per (parameter storage, dtype, forms) and live on the device."""
+
+    def __init__(self, convs_and_masters, dtype, need_dgrad):
+        """convs_and_masters: [(Conv, fp32 master view [taps, cout, cin] inside the flat parameter vector)]."""
+        import numpy as np
+        L = _lib.lib()
+        device = convs_and_masters[0][1].device
+        items = []
+        for conv, w in convs_and_masters:
+            assert w.dtype == torch.float32 and w.is_contiguous() and w.numel() == conv.ksize ** 3 * conv.cout * conv.cin
+            conv.alloc_packed(device, dtype, need_dgrad)
+            d = conv.desc(1, 2, 2, 2, dtype)
+            for mode, buf in ((PACK_FWD, conv.wf),) + (((PACK_DGRAD, conv.wd),) if need_dgrad else ()):
+                it = _lib.PackItem()
+                check(L.vdm_conv_pack_plan(d, mode, _p(w), _p(buf), C.byref(it)), "vdm_conv_pack_plan")
+                items.append(it)
+        chunks = []
+        for i, it in enumerate(items):
+            for first in range(0, it.elems, _lib.PACK_CHUNK):
+                chunks.append((i, min(_lib.PACK_CHUNK, it.elems - first), first))
+        item_arr = (_lib.PackItem * len(items))(*items)
+        chunk_arr = (_lib.PackChunk * len(chunks))(*[_lib.PackChunk(*c) for c in chunks])
+        self.items = torch.from_numpy(np.frombuffer(bytes(item_arr), dtype=np.uint8).copy()).to(device)
+        self.chunks = torch.from_numpy(np.frombuffer(bytes(chunk_arr), dtype=np.uint8).copy()).to(device)
+        self.nchunks = len(chunks)
+        self.dtype = dtype
+
+    def run(self):
+        check(_lib.lib().vdm_conv_pack_many(_p(self.items), _p(self.chunks), self.nchunks, dt_id(self.dtype), _s()), "vdm_conv_pack_many")

@@ -154,6 +154,7 @@ class HipUNet:
         self.up = [Conv(chs[i + 1], chs[i], 3, upsample=1, circular=circ) for i in range(L - 1)]
         self.res = {b.name: _Res(net, b) for b in net.blocks}
         self._packed_key = None
+        self._pack_plan = None
         self.saved = None
         self._ss = None
 
@@ -177,8 +178,10 @@ class HipUNet:
             return
         if self._packed_key is not None and self._packed_key[:4] == key[:4] and not need_dgrad:
             return                                   # fwd buffers already current
-        for conv, name in self._all_convs():
-            conv.pack(self.net.view(name, flat), dtype, need_dgrad)
+        pkey = (flat.data_ptr(), dtype, bool(need_dgrad))
+        if self._pack_plan is None or self._pack_plan[0] != pkey:         # one launch for all ~120 (conv, form) packings
+            self._pack_plan = (pkey, ops.PackPlan([(conv, self.net.view(name, flat)) for conv, name in self._all_convs()], dtype, need_dgrad))
+        self._pack_plan[1].run()
         self._packed_key = key
 
     def _side_stream(self, device):
