@@ -1663,14 +1663,12 @@ static void fwd_args(ConvArgs& a, const vdm_conv_desc* d) {
 // both tables once and calls vdm_conv_pack_many() per step.
 __device__ ClsMasks g_cls_masks[3];
 
+// value of packed element (row r = everything above the [lane][EPL] fragment, lane, j)
 template <typename T>
-__device__ __forceinline__ float pack_value(const vdm_pack_item& it, const float* __restrict__ w, size_t i) {
+__device__ __forceinline__ float pack_value(const vdm_pack_item& it, const float* __restrict__ w, size_t r, int lane, int j) {
     constexpr int EPL = DT<T>::EPL, KB = DT<T>::KB;
     const int dgrad = it.dgrad, cout_m = it.cout, cin_m = it.cin, nc = it.nc;
     const int O = dgrad ? cin_m : cout_m, K = dgrad ? cout_m : cin_m;
-    size_t r = i;
-    const int j = r % EPL; r /= EPL;
-    const int lane = r % 64; r /= 64;
     const int ct = r % nc; r /= nc;
     const int m = lane & 15, q = lane >> 4;
     if (it.variant == VDM_CONV_VARIANT_KPACK) {
@@ -1705,14 +1703,24 @@ __device__ __forceinline__ float pack_value(const vdm_pack_item& it, const float
     return dgrad ? w[((size_t)(taps - 1 - tap) * cout_m + k) * cin_m + o] : w[((size_t)tap * cout_m + o) * cin_m + k];
 }
 
+// one block = one chunk (a whole number of [64 lanes][EPL] fragments): the slow coordinates (cout tile, tap, K-block, chunk) are
+// block-uniform per fragment, only (lane, j) vary over the threads
 template <typename T>
 __global__ void __launch_bounds__(256) pack_many_kernel(const vdm_pack_item* __restrict__ items, const vdm_pack_chunk* __restrict__ chunks) {
+    constexpr int EPL = DT<T>::EPL, FRAG = 64 * EPL;
     const vdm_pack_chunk c = chunks[blockIdx.x];
     const vdm_pack_item it = items[c.item];
     const float* w = it.w_master;
     T* out = reinterpret_cast<T*>(it.w_packed);
-    const long long end = c.first + c.count;
-    for (long long i = c.first + threadIdx.x; i < end; i += 256) st_elem<T>(out + i, pack_value<T>(it, w, (size_t)i));
+    const int j = threadIdx.x % EPL;
+    for (long long f = c.first; f < c.first + c.count; f += FRAG) {          // (first and count are multiples of FRAG)
+        const size_t r = (size_t)(f / FRAG);
+#pragma unroll
+        for (int u = 0; u < FRAG / 256; ++u) {
+            const int e = threadIdx.x + u * 256;
+            st_elem<T>(out + f + e, pack_value<T>(it, w, r, e / EPL, j));
+        }
+    }
 }
 
 extern "C" int vdm_conv_pack_plan(const vdm_conv_desc* d, int pack_mode, const float* w_master, void* w_packed, vdm_pack_item* item) {
