@@ -292,14 +292,20 @@ class LightVDM(nn.Module):
         self.model = VDM(score_model, noise_schedule=noise_schedule, gamma_min=gamma_min, gamma_max=gamma_max, **vdm_kwargs)
         self.draw_figure = draw_figure
         self.learning_rate = learning_rate
-        self.logged = {}
+        self._logged = {}
 
     @property
     def device(self):
         return self.model.score_model.flat.device
 
     def log_dict(self, d):
-        self.logged.update({k: float(v) for k, v in d.items()})
+        """Keeps the latest value per key WITHOUT reading it back (a float() here would synchronise host and GPU in every step);
+        `logged` converts on access, i.e. when a logger actually wants the numbers."""
+        self._logged.update({k: (v.detach() if torch.is_tensor(v) else v) for k, v in d.items()})
+
+    @property
+    def logged(self):
+        return {k: float(v) for k, v in self._logged.items()}
 
     @staticmethod
     def _unpack(batch):
