@@ -72,3 +72,29 @@ def test_sample_power_spectrum_matches_oracle(precision, tol):
     _, pk_ref, _ = utils.pk(ref)
     ratio = (pk_hip / pk_ref).numpy()
     assert np.abs(ratio - 1).max() < tol, f"P(k) ratio off by {np.abs(ratio - 1).max():.3e} ({precision})"
+
+
+def test_ddnm_sampler_hip_vs_torch_backend():
+    """Next row 1 of SURVEY 8f: get_ddnm_result (reference src/utils.py:277-304) on the HIP backend gives the same inpainting as the
+    same loop on this package's explicit torch backend (same weights, same torch.randn stream on the same device)."""
+    import torch
+    from helpers import randomize
+    from vdm4cdm_amd import utils
+    from vdm4cdm_amd.networks import CUNet
+    from vdm4cdm_amd.vdm_model import LightVDM
+    dev = "cuda:0"
+    outs = []
+    for backend in ("torch", "hip"):
+        net = CUNet(shape=(1, 16, 16, 16), chs=[16, 32], s_conditioning_channels=0, v_conditioning_dims=[], norm_groups=8,
+                    backend=backend, precision="fp32")
+        vdm = LightVDM(score_model=randomize(net, 4, zero_init_std=0.02), gamma_max=13.3).to(dev).eval()
+        g = torch.Generator().manual_seed(9)
+        mask = torch.zeros(2, 1, 16, 16, 16)
+        mask[..., :8] = 1
+        mask = mask.to(dev)
+        y = torch.randn(2, 1, 16, 16, 16, generator=g).to(dev) * mask
+        torch.manual_seed(123)
+        outs.append(utils.get_ddnm_result(vdm, y, A=lambda x: x * mask, AT=lambda x: x * mask, n_sampling_steps=6, l=2))
+        assert torch.allclose(outs[-1] * mask, y, atol=1e-5)
+    err = (outs[0] - outs[1]).abs().max().item()
+    assert err <= 2e-3 * outs[0].abs().max().item() + 1e-4, f"DDNM on HIP differs from the torch backend: {err}"
