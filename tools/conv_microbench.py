@@ -33,12 +33,16 @@ def main():
     ap.add_argument("--only", default="")
     ap.add_argument("--iters", type=int, default=20)
     ap.add_argument("--ops", default="fwd,dgrad,wgrad")
+    ap.add_argument("--n", type=int, default=0, help="override the batch size of every shape (1 = the sampler's shapes)")
+    ap.add_argument("--graph", action="store_true", help="time a hipGraph replay of the launches (small kernels are host-bound otherwise)")
     args = ap.parse_args()
     dt = torch.bfloat16 if args.dtype == "bf16" else torch.float32
     dev = "cuda:0"
     for name, N, D, cin, cout, ks, stride, ups in SHAPES:
         if args.only and args.only not in name:
             continue
+        if args.n:
+            N = args.n
         conv = ops.Conv(cin, cout, ks, stride=stride, upsample=ups)
         w = torch.randn(ks ** 3, cout, cin, device=dev) * 0.05
         conv.pack(w, dt, need_dgrad=True)
@@ -55,11 +59,28 @@ def main():
             for _ in range(3):
                 fn()
             torch.cuda.synchronize()
-            t0 = time.perf_counter()
-            for _ in range(args.iters):
-                fn()
-            torch.cuda.synchronize()
-            dtm = (time.perf_counter() - t0) / args.iters
+            if args.graph:                                  # replay a captured graph: device time without the Python launch cost
+                side = torch.cuda.Stream()
+                side.wait_stream(torch.cuda.current_stream())
+                with torch.cuda.stream(side):
+                    fn()
+                torch.cuda.current_stream().wait_stream(side)
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g):
+                    for _ in range(args.iters):
+                        fn()
+                g.replay()
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                g.replay()
+                torch.cuda.synchronize()
+                dtm = (time.perf_counter() - t0) / args.iters
+            else:
+                t0 = time.perf_counter()
+                for _ in range(args.iters):
+                    fn()
+                torch.cuda.synchronize()
+                dtm = (time.perf_counter() - t0) / args.iters
             res.append(f"{op} {dtm * 1e3:7.3f} ms {flops / dtm / 1e12:7.1f} TF/s")
         print(f"{name:16s} " + " | ".join(res), flush=True)
 

@@ -1318,14 +1318,30 @@ static int cu_count() {
     return n;
 }
 
+// Spatial tile of the bf16 3x3x3 stride-1 kernel.  Large grids: 4x8x16 (least halo traffic).  Small grids (deep UNet levels, and
+// everything at batch 1): smaller tiles so that more workgroups exist - a workgroup runs its K-blocks strictly one after the other
+// (stage, barrier, 27 taps), so a deep-level conv is bound by that serial chain unless co-resident workgroups overlap it:
+// 2x8x16 (46 KB LDS, 3 per CU) below 2 workgroups per CU, 1x8x16 / 1x4x16 when even those leave CUs empty.
+static void small_grid_tile(const ConvArgs& a, int& tz, int& ty) {
+    const long long per_sample = (long long)a.nchunks * a.N * cdiv(a.Dx, 16);
+    const long long tiles48 = per_sample * cdiv(a.Dz, 4) * cdiv(a.Dy, 8), tiles28 = per_sample * cdiv(a.Dz, 2) * cdiv(a.Dy, 8);
+    tz = 4; ty = 8;
+    if (tiles48 >= 2LL * cu_count()) return;
+    tz = 2;
+    if (tiles28 >= cu_count()) return;
+    tz = 1;
+    if (2 * tiles28 < cu_count()) ty = 4;
+}
+
 template <typename T, typename TO, int KS, int STRIDE, int UPS, int NC>
 static int launch_fwd_geo(const ConvArgs& a, hipStream_t s) {
     if constexpr (STRIDE == 2)
         return launch_fwd_cfg<T, TO, KS, STRIDE, UPS, NC, 2, 4>(a, s);
     else if constexpr (KS == 3 && sizeof(T) == 2) {
-        // small grids (deep UNet levels): 2x8x16 tiles (46 KB LDS, 3 workgroups / CU) fill the chip better
-        const long long tiles48 = (long long)a.nchunks * a.N * cdiv(a.Dz, 4) * cdiv(a.Dy, 8) * cdiv(a.Dx, 16);
-        if (tiles48 < 2LL * cu_count()) return launch_fwd_cfg<T, TO, KS, STRIDE, UPS, NC, 2, 8>(a, s);
+        int tz, ty;
+        small_grid_tile(a, tz, ty);
+        if (tz == 1) return ty == 4 ? launch_fwd_cfg<T, TO, KS, STRIDE, UPS, NC, 1, 4>(a, s) : launch_fwd_cfg<T, TO, KS, STRIDE, UPS, NC, 1, 8>(a, s);
+        if (tz == 2) return launch_fwd_cfg<T, TO, KS, STRIDE, UPS, NC, 2, 8>(a, s);
         return launch_fwd_cfg<T, TO, KS, STRIDE, UPS, NC, 4, 8>(a, s);
     } else
         return launch_fwd_cfg<T, TO, KS, STRIDE, UPS, NC, 4, 8>(a, s);
@@ -1593,10 +1609,7 @@ static void fwd_tile_shape(const ConvArgs& a, int dtype, int out_f32, int ks, in
     tz = 4; ty = 8;
     if (stride == 2) { tz = 2; ty = 4; return; }
     if (uses_kpack(dtype, ks, stride, ups, a.Cin, a.Cout, out_f32)) return;
-    if (ks == 3 && dtype == VDM_BF16) {
-        const long long tiles48 = (long long)a.nchunks * a.N * cdiv(a.Dz, 4) * cdiv(a.Dy, 8) * cdiv(a.Dx, 16);
-        if (tiles48 < 2LL * cu_count()) tz = 2;
-    }
+    if (ks == 3 && dtype == VDM_BF16) small_grid_tile(a, tz, ty);
 }
 
 }  // namespace vdm
