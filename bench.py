@@ -103,6 +103,7 @@ def main():
     ap.add_argument("--all-kernel-events", action="store_true",
                     help="HIP events around EVERY kernel launch (full per-kernel table; ~600 event pairs per step cost ~6 %% of the step)."
                          " Default: only the 3^3 conv fwd/dgrad launches, the candidates for the dominant kernel (~50 per step)")
+    ap.add_argument("--per-step", action="store_true", help="diagnostic: synchronise after every timed step and print its duration to stderr")
     ap.add_argument("--sample-steps", type=int, default=0, help="also time an n-step reverse-diffusion sample (batch 1)")
     args = ap.parse_args()
 
@@ -138,6 +139,8 @@ def main():
         opt.step()
         return loss
 
+    for _ in range(2):          # setup, not warm-up: sizes the caching allocator's pools (main + side streams) and packs the weights once
+        step()
     for _ in range(args.warmup):
         step()
     prof = None
@@ -147,7 +150,11 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
+    per_step = []
     for i in range(args.steps):
+        if args.per_step:
+            torch.cuda.synchronize()
+            per_step.append(time.perf_counter())
         # per-launch events perturb the step (~3 % even for the conv launches alone): sample every 5th timed step unless asked for all
         hip_ops.PROFILER = prof if (args.all_kernel_events or i % 5 == 0) else None
         loss = step()
@@ -155,6 +162,9 @@ def main():
     if world > 1:
         dist.barrier()
     elapsed = time.perf_counter() - t0
+    if args.per_step and rank == 0:
+        per_step.append(time.perf_counter())
+        print("per-step ms:", " ".join(f"{1e3 * (b - a):.2f}" for a, b in zip(per_step, per_step[1:])), file=sys.stderr, flush=True)
     hip_ops.PROFILER = None
     el = torch.tensor([elapsed], device=device, dtype=torch.float64)
     if world > 1:

@@ -215,19 +215,19 @@ __device__ __forceinline__ void operand_lane_offsets(int (&lanex)[G::KS], int cw
 template <int NC> struct WPipe { static constexpr int WPD = (NC <= 2) ? 2 : 1; };   // weight prefetch depth (taps)
 
 // bf16: first WPD taps' weights (issued before the staging barrier so their latency overlaps it)
-template <int TAPS, int NC, int WPD>
+template <int TAPS, int NC, int WPD, int NCW = NC>
 __device__ __forceinline__ void taps_prefetch_weights(uint4 (&wf)[WPD + 1][NC], const uint4* wk) {
 #pragma unroll
     for (int p = 0; p < WPD && p < TAPS; ++p)
 #pragma unroll
-        for (int c = 0; c < NC; ++c) wf[p][c] = wk[(p * NC + c) * 64];
+        for (int c = 0; c < NC; ++c) wf[p][c] = wk[(p * NCW + c) * 64];
 }
 
 // bf16: explicit software pipeline over the fully unrolled taps.
 //   weights (global, L2-resident)  : WPD taps ahead, ring of WPD+1 register sets
 //   activations (LDS)              : one tap ahead, two register sets of NV fragments
 // sched_barrier(0) pins [issue next operands] | [MFMAs of this tap] so the loads stay early.
-template <typename T, typename G, int NC, int NV, int WPD>
+template <typename T, typename G, int NC, int NV, int WPD, int NCW = NC>
 __device__ __forceinline__ void taps_pipelined(f32x4 (&acc)[NV][NC], const char* lds, const uint4* wk,
                                                uint4 (&wf)[WPD + 1][NC], const int (&lanex)[G::KS]) {
     constexpr int TAPS = G::TAPS, KS = G::KS;
@@ -239,7 +239,7 @@ __device__ __forceinline__ void taps_pipelined(f32x4 (&acc)[NV][NC], const char*
     for (int tap = 0; tap < TAPS; ++tap) {
         if (tap + WPD < TAPS) {
 #pragma unroll
-            for (int c = 0; c < NC; ++c) wf[(tap + WPD) % (WPD + 1)][c] = wk[((tap + WPD) * NC + c) * 64];
+            for (int c = 0; c < NC; ++c) wf[(tap + WPD) % (WPD + 1)][c] = wk[((tap + WPD) * NCW + c) * 64];
         }
         if (tap + 1 < TAPS) {
             const int t1 = tap + 1;
@@ -320,7 +320,7 @@ __device__ __forceinline__ float row16_sum(float v) {
 
 template <int NC>
 __device__ __forceinline__ void gn_partials_reduce(float (&gs)[NC * 4], float (&gq)[NC * 4], float* sm, float* dst /* [Cout][2] of this tile */,
-                                                   int cout0, int Cout, int wave, int lane) {
+                                                   int cout0, int Cout, int wave, int lane, int qstride = NC * 4) {
     const int lx = lane & 15, q = lane >> 4;
 #pragma unroll
     for (int j = 0; j < NC * 4; ++j) {
@@ -337,7 +337,7 @@ __device__ __forceinline__ void gn_partials_reduce(float (&gs)[NC * 4], float (&
     __syncthreads();
     const int t = wave * 64 + lane;
     if (t < NC * 16 * 2) {
-        const int c = t >> 1;
+        const int c = ((t >> 1) / (NC * 4)) * qstride + (t >> 1) % (NC * 4);      // lane group q owns NC*4 channels every qstride
         const float tot = (sm[t] + sm[NC * 16 * 2 + t]) + (sm[2 * NC * 16 * 2 + t] + sm[3 * NC * 16 * 2 + t]);
         if (cout0 + c < Cout) dst[(size_t)(cout0 + c) * 2 + (t & 1)] = tot;
     }
@@ -346,13 +346,15 @@ __device__ __forceinline__ void gn_partials_reduce(float (&gs)[NC * 4], float (&
 // epilogue: + bias + per-sample conditioning bias + residual, cast, 16-byte NDHWC stores
 template <typename T, typename TO, typename G, int NC, int NV>
 __device__ __forceinline__ void conv_epilogue(const f32x4 (&acc)[NV][NC], const ConvArgs& a, int n, int chunk, int oz0, int oy0,
-                                              int ox0, int cwave, int lane, float* gn_sm = nullptr, int tile = 0) {
+                                              int ox0, int cwave, int lane, float* gn_sm = nullptr, int tile = 0, int cout0 = -1,
+                                              int qstride = NC * 4) {
     constexpr int EPL = DT<T>::EPL;
     float gs[NC * 4], gq[NC * 4];
 #pragma unroll
     for (int j = 0; j < NC * 4; ++j) gs[j] = gq[j] = 0.f;
     const int lx = lane & 15, q = lane >> 4;
-    const int cbase = chunk * NC * 16 + q * NC * 4;     // first of this lane's NC*4 consecutive couts
+    if (cout0 < 0) cout0 = chunk * NC * 16;             // (half-chunk kernels pass their own origin and lane-group stride)
+    const int cbase = cout0 + q * qstride;              // first of this lane's NC*4 consecutive couts
     float badd[NC * 4];
 #pragma unroll
     for (int j = 0; j < NC * 4; ++j) {
@@ -434,15 +436,20 @@ __device__ __forceinline__ void conv_epilogue(const f32x4 (&acc)[NV][NC], const 
         }
     }
     if (a.gnp)                                            // workgroup-uniform
-        gn_partials_reduce<NC>(gs, gq, gn_sm, a.gnp + ((size_t)n * (a.ntz * a.nty * a.ntx) + tile) * a.Cout * 2, chunk * NC * 16, a.Cout,
-                               cwave, lane);
+        gn_partials_reduce<NC>(gs, gq, gn_sm, a.gnp + ((size_t)n * (a.ntz * a.nty * a.ntx) + tile) * a.Cout * 2, cout0, a.Cout,
+                               cwave, lane, qstride);
 }
 
 // ---------------------------------------------------------------------------------------------
 // forward / dgrad kernel, one tile per workgroup (all variants; small grids)
 // ---------------------------------------------------------------------------------------------
-template <typename T, typename TO, int KS, int STRIDE, int UPS, int NC, int TZ, int TY>
+// SPLIT (NC == 2 only): the weights are packed for 64-cout chunks (4 tiles per tap) but a workgroup takes HALF a chunk (tiles 2h,
+// 2h+1 = couts 16q + 8h .. +7 of every lane group q): twice the workgroups for the small grids of the deep levels, where a
+// workgroup's K-blocks run strictly one after the other and only co-resident workgroups overlap staging with MFMAs.
+template <typename T, typename TO, int KS, int STRIDE, int UPS, int NC, int TZ, int TY, bool SPLIT = false>
 __global__ void __launch_bounds__(256, (TZ * TY <= 16 && NC <= 2) ? 3 : 2) conv_fwd_kernel(const ConvArgs a) {
+    static_assert(!SPLIT || NC == 2, "half-chunk mode is the NC=2 kernel on NC=4 weights");
+    constexpr int NCW = SPLIT ? 4 : NC;
     using G = Geo<KS, STRIDE, TZ, TY>;
     constexpr int NV = G::NV, TAPS = G::TAPS;
     extern __shared__ __attribute__((aligned(16))) char lds[];
@@ -467,27 +474,32 @@ __global__ void __launch_bounds__(256, (TZ * TY <= 16 && NC <= 2) ? 3 : 2) conv_
     int lanex[KS];
     operand_lane_offsets<G, NV>(lanex, wave, lane);
 
-    const uint4* wbase = reinterpret_cast<const uint4*>(a.w) + (size_t)chunk * a.nkb * TAPS * NC * 64 + lane;
+    const uint4* wbase = reinterpret_cast<const uint4*>(a.w) + (size_t)(SPLIT ? chunk >> 1 : chunk) * a.nkb * TAPS * NCW * 64 +
+                         (SPLIT ? (chunk & 1) * 2 * 64 : 0) + lane;
     const T* x = reinterpret_cast<const T*>(a.x);
 
     for (int kb = 0; kb < a.nkb; ++kb) {
         if (kb) __syncthreads();
         stage_halo_dma<T, G, UPS>(lds, x, a, n, oz0, oy0, ox0, kb, wave, lane);
-        const uint4* wk = wbase + (size_t)kb * TAPS * NC * 64;
+        const uint4* wk = wbase + (size_t)kb * TAPS * NCW * 64;
         if constexpr (sizeof(T) == 2) {
             constexpr int WPD = WPipe<NC>::WPD;
             uint4 wf[WPD + 1][NC];
-            taps_prefetch_weights<TAPS, NC, WPD>(wf, wk);
+            taps_prefetch_weights<TAPS, NC, WPD, NCW>(wf, wk);
             __syncthreads();
-            taps_pipelined<T, G, NC, NV, WPD>(acc, lds, wk, wf, lanex);
+            taps_pipelined<T, G, NC, NV, WPD, NCW>(acc, lds, wk, wf, lanex);
         } else {
             __syncthreads();
             taps_rolled<T, G, NC, NV>(acc, lds, wk, lanex);
         }
     }
     constexpr int IMG = ((G::HVOX + 15) / 16) * 1024;     // the GN scratch sits behind the operand image
-    conv_epilogue<T, TO, G, NC, NV>(acc, a, n, chunk, oz0, oy0, ox0, wave, lane, reinterpret_cast<float*>(lds + IMG),
-                                    (tz * a.nty + ty) * a.ntx + tx);
+    if constexpr (SPLIT)
+        conv_epilogue<T, TO, G, NC, NV>(acc, a, n, chunk, oz0, oy0, ox0, wave, lane, reinterpret_cast<float*>(lds + IMG),
+                                        (tz * a.nty + ty) * a.ntx + tx, (chunk >> 1) * 64 + (chunk & 1) * 8, 16);
+    else
+        conv_epilogue<T, TO, G, NC, NV>(acc, a, n, chunk, oz0, oy0, ox0, wave, lane, reinterpret_cast<float*>(lds + IMG),
+                                        (tz * a.nty + ty) * a.ntx + tx);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1288,13 +1300,14 @@ static int set_lds(K kernel, size_t bytes) {
                      "hipFuncSetAttribute(MaxDynamicSharedMemorySize)");
 }
 
-template <typename T, typename TO, int KS, int STRIDE, int UPS, int NC, int TZ, int TY>
+template <typename T, typename TO, int KS, int STRIDE, int UPS, int NC, int TZ, int TY, bool SPLIT = false>
 static int launch_fwd_cfg(const ConvArgs& a0, hipStream_t s) {
     using G = Geo<KS, STRIDE, TZ, TY>;
     ConvArgs a = a0;
+    if (SPLIT) a.nchunks *= 2;
     a.ntz = cdiv(a.Dz, TZ); a.nty = cdiv(a.Dy, TY); a.ntx = cdiv(a.Dx, 16);
     const size_t lds = (size_t)((G::HVOX + 15) / 16) * 1024 + GN_SCRATCH_BYTES;
-    auto kern = conv_fwd_kernel<T, TO, KS, STRIDE, UPS, NC, TZ, TY>;
+    auto kern = conv_fwd_kernel<T, TO, KS, STRIDE, UPS, NC, TZ, TY, SPLIT>;
     static bool attr_done = false;
     if (!attr_done) {
         int e = set_lds(kern, lds);
@@ -1340,6 +1353,14 @@ static int launch_fwd_geo(const ConvArgs& a, hipStream_t s) {
     else if constexpr (KS == 3 && sizeof(T) == 2) {
         int tz, ty;
         small_grid_tile(a, tz, ty);
+        if constexpr (NC == 4 && UPS == 0 && sizeof(TO) == 2) {
+            // still fewer than two workgroups per CU: half-chunk workgroups (the NC=2 kernel on the same packed weights)
+            const long long wgs = (long long)a.nchunks * a.N * cdiv(a.Dz, tz) * cdiv(a.Dy, ty) * cdiv(a.Dx, 16);
+            if (tz <= 2 && wgs < 2LL * cu_count() && a.Cout % 64 == 0 && getenv("VDM4CDM_NO_SPLIT") == nullptr) {
+                if (tz == 1) return ty == 4 ? launch_fwd_cfg<T, TO, KS, STRIDE, UPS, 2, 1, 4, true>(a, s) : launch_fwd_cfg<T, TO, KS, STRIDE, UPS, 2, 1, 8, true>(a, s);
+                return launch_fwd_cfg<T, TO, KS, STRIDE, UPS, 2, 2, 8, true>(a, s);
+            }
+        }
         if (tz == 1) return ty == 4 ? launch_fwd_cfg<T, TO, KS, STRIDE, UPS, NC, 1, 4>(a, s) : launch_fwd_cfg<T, TO, KS, STRIDE, UPS, NC, 1, 8>(a, s);
         if (tz == 2) return launch_fwd_cfg<T, TO, KS, STRIDE, UPS, NC, 2, 8>(a, s);
         return launch_fwd_cfg<T, TO, KS, STRIDE, UPS, NC, 4, 8>(a, s);
