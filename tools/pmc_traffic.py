@@ -18,9 +18,9 @@ import sys
 
 
 def simplify(name):
-    m = re.search(r"conv_fwd_kernel<vdm::(\w+), (?:vdm::)?(\w+), (\d), (\d), (\d), (\d), \d, \d>", name)
+    m = re.search(r"conv_fwd_kernel<vdm::(\w+), (?:vdm::)?(\w+), (\d), (\d), (\d), (\d), \d, \d(?:, (true|false))?>", name)
     if m:
-        return f"conv_fwd_kernel<{m.group(1)},k{m.group(3)},s{m.group(4)},NC{m.group(6)}>"
+        return f"conv_fwd_kernel<{m.group(1)},k{m.group(3)},s{m.group(4)},NC{m.group(6)}{',split' if m.group(7) == 'true' else ''}>"
     if "conv_kpack_kernel" in name:
         return "conv_kpack_kernel"
     m = re.search(r"conv_cls_kernel<vdm::(\w+), (\d), (\d)>", name)

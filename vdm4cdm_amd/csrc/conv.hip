@@ -1346,6 +1346,13 @@ static void small_grid_tile(const ConvArgs& a, int& tz, int& ty) {
     if (2 * tiles28 < cu_count()) ty = 4;
 }
 
+// NC=4 conv with fewer than two workgroups per CU even on the small tiles: half-chunk workgroups (the NC=2 kernel on the same packed
+// weights; bf16 3x3x3 stride 1, not the up-sampling conv)
+static bool uses_split(const ConvArgs& a, int tz, int ty) {
+    const long long wgs = (long long)a.nchunks * a.N * cdiv(a.Dz, tz) * cdiv(a.Dy, ty) * cdiv(a.Dx, 16);
+    return tz <= 2 && wgs < 2LL * cu_count() && a.Cout % 64 == 0 && getenv("VDM4CDM_NO_SPLIT") == nullptr;
+}
+
 template <typename T, typename TO, int KS, int STRIDE, int UPS, int NC>
 static int launch_fwd_geo(const ConvArgs& a, hipStream_t s) {
     if constexpr (STRIDE == 2)
@@ -1354,9 +1361,7 @@ static int launch_fwd_geo(const ConvArgs& a, hipStream_t s) {
         int tz, ty;
         small_grid_tile(a, tz, ty);
         if constexpr (NC == 4 && UPS == 0 && sizeof(TO) == 2) {
-            // still fewer than two workgroups per CU: half-chunk workgroups (the NC=2 kernel on the same packed weights)
-            const long long wgs = (long long)a.nchunks * a.N * cdiv(a.Dz, tz) * cdiv(a.Dy, ty) * cdiv(a.Dx, 16);
-            if (tz <= 2 && wgs < 2LL * cu_count() && a.Cout % 64 == 0 && getenv("VDM4CDM_NO_SPLIT") == nullptr) {
+            if (uses_split(a, tz, ty)) {
                 if (tz == 1) return ty == 4 ? launch_fwd_cfg<T, TO, KS, STRIDE, UPS, 2, 1, 4, true>(a, s) : launch_fwd_cfg<T, TO, KS, STRIDE, UPS, 2, 1, 8, true>(a, s);
                 return launch_fwd_cfg<T, TO, KS, STRIDE, UPS, 2, 2, 8, true>(a, s);
             }
@@ -1846,7 +1851,19 @@ extern "C" int vdm_conv_dgrad(const vdm_conv_desc* d, const void* dout, const vo
 extern "C" int vdm_conv_kernel_variant(const vdm_conv_desc* d, int dgrad) {
     if (validate(d)) return -1;
     if (uses_cls(d, dgrad)) return VDM_CONV_VARIANT_CLASS;
-    return uses_kpack(d, dgrad) ? VDM_CONV_VARIANT_KPACK : VDM_CONV_VARIANT_GENERIC;
+    if (uses_kpack(d, dgrad)) return VDM_CONV_VARIANT_KPACK;
+    if (d->dtype == VDM_BF16 && d->ksize == 3 && !d->upsample && (dgrad || (d->stride == 1 && !d->out_f32))) {
+        const Plan p = plan_of(d, dgrad);
+        if (p.nc == 4) {
+            ConvArgs a{};
+            a.N = d->n; a.Dz = d->od; a.Dy = d->oh; a.Dx = d->ow;         // (dgrad of a stride-1 conv runs on the output grid too)
+            a.Cout = p.O; a.nchunks = p.nchunks;
+            int tz, ty;
+            small_grid_tile(a, tz, ty);
+            if (uses_split(a, tz, ty)) return VDM_CONV_VARIANT_SPLIT;
+        }
+    }
+    return VDM_CONV_VARIANT_GENERIC;
 }
 
 extern "C" size_t vdm_conv_wgrad_workspace_bytes(const vdm_conv_desc* d) {

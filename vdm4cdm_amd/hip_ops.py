@@ -189,6 +189,8 @@ class Conv:
                 key = f"conv_cls_kernel<{_tname(x.dtype)},NC{_nc_for(self.cout, x.dtype)},F>"
             elif L.vdm_conv_kernel_variant(d, 0) == 2:
                 key = "conv_kpack_kernel"
+            elif L.vdm_conv_kernel_variant(d, 0) == 3:
+                key = f"conv_fwd_kernel<{_tname(x.dtype)},k3,s1,NC2,split>"
             else:
                 key = f"conv_fwd_kernel<{_tname(x.dtype)},k{self.ksize},s{self.stride},NC{_nc_for(self.cout, x.dtype)}>"
             _pe(ev, key,
@@ -221,6 +223,8 @@ class Conv:
                 key = f"conv_cls_kernel<{_tname(dout.dtype)},NC{_nc_for(self.cin, dout.dtype)},{'B' if self.upsample else 'F'}>"
             elif L.vdm_conv_kernel_variant(d, 1) == 2:
                 key = "conv_kpack_kernel"
+            elif L.vdm_conv_kernel_variant(d, 1) == 3:
+                key = f"conv_fwd_kernel<{_tname(dout.dtype)},k3,s1,NC2,split>"
             else:
                 key = f"conv_fwd_kernel<{_tname(dout.dtype)},k{self.ksize},s1,NC{_nc_for(self.cin, dout.dtype)}>"
             _pe(ev, key,
