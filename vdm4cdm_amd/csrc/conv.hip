@@ -9,12 +9,16 @@
 //   B = activations read from an LDS halo tile, D: lane (v = lane&15, q = lane>>4) owns voxel v and
 //   4*NC consecutive output channels -> 16-byte NDHWC stores.
 //   One workgroup = 4 waves = TZ x TY x 16 output voxels x (NC*16) output channels.
-//   LDS halo image is "piece-major": [piece 0..3][halo voxel][16 B], plane stride a multiple of
-//   256 B, so the 64-lane ds_read_b128 of 16 x-consecutive voxels is bank-conflict-free.
+//   LDS halo image: voxel-major, 64 B per halo voxel with the four 16-B pieces x-swizzled (see stage_halo_dma), filled by
+//   LDS-DMA; the 64-lane ds_read_b128 of 16 x-consecutive voxels is bank-conflict-free.
+// Kernels in this file: conv_fwd_kernel (generic fwd / dgrad, incl. half-chunk workgroups for small grids), conv_kpack_kernel
+//   (<= 8 reduction channels), conv_cls_kernel (per-parity-class convs: up-sampling conv fwd / dgrad, stride-2 dgrad),
+//   conv_wgrad_kernel (+ class mode for the up-sampling conv) with its slab reduce kernels, the weight packers
+//   (per conv and pack_many_kernel), and the host-side planning behind the C-ABI entry points.
 // wgrad: D[cout][cin] += dOut^T[cout][voxel] * X[voxel][cin]; both operands are voxel-major in LDS
 //   and are read transposed with ds_read_b64_tr_b16 (bf16) / ds_read_b32 (fp32); workgroups are
 //   persistent over spatial tiles and write partial slabs that a second kernel reduces
-//   (deterministic, no float atomics).
+//   (deterministic, no float atomics).  Conv epilogues can also reduce the GroupNorm statistics of their output.
 #include <stdarg.h>
 #include <stdio.h>
 #include <stdlib.h>
@@ -37,12 +41,9 @@ struct Geo {
     static constexpr int TAPS = KS * KS * KS;
     static constexpr int HZ = (TZ - 1) * STRIDE + KS, HY = (TY - 1) * STRIDE + KS, HX = (TX - 1) * STRIDE + KS;
     static constexpr int HVOX = HZ * HY * HX;
-    static constexpr int HVOX_PAD = (HVOX + 15) / 16 * 16;
-    static constexpr int PLANE = HVOX_PAD * 16;          // bytes, multiple of 256
     static constexpr int ROWS = TZ * TY;                 // 16-voxel MFMA columns-tiles per workgroup
     static constexpr int NV = ROWS / 4;                  // per wave
     static constexpr int OVOX = ROWS * 16;
-    static constexpr int OPLANE = OVOX * 16;             // dOut tile plane (wgrad)
     static_assert(ROWS % 4 == 0, "rows must split over 4 waves");
 };
 
@@ -64,52 +65,9 @@ struct ConvArgs {
     float* gnp;          // optional GroupNorm partials of the output: [N][ntz*nty*ntx][Cout][2] = (sum, sum of squares) per tile
 };
 
-// halo voxel index -> LDS byte offset of piece pc
-template <int PLANE, int ODD_OFF>
-__device__ __forceinline__ int lds_off(int pc, int hv) {
-    // ODD_OFF = 128 shifts odd pieces by half a 256-B bank row (conflict-free transposed reads in wgrad);
-    // the shift is folded into the plane stride so that planes never overlap.
-    return pc * (PLANE + ODD_OFF) + hv * 16;
-}
-
 __device__ __forceinline__ int wrap(int i, int n) {
     i %= n;
     return i < 0 ? i + n : i;
-}
-
-// Stage one K-block (64 B of channels per voxel) of the halo tile into LDS.
-template <typename T, typename G, int UPS, int ODD_OFF>
-__device__ __forceinline__ void stage_halo(char* lds, const T* __restrict__ x, const ConvArgs& a, int n,
-                                           int oz0, int oy0, int ox0, int kb, int tid) {
-    constexpr int EPL = DT<T>::EPL, KB = DT<T>::KB;
-    constexpr int NP = (G::HVOX + 7) / 8 * 32;
-    const int iz0 = oz0 * G::STRIDE - G::PAD, iy0 = oy0 * G::STRIDE - G::PAD, ix0 = ox0 * G::STRIDE - G::PAD;
-#pragma unroll 4
-    for (int p = tid; p < NP; p += 256) {
-        const int pc = (p >> 3) & 3;
-        const int hv = ((p >> 5) << 3) + (p & 7);
-        if (hv < G::HVOX) {
-            const int hx = hv % G::HX;
-            const int t = hv / G::HX;
-            const int hy = t % G::HY;
-            const int hz = t / G::HY;
-            int iz = iz0 + hz, iy = iy0 + hy, ix = ix0 + hx;
-            const int ci = kb * KB + pc * EPL;
-            bool ok = ci < a.Cin;
-            if (a.circular) {
-                iz = wrap(iz, a.Iz); iy = wrap(iy, a.Iy); ix = wrap(ix, a.Ix);
-            } else {
-                ok = ok && (unsigned)iz < (unsigned)a.Iz && (unsigned)iy < (unsigned)a.Iy && (unsigned)ix < (unsigned)a.Ix;
-            }
-            if (UPS) { iz >>= 1; iy >>= 1; ix >>= 1; }
-            uint4 v = make_uint4(0, 0, 0, 0);
-            if (ok) {
-                const size_t off = ((((size_t)n * a.Sz + iz) * a.Sy + iy) * a.Sx + ix) * a.CinStride + ci;
-                v = *reinterpret_cast<const uint4*>(x + off);
-            }
-            *reinterpret_cast<uint4*>(lds + lds_off<G::PLANE, ODD_OFF>(pc, hv)) = v;
-        }
-    }
 }
 
 // 64 zero bytes: source of every padded / out-of-range piece of the LDS-DMA staging below.
@@ -148,28 +106,6 @@ __device__ __forceinline__ void stage_halo_dma(char* lds, const T* __restrict__ 
         const void* src = ok ? static_cast<const void*>(x + off) : static_cast<const void*>(g_zero_page);
         __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
                                          (__attribute__((address_space(3))) void*)(lds + c * 1024), 16, 0, 0);
-    }
-}
-
-// Stage the (halo-free) dOut tile of a wgrad workgroup: OVOX voxels x 64 B (one channel block).
-template <typename T, typename G>
-__device__ __forceinline__ void stage_dout(char* lds, const T* __restrict__ g, const ConvArgs& a, int n, int oz0,
-                                           int oy0, int ox0, int cb, int cstride, int tid) {
-    constexpr int EPL = DT<T>::EPL, KB = DT<T>::KB;
-    constexpr int NP = G::OVOX * 4;
-#pragma unroll 4
-    for (int p = tid; p < NP; p += 256) {
-        const int pc = (p >> 3) & 3;
-        const int ov = ((p >> 5) << 3) + (p & 7);
-        const int lx = ov & 15, r = ov >> 4;
-        const int oz = oz0 + r / G::TY, oy = oy0 + r % G::TY, ox = ox0 + lx;
-        const int co = cb * KB + pc * EPL;
-        uint4 v = make_uint4(0, 0, 0, 0);
-        if (co < a.Cout && oz < a.Dz && oy < a.Dy && ox < a.Dx) {
-            const size_t off = ((((size_t)n * a.Dz + oz) * a.Dy + oy) * a.Dx + ox) * cstride + co;
-            v = *reinterpret_cast<const uint4*>(g + off);
-        }
-        *reinterpret_cast<uint4*>(lds + lds_off<G::OPLANE, 128>(pc, ov)) = v;
     }
 }
 
