@@ -65,6 +65,9 @@ CONV_CASES = [
     ("k3_cout1", 2, (8, 8, 16), 32, 1, 3, 1, 0, False),
     ("k3_mid_64_64", 2, (32, 32, 32), 64, 64, 3, 1, 0, False),      # 256 tiles of 2x8x16: the middle tile shape (bf16)
     ("k3_mid_32_128", 1, (16, 32, 32), 32, 128, 3, 1, 0, True),      # 128 tiles of 1x8x16 (2 chunks)
+    ("k3_mid_128_64", 2, (16, 32, 32), 128, 64, 3, 1, 0, False),     # 4 K-blocks, 1x8x16 tiles, half-chunk workgroups
+    ("k3_mid_64_128", 2, (32, 32, 32), 64, 128, 3, 1, 0, True),      # 2 K-blocks, 2x8x16 tiles, whole chunks
+    ("k3_big_64_64", 2, (64, 64, 64), 64, 64, 3, 1, 0, False),       # 2 K-blocks, 4x8x16 tiles, 4 workgroups per CU
     ("k3_cin8_circ", 1, (6, 9, 20), 8, 16, 3, 1, 0, True),           # <= 8 input channels: tap-packed kernel (bf16)
     ("k3_cin3_ragged", 2, (5, 7, 18), 3, 32, 3, 1, 0, False),
     ("k3_circ", 1, (8, 8, 16), 32, 32, 3, 1, 0, True),
@@ -181,7 +184,7 @@ def test_conv_large(case):
         assert err_a <= conv_tol(dtype, xr.grad + acc_in), f"{name}: dgrad+residual err {err_a}"
 
 
-GN_FUSED_CASES = [c for c in CONV_CASES if c[0] in ("k3_32_32", "k3_32_32_ragged", "k3_64_32", "k3_128_256", "k3_cin2pad", "k3_cin8_circ", "k3_cin3_ragged", "k3_mid_64_64", "k3_mid_32_128", "k3_circ_small",
+GN_FUSED_CASES = [c for c in CONV_CASES if c[0] in ("k3_32_32", "k3_32_32_ragged", "k3_64_32", "k3_128_256", "k3_cin2pad", "k3_cin8_circ", "k3_cin3_ragged", "k3_mid_64_64", "k3_mid_32_128", "k3_mid_128_64", "k3_mid_64_128", "k3_big_64_64", "k3_circ_small",
                                                       "k3_s2", "k3_s2_ragged", "k1_64_32", "k3_16_16", "k3_48_96")] + LARGE_CASES[:2]
 
 
@@ -221,7 +224,7 @@ def test_conv_fused_gn_stats(case, dtype):
         assert (two - two_plain).abs().max().item() <= ftol.max().item(), f"{name}: two-source stats"
 
 
-GRAD_CASES = [c for c in CONV_CASES if c[0] in ("k3_32_32", "k3_32_32_ragged", "k3_64_32", "k3_32_64", "k3_128_256", "k3_cin2pad", "k3_cin8_circ", "k3_cin3_ragged", "k3_mid_64_64", "k3_mid_32_128",
+GRAD_CASES = [c for c in CONV_CASES if c[0] in ("k3_32_32", "k3_32_32_ragged", "k3_64_32", "k3_32_64", "k3_128_256", "k3_cin2pad", "k3_cin8_circ", "k3_cin3_ragged", "k3_mid_64_64", "k3_mid_32_128", "k3_mid_128_64", "k3_mid_64_128", "k3_big_64_64",
                                                   "k3_cout1", "k3_circ", "k3_s2", "k3_s2_circ", "k3_ups", "k3_ups_circ", "k3_ups_ragged", "k3_ups_128_64",
                                                   "k3_s2_ragged", "k3_s2_128", "k1_64_32",
                                                   "k1_32_128", "k3_48_96")]

@@ -81,12 +81,12 @@ __device__ uint4 g_zero_page[16];
 // linearly; the four lanes of a voxel fetch its (permuted) pieces, i.e. whole 64-B segments of the NDHWC row.
 template <typename T, typename G, int UPS>
 __device__ __forceinline__ void stage_halo_dma(char* lds, const T* __restrict__ x, const ConvArgs& a, int n,
-                                               int oz0, int oy0, int ox0, int kb, int wave, int lane) {
+                                               int oz0, int oy0, int ox0, int kb, int wave, int lane, int nwaves = 4) {
     constexpr int EPL = DT<T>::EPL, KB = DT<T>::KB;
     constexpr int NCHUNK = (G::HVOX + 15) / 16;
     const int iz0 = oz0 * G::STRIDE - G::PAD, iy0 = oy0 * G::STRIDE - G::PAD, ix0 = ox0 * G::STRIDE - G::PAD;
     const int k = lane >> 2, j = lane & 3;
-    for (int c = wave; c < NCHUNK; c += 4) {
+    for (int c = wave; c < NCHUNK; c += nwaves) {
         const int hv = c * 16 + k;
         const int hx = hv % G::HX;
         const int t = hv / G::HX;
