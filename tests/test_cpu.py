@@ -244,3 +244,9 @@ def test_synthetic_datamodule_contract():
     assert abs(b["x"].var().item() - 1) < 0.05
     rho = dm.unnorm_func(b["x"], 1)
     assert torch.allclose(dm.norm_func(rho, 1), b["x"], atol=1e-4)
+
+
+def test_graft_entry_build_imports_and_checks_the_abi(hip_lib):
+    """__graft_entry__.build() (run by the driver every round) must succeed on the CPU-only container."""
+    import __graft_entry__ as g
+    g.build()
