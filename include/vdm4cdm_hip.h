@@ -85,7 +85,7 @@ int vdm_conv_pack_many(const vdm_pack_item* items_device, const vdm_pack_chunk* 
  * element distance between samples (the table of all blocks is one [n][sum cout] matrix). */
 /* gn_partials (may be NULL): the epilogue also reduces the GroupNorm statistics of the output it stores, per spatial tile:
  * gn_partials[n][tile][cout][2] = (sum, sum of squares) fp32, tile < vdm_conv_gn_tiles(d); feed them to vdm_gn_stats instead of
- * a separate pass over the tensor.  vdm_conv_gn_tiles() == 0: this conv cannot (the up-sampling conv). */
+ * a separate pass over the tensor (the up-sampling conv has one slot per coarse tile and parity class). */
 int vdm_conv_gn_tiles(const vdm_conv_desc* d);
 int vdm_conv_fwd(const vdm_conv_desc* d, const void* x, const void* w_packed_fwd, const float* bias,
                  const float* nbias, int64_t nbias_stride, const void* residual, void* out, float* gn_partials, void* stream);

@@ -184,7 +184,7 @@ def test_conv_large(case):
         assert err_a <= conv_tol(dtype, xr.grad + acc_in), f"{name}: dgrad+residual err {err_a}"
 
 
-GN_FUSED_CASES = [c for c in CONV_CASES if c[0] in ("k3_32_32", "k3_32_32_ragged", "k3_64_32", "k3_128_256", "k3_cin2pad", "k3_cin8_circ", "k3_cin3_ragged", "k3_mid_64_64", "k3_mid_32_128", "k3_mid_128_64", "k3_mid_64_128", "k3_big_64_64", "k3_circ_small",
+GN_FUSED_CASES = [c for c in CONV_CASES if c[0] in ("k3_32_32", "k3_32_32_ragged", "k3_64_32", "k3_128_256", "k3_cin2pad", "k3_cin8_circ", "k3_cin3_ragged", "k3_mid_64_64", "k3_mid_32_128", "k3_mid_128_64", "k3_mid_64_128", "k3_big_64_64", "k3_ups", "k3_ups_circ", "k3_ups_ragged", "k3_ups_128_64", "k3_circ_small",
                                                       "k3_s2", "k3_s2_ragged", "k1_64_32", "k3_16_16", "k3_48_96")] + LARGE_CASES[:2]
 
 

@@ -632,11 +632,14 @@ __device__ __forceinline__ void taps_list(f32x4 (&acc)[NV][NC], const char* lds,
 // epilogue with an output coordinate map  u = os * (tile voxel) + p   (os = 1: plain; os = 2: scatter into the fine grid)
 template <typename T, typename G, int NC, int NV>
 __device__ __forceinline__ void cls_epilogue(const f32x4 (&acc)[NV][NC], const ClsArgs& ca, int n, int chunk, int oz0, int oy0, int ox0,
-                                             int os, int pz, int py, int px, int cwave, int lane) {
+                                             int os, int pz, int py, int px, int cwave, int lane, float* gn_sm = nullptr, int tile = 0) {
     constexpr int EPL = DT<T>::EPL;
     const ConvArgs& a = ca.c;
     const int lx = lane & 15, q = lane >> 4;
     const int cbase = chunk * NC * 16 + q * NC * 4;
+    float gs[NC * 4], gq[NC * 4];                          // GroupNorm partials of the stored outputs (a.gnp; see conv_epilogue)
+#pragma unroll
+    for (int j = 0; j < NC * 4; ++j) gs[j] = gq[j] = 0.f;
     float badd[NC * 4];
 #pragma unroll
     for (int j = 0; j < NC * 4; ++j) badd[j] = (a.bias && cbase + j < a.Cout) ? a.bias[cbase + j] : 0.f;
@@ -669,6 +672,11 @@ __device__ __forceinline__ void cls_epilogue(const f32x4 (&acc)[NV][NC], const C
                     if (vec_ok || cbase + j < a.Cout) val[j] += ld_elem<T>(res + vo + j);
             }
         }
+        if (a.gnp) {
+#pragma unroll
+            for (int j = 0; j < NC * 4; ++j)
+                if (vec_ok || cbase + j < a.Cout) { gs[j] += val[j]; gq[j] += val[j] * val[j]; }
+        }
         if (vec_ok && sizeof(T) == 2 && NC >= 2) {
             uint16_t* o16 = reinterpret_cast<uint16_t*>(out) + vo;
 #pragma unroll
@@ -687,6 +695,9 @@ __device__ __forceinline__ void cls_epilogue(const f32x4 (&acc)[NV][NC], const C
                 if (cbase + j < a.Cout) st_elem<T>(out + vo + j, val[j]);
         }
     }
+    if (a.gnp)                                            // workgroup-uniform; one partial slot per (coarse tile, class)
+        gn_partials_reduce<NC>(gs, gq, gn_sm, a.gnp + ((size_t)n * (a.ntz * a.nty * a.ntx * 8) + tile) * a.Cout * 2, chunk * NC * 16, a.Cout,
+                               cwave, lane);
     (void)EPL;
 }
 
@@ -745,7 +756,8 @@ __global__ void __launch_bounds__(256, 2) conv_cls_kernel(const ClsArgs ca) {
     if (MODE == 1)
         cls_epilogue<T, G, NC, NV>(acc, ca, n, chunk, oz0, oy0, ox0, 1, 0, 0, 0, wave, lane);
     else
-        cls_epilogue<T, G, NC, NV>(acc, ca, n, chunk, oz0, oy0, ox0, 2, (cls >> 2) & 1, (cls >> 1) & 1, cls & 1, wave, lane);
+        cls_epilogue<T, G, NC, NV>(acc, ca, n, chunk, oz0, oy0, ox0, 2, (cls >> 2) & 1, (cls >> 1) & 1, cls & 1, wave, lane,
+                                   reinterpret_cast<float*>(lds + ((G::HVOX + 15) / 16) * 1024), ((tz * a.nty + ty) * a.ntx + tx) * 8 + cls);
 }
 
 // packed[chunk][kb][slot 0..63][ct][lane][EPL] = sum over the master taps in mask[slot] of W (transpose: W[t][k][o]).
@@ -1506,7 +1518,7 @@ static int launch_cls_cfg(const ClsArgs& ca0, hipStream_t s) {
     ClsArgs ca = ca0;
     ConvArgs& a = ca.c;
     a.ntz = cdiv(a.Dz, G::TZ); a.nty = cdiv(a.Dy, G::TY); a.ntx = cdiv(a.Dx, 16);
-    const size_t lds = (size_t)((G::HVOX + 15) / 16) * 1024;
+    const size_t lds = (size_t)((G::HVOX + 15) / 16) * 1024 + GN_SCRATCH_BYTES;
     auto kern = conv_cls_kernel<T, NC, MODE>;
     static bool attr_done = false;
     if (!attr_done) {
@@ -1539,14 +1551,14 @@ static int launch_cls(const ClsArgs& ca, int nc, int mode_b, hipStream_t s) {
 
 // x: staged tensor (K channels), out: O channels.  cd/ch/cw: coarse dims.
 static int run_cls(const vdm_conv_desc* d, int kind, const void* x, const void* w, const float* bias, const void* res, void* out,
-                   int cd, int ch, int cw, hipStream_t s) {
+                   int cd, int ch, int cw, hipStream_t s, float* gn_partials = nullptr) {
     const int dgrad = kind != CLS_UP_FWD;
     const Plan p = plan_of(d, dgrad);
     ClsArgs ca{};
     ClsMasks masks;
     build_cls(kind, ca.t, masks);
     ConvArgs& a = ca.c;
-    a.x = x; a.w = w; a.bias = bias; a.res = res; a.out = out;
+    a.x = x; a.w = w; a.bias = bias; a.res = res; a.out = out; a.gnp = gn_partials;
     a.N = d->n; a.Dz = cd; a.Dy = ch; a.Dx = cw;
     a.Iz = cd; a.Iy = ch; a.Ix = cw;
     a.circular = d->pad_mode == VDM_PAD_CIRCULAR;
@@ -1737,7 +1749,8 @@ extern "C" int vdm_conv_pack_many(const vdm_pack_item* items_dev, const vdm_pack
 }
 
 extern "C" int vdm_conv_gn_tiles(const vdm_conv_desc* d) {
-    if (validate(d) != VDM_OK || uses_cls(d, 0)) return 0;
+    if (validate(d) != VDM_OK) return 0;
+    if (uses_cls(d, 0)) return 8 * cdiv(d->od / 2, 4) * cdiv(d->oh / 2, 8) * cdiv(d->ow / 2, 16);     // up-sampling conv: (coarse tile, class)
     ConvArgs a{};
     fwd_args(a, d);
     int tz, ty;
@@ -1751,9 +1764,8 @@ extern "C" int vdm_conv_fwd(const vdm_conv_desc* d, const void* x, const void* w
     if (e) return e;
     VDM_REQUIRE(x && w_packed && out, "conv_fwd: NULL pointer");
     if (uses_cls(d, 0)) {
-        VDM_REQUIRE(!gn_partials, "conv_fwd: the up-sampling conv does not produce GroupNorm partials (vdm_conv_gn_tiles() == 0)");
         VDM_REQUIRE(!nbias && !d->out_f32, "conv_fwd: the up-sampling conv takes no per-sample bias / fp32 output");
-        return run_cls(d, CLS_UP_FWD, x, w_packed, bias, residual, out, d->od / 2, d->oh / 2, d->ow / 2, (hipStream_t)stream);
+        return run_cls(d, CLS_UP_FWD, x, w_packed, bias, residual, out, d->od / 2, d->oh / 2, d->ow / 2, (hipStream_t)stream, gn_partials);
     }
     const Plan p = plan_of(d, 0);
     ConvArgs a{};

@@ -211,7 +211,7 @@ class HipUNet:
         coarse = []
         for i in reversed(range(L - 1)):
             coarse.append(h)
-            u = self.up[i].fwd(h, P(f"ups.{i}.up.bias"))
+            u = self.up[i].fwd(h, P(f"ups.{i}.up.bias"), gn=FUSED_GN)
             h = self.res[f"ups.{i}.block"].fwd(P, u, skips[i], table, train, seed + 200 + i, ss)
         st = ops.gn_stats(h, None, net.norm_groups)
         a = ops.gn_silu_fwd(h, None, net.norm_groups, st, P("norm_out.weight"), P("norm_out.bias"))
