@@ -6,6 +6,7 @@ Tolerances: fp32 storage - forward max|d| <= 2e-4 * max|ref|, parameter gradient
 re-rounded to bf16 ~20 times along the deepest path), gradients checked by cosine similarity >= 0.995.
 """
 import math
+import os
 
 import pytest
 import torch
@@ -307,3 +308,44 @@ def test_training_reduces_the_loss():
     first, last = sum(losses[:10]) / 10, sum(losses[-10:]) / 10
     assert all(math.isfinite(l) for l in losses)
     assert last < 0.8 * first, f"loss did not go down: first 10 avg {first:.4f}, last 10 avg {last:.4f}"
+
+
+@pytest.mark.parametrize("pm,chs", [("zeros", (32, 64, 128, 256)), ("circular", (16, 32, 64, 128))], ids=["c3_zeros", "c256_circular"])
+def test_full_size_128_forward(pm, chs):
+    """The forward at the BASELINE size (128^3, the channel ladders of C3 and of the 224^3/256^3 configs; batch 1) against the oracle:
+    every level runs the kernels and tile shapes of the benchmark (4x8x16 tiles, tap-packed conv_in, class kernels, half-chunk
+    workgroups at the deep levels).  fp32 <= 2e-4, bf16 <= 3e-2 relative to max|ref|."""
+    torch.set_num_threads(min(64, os.cpu_count() or 8))
+    ref = None
+    for precision, tol in (("fp32", 2e-4), ("bf16", 3e-2)):
+        net = make_net(D=128, chs=chs, pm=pm, precision=precision, seed=3)
+        x, t, s, v = inputs(net, 1, seed=5)
+        if ref is None:
+            with torch.no_grad():
+                ref = oracle_forward(net, x, t, s, v)
+        net = net.to(DEV).eval()
+        with torch.no_grad():
+            out = hip_forward(net, x, t, s, v).cpu()
+        err = (out - ref).abs().max().item()
+        assert err <= tol * ref.abs().max().item(), f"{precision}: max|d| {err} vs max|ref| {ref.abs().max().item()}"
+
+
+def test_c2_size_backward_fp32():
+    """fp32 gradients at the C2 size (64^3, chs 32..256, batch 1) against torch.autograd through the oracle."""
+    torch.set_num_threads(min(64, os.cpu_count() or 8))
+    net = make_net(D=64, chs=(32, 64, 128, 256), precision="fp32", seed=9).to(DEV).train()
+    x, t, s, v = inputs(net, 1, seed=13)
+    w = grf((1, 1) + net.shape[1:], 77) + 0.5
+    y, gflat = _grads(net, x, t, s, v, w)
+    yr, gref = _oracle_grads(net, x, t, s, v, w)
+    assert (y - yr).abs().max().item() <= 2e-4 * yr.abs().max().item()
+    got = _product_grad_views(net, gflat)
+    bad = []
+    for k, g in gref.items():
+        if g is None:
+            continue
+        scale = max(g.abs().max().item(), 1e-8)
+        err = (got[k] - g).abs().max().item()
+        if err > 3e-3 * scale + 1e-6:
+            bad.append((k, err, scale))
+    assert not bad, f"{len(bad)} tensors off: {bad[:8]}"
