@@ -104,7 +104,9 @@ def main():
                     help="HIP events around EVERY kernel launch (full per-kernel table; ~600 event pairs per step cost ~6 %% of the step)."
                          " Default: only the 3^3 conv fwd/dgrad launches, the candidates for the dominant kernel (~50 per step)")
     ap.add_argument("--per-step", action="store_true", help="diagnostic: synchronise after every timed step and print its duration to stderr")
-    ap.add_argument("--sample-steps", type=int, default=0, help="also time an n-step reverse-diffusion sample (batch 1)")
+    ap.add_argument("--sample-steps", type=int, default=0,
+                    help="after the training steps, rank 0 also times an n-step reverse-diffusion sample of one cube (second half of the "
+                         "BASELINE metric; reported under \"sample\", never part of \"value\"); e.g. --sample-steps 1000")
     args = ap.parse_args()
 
     import torch.distributed as dist
@@ -220,15 +222,19 @@ def main():
             roof["step_algorithmic_TFLOP"] = alg_flops / 1e12
         out["roofline"] = roof
         if args.sample_steps:
-            vdm.eval()
-            s = batch["conditioning"][:1]
-            v = [batch["conditioning_values"][0][:1]]
-            vdm.draw_samples(batch_size=1, n_sampling_steps=3, s_conditioning=s, v_conditionings=v)
-            torch.cuda.synchronize()
-            t1 = time.perf_counter()
-            vdm.draw_samples(batch_size=1, n_sampling_steps=args.sample_steps, s_conditioning=s, v_conditionings=v)
-            torch.cuda.synchronize()
-            out["sample"] = {"steps": args.sample_steps, "seconds": time.perf_counter() - t1, "cube": D, "batch": 1}
+            try:
+                vdm.eval()
+                s = batch["conditioning"][:1]
+                v = [batch["conditioning_values"][0][:1]]
+                vdm.draw_samples(batch_size=1, n_sampling_steps=3, s_conditioning=s, v_conditionings=v)
+                torch.cuda.synchronize()
+                t1 = time.perf_counter()
+                vdm.draw_samples(batch_size=1, n_sampling_steps=args.sample_steps, s_conditioning=s, v_conditionings=v)
+                torch.cuda.synchronize()
+                out["sample"] = {"steps": args.sample_steps, "seconds": time.perf_counter() - t1, "cube": D, "batch": 1,
+                                 "note": "one chain on rank 0, hipGraph-captured denoise step; chains on other GPUs are independent"}
+            except Exception as e:                          # never lose the training line over the secondary measurement
+                out["sample"] = {"error": repr(e)}
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(chs)
         print(json.dumps(out), flush=True)
