@@ -1,5 +1,11 @@
 """Shared test helpers: product <-> oracle parameter conversion, seeded synthetic inputs."""
+import importlib.util
+import os
+
+import numpy as np
 import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def oracle_params(net, flat=None):
@@ -51,3 +57,40 @@ def grf(shape, seed, slope=-2.0):
     x = torch.fft.ifftn(F * amp, dim=dims).real
     x = x - x.mean(dim=dims, keepdim=True)
     return (x / x.std(dim=dims, keepdim=True)).float()
+
+
+# ---------------------------------------------------------------- DDNM fixture replay (tests/golden/make_ddnm_golden.py)
+def _ddnm_mod():
+    spec = importlib.util.spec_from_file_location("mk_ddnm", os.path.join(ROOT, "tests", "golden", "make_ddnm_golden.py"))
+    m = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(m)
+    return m
+
+
+DD = _ddnm_mod()
+DDNM_GOLD = np.load(os.path.join(ROOT, "tests", "golden", "ddnm_golden.npz"))
+
+
+def replay_ddnm_case(case, device, backend, precision="fp32"):
+    """Run the PRODUCT's get_ddnm_result on one fixture case with the fixture's noise stream.  Returns (x, gold x, relative residual of A x = y)."""
+    from vdm4cdm_amd import utils
+    from vdm4cdm_amd.networks import CUNet
+    from vdm4cdm_amd.vdm_model import LightVDM
+    name, D, chs, seed, B, n, l, op, cond = case
+    net0, y, kwargs = DD.case_inputs(case)
+    flat = net0.flat.detach().double()
+    np.testing.assert_allclose([flat.sum().item(), (flat ** 2).sum().item()], DDNM_GOLD[f"{name}/weights_check"], rtol=1e-9)
+    np.testing.assert_allclose([y.double().sum().item(), (y.double() ** 2).sum().item()], DDNM_GOLD[f"{name}/y_check"], rtol=1e-9)
+    net = CUNet(shape=net0.shape, chs=net0.chs, s_conditioning_channels=net0.s_conditioning_channels,
+                v_conditioning_dims=net0.v_conditioning_dims, norm_groups=8, backend=backend, precision=precision)
+    with torch.no_grad():
+        net.flat.copy_(net0.flat)
+    vdm = LightVDM(score_model=net, gamma_max=13.3).to(device).eval()
+    A, AT = DD.operators(op, (B, 1, D, D, D), device)
+    kw = {k: ([a.to(device) for a in v] if isinstance(v, list) else v.to(device)) for k, v in kwargs.items()}
+    with DD.NoiseStream(DD.NOISE_SEED + seed) as ns:
+        x = utils.get_ddnm_result(vdm, y.to(device), A, AT, n_sampling_steps=n, l=l, **kw)
+    assert ns.calls == int(DDNM_GOLD[f"{name}/noise_calls"][0]), "the product loop draws noise a different number of times"
+    yd = y.to(device)
+    resid = (A(x) - yd).abs().max().item() / max(1.0, yd.abs().max().item())        # range-space consistency A x = y
+    return x.cpu(), torch.from_numpy(DDNM_GOLD[f"{name}/x"]), resid

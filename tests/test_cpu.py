@@ -250,3 +250,42 @@ def test_graft_entry_build_imports_and_checks_the_abi(hip_lib):
     """__graft_entry__.build() (run by the driver every round) must succeed on the CPU-only container."""
     import __graft_entry__ as g
     g.build()
+
+
+# ------------------------------------------------------------------------------ DDNM: product loop vs the reference's own loop
+from helpers import DD, replay_ddnm_case  # noqa: E402
+
+
+@pytest.mark.parametrize("case", DD.CASES, ids=[c[0] for c in DD.CASES])
+def test_ddnm_product_loop_matches_reference_golden(case):
+    """utils.get_ddnm_result (product restatement, torch backend, CPU) against the output of the REFERENCE's own
+    get_ddnm_result (/root/reference/src/utils.py:277-304) run on the oracle with the same noise stream."""
+    x, gold, resid = replay_ddnm_case(case, "cpu", "torch")
+    assert x.shape == gold.shape
+    err = (x - gold).abs().max().item()
+    assert err <= 1e-4 * gold.abs().max().item(), f"{case[0]}: {err} vs max|gold| {gold.abs().max().item()}"
+    assert resid <= 1e-3
+
+
+def test_load_state_dict_layouts():
+    """Checkpoint tensors are accepted in this package's tap-major layout or in the PyTorch conv layout [cout, cin, k, k, k]
+    (permuted, not reshaped); a concatenated skip weight is split; any other shape raises instead of being scrambled."""
+    from vdm4cdm_amd.networks import CUNet
+    mk = lambda: CUNet(shape=(1, 8, 8, 8), chs=[8, 16], s_conditioning_channels=1, v_conditioning_dims=[6], norm_groups=4, backend="torch")
+    a, b = randomize(mk(), 3), mk()
+    sd = a.state_dict()
+    torch_layout = {}
+    for k, v in oracle_params(a).items():                 # oracle_params converts to [cout, cin, k, k, k] and concatenates skip/skip2
+        torch_layout[k] = v
+    b.load_state_dict(torch_layout)
+    assert torch.equal(a.flat, b.flat)
+    bad = dict(sd)
+    bad["conv_in.weight"] = sd["conv_in.weight"].reshape(-1)           # right element count, wrong shape
+    with pytest.raises(RuntimeError, match="expected"):
+        mk().load_state_dict(bad)
+    x = torch.randn(1, 1, 8, 8, 8, generator=torch.Generator().manual_seed(0))
+    s = torch.randn(1, 1, 8, 8, 8, generator=torch.Generator().manual_seed(1))
+    v = [torch.rand(1, 6, generator=torch.Generator().manual_seed(2))]
+    with torch.no_grad():
+        assert torch.equal(a.eval()(x, t=torch.tensor([0.3]), s_conditioning=s, v_conditionings=v),
+                           b.eval()(x, t=torch.tensor([0.3]), s_conditioning=s, v_conditionings=v))

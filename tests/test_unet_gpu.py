@@ -349,3 +349,118 @@ def test_c2_size_backward_fp32():
         if err > 3e-3 * scale + 1e-6:
             bad.append((k, err, scale))
     assert not bad, f"{len(bad)} tensors off: {bad[:8]}"
+
+
+# ------------------------------------------------------------------------------------------ BASELINE configs at their full size
+def _per_tensor_report(net, gflat, gref, min_numel=8):
+    got = _product_grad_views(net, gflat)
+    rows = []
+    for k, g in gref.items():
+        if g is None:
+            continue
+        scale = max(g.abs().max().item(), 1e-12)
+        rel = (got[k] - g).abs().max().item() / scale
+        cos = torch.nn.functional.cosine_similarity(got[k].flatten().double(), g.flatten().double(), dim=0).item() if g.numel() >= min_numel else 1.0
+        rows.append((k, cos, rel, g.numel()))
+    return rows
+
+
+def test_c3_backward_128_bf16():
+    """BASELINE config C3 (trainVDM3D128_c_c: 128^3, chs 32..256, bf16 storage), backward at full size, batch 1: every parameter
+    gradient of the HIP path against torch.autograd through the fp32 CPU oracle.  bf16 tolerance: per-tensor cosine >= 0.999 and
+    max|d| <= 3e-2 * max|ref| (2^-8 storage rounding of ~25 saved activations and of the gradients along the deepest path);
+    eval-mode dropout (p=0) so that the two paths compute the same function."""
+    torch.set_num_threads(min(64, os.cpu_count() or 8))
+    net = make_net(D=128, chs=(32, 64, 128, 256), precision="bf16", seed=3).to(DEV).train()
+    x, t, s, v = inputs(net, 1, seed=5)
+    w = grf((1, 1) + net.shape[1:], 77) + 0.5
+    y, gflat = _grads(net, x, t, s, v, w)
+    yr, gref = _oracle_grads(net, x, t, s, v, w)
+    assert (y - yr).abs().max().item() <= 3e-2 * yr.abs().max().item()
+    rows = _per_tensor_report(net, gflat, gref)
+    bad = [(k, round(c, 5), round(r, 4)) for k, c, r, n in rows if c < 0.999 or r > 3e-2]
+    assert not bad, f"{len(bad)}/{len(rows)} gradient tensors off (name, cosine, max-rel): {bad[:10]}"
+
+
+def test_c4_192_forward():
+    """BASELINE config C4 (trainVDM3D192_c_c: 192^3, chs 32..256), forward at full size, batch 1, fp32 and bf16 storage against the
+    oracle (same tolerances as test_full_size_128_forward).  192 = 12 tiles of 16: ragged z/y tile counts at every level."""
+    torch.set_num_threads(min(64, os.cpu_count() or 8))
+    ref = None
+    for precision, tol in (("fp32", 2e-4), ("bf16", 3e-2)):
+        net = make_net(D=192, chs=(32, 64, 128, 256), precision=precision, seed=3)
+        x, t, s, v = inputs(net, 1, seed=5)
+        if ref is None:
+            with torch.no_grad():
+                ref = oracle_forward(net, x, t, s, v)
+        net = net.to(DEV).eval()
+        with torch.no_grad():
+            out = hip_forward(net, x, t, s, v).cpu()
+        err = (out - ref).abs().max().item()
+        assert err <= tol * ref.abs().max().item(), f"{precision}: max|d| {err} vs max|ref| {ref.abs().max().item()}"
+        del net
+        torch.cuda.empty_cache()
+
+
+def test_c4_192_training_step_properties():
+    """C4 at its training shape (192^3, batch 2, bf16, dropout 0.1): size-independent properties of one fwd+bwd -
+    finite loss and gradients, every parameter tensor receives a gradient, and the step is bit-reproducible (same seed =>
+    identical loss and identical flat gradient: no float atomics on the path)."""
+    from vdm4cdm_amd.data import SyntheticAstroDataModule
+    net = make_net(D=192, chs=(32, 64, 128, 256), precision="bf16", dropout=0.1, seed=3)
+    vdm = make_vdm(net).to(DEV).train()
+    b = SyntheticAstroDataModule(cropsize=192, batch_size=2, seed=1000)._make_batch(1000, 2)
+    batch = {"x": b["x"].to(DEV), "conditioning": b["conditioning"].to(DEV), "conditioning_values": [b["conditioning_values"][0].to(DEV)]}
+    outs = []
+    for rep in range(2):
+        torch.manual_seed(11)
+        import vdm4cdm_amd.unet_hip as uh
+        uh._seed_counter[0] = 0
+        vdm.zero_grad()
+        loss = vdm.training_step(batch, 0)
+        loss.backward()
+        torch.cuda.synchronize()
+        outs.append((loss.detach().clone(), net.flat.grad.detach().clone()))
+    loss, g = outs[0]
+    assert torch.isfinite(loss) and torch.isfinite(g).all()
+    for name in net.spec.items:
+        assert net.view(name, g).abs().max().item() > 0, f"no gradient reached {name}"
+    assert torch.equal(outs[0][0], outs[1][0]), "loss differs between two identical steps"
+    assert torch.equal(outs[0][1], outs[1][1]), f"gradient not bit-reproducible: max|d| {(outs[0][1] - outs[1][1]).abs().max().item()}"
+
+
+def test_c5_sampler_128_power_spectrum():
+    """BASELINE config C5 (generate_3D: reverse diffusion at 128^3, hipGraph-captured denoise step, batch 1) against the oracle
+    sampler on the same weights, z_1 and per-step noise, 20 steps.  Acceptance metric of BASELINE.json / SURVEY T8: the P(k) of the
+    sampled field (pinned estimator, 64 k-bins) within 1 % per bin - fp32 storage additionally <= 1e-3, and element-wise
+    <= 2e-3 * max|ref|."""
+    from oracle import unet_oracle, vdm_oracle
+    from vdm4cdm_amd import utils
+    torch.set_num_threads(min(64, os.cpu_count() or 8))
+    D, n = 128, 20
+    ref = None
+    for precision, tol_pk in (("fp32", 1e-3), ("bf16", 1e-2)):
+        net = make_net(D=D, chs=(32, 64, 128, 256), precision=precision, dropout=0.1, seed=4)
+        randomize(net, 4, zero_init_std=0.01)            # near-identity denoiser: a tame (non-expansive) chain, as at 32^3
+        x, _, s, v = inputs(net, 1, seed=7)
+        z1 = grf(x.shape, 9, slope=0.0)
+        noises = [grf(x.shape, 100 + i, slope=0.0) for i in range(n)]
+        if ref is None:
+            P = oracle_params(net)
+            with torch.no_grad():
+                ref = vdm_oracle.sample(lambda z, tn: unet_oracle.cunet_forward(P, oracle_cfg(net), z, tn, s, v),
+                                        vdm_oracle.Schedule(-13.3, 13.3), z1.clone(), n, noises)
+            k_ref, pk_ref, n_ref = utils.pk(ref)
+        vdm = make_vdm(net).to(DEV).eval()
+        out = vdm.draw_samples(batch_size=1, n_sampling_steps=n, z=z1.clone(), noises=noises, use_graph=True,
+                               s_conditioning=s.to(DEV), v_conditionings=[a.to(DEV) for a in v])
+        assert torch.isfinite(out).all()
+        k, pk_hip, n_hip = utils.pk(out)                  # rocFFT on the device tensor
+        assert pk_hip.shape == (1, D // 2) and torch.equal(n_hip.cpu(), n_ref)
+        ratio = (pk_hip.cpu() / pk_ref).numpy()
+        assert abs(ratio - 1).max() < tol_pk, f"{precision}: P(k) ratio off by {abs(ratio - 1).max():.3e}"
+        if precision == "fp32":
+            err = (out.cpu() - ref).abs().max().item()
+            assert err <= 2e-3 * ref.abs().max().item(), f"fp32 sampler err {err} vs max|ref| {ref.abs().max().item()}"
+        del vdm, net
+        torch.cuda.empty_cache()

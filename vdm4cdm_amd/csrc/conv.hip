@@ -1242,10 +1242,23 @@ static Plan plan_of(const vdm_conv_desc* d, int dgrad) {
 
 static int cu_count();
 
+static int current_device() {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0) dev = 0;
+    return dev;
+}
+
+// The dynamic-LDS limit of a kernel is a per-device attribute: `done_mask` (one static per kernel instantiation) has one bit per
+// device ordinal, so a process that drives several GPUs raises the limit on each of them.
 template <typename K>
-static int set_lds(K kernel, size_t bytes) {
-    return check_hip(hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes),
-                     "hipFuncSetAttribute(MaxDynamicSharedMemorySize)");
+static int set_lds(K kernel, size_t bytes, unsigned long long& done_mask) {
+    const int dev = current_device();
+    if (dev < 64 && ((done_mask >> dev) & 1ull)) return VDM_OK;
+    int e = check_hip(hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes),
+                      "hipFuncSetAttribute(MaxDynamicSharedMemorySize)");
+    if (e) return e;
+    if (dev < 64) done_mask |= 1ull << dev;
+    return VDM_OK;
 }
 
 template <typename T, typename TO, int KS, int STRIDE, int UPS, int NC, int TZ, int TY, bool SPLIT = false>
@@ -1256,11 +1269,10 @@ static int launch_fwd_cfg(const ConvArgs& a0, hipStream_t s) {
     a.ntz = cdiv(a.Dz, TZ); a.nty = cdiv(a.Dy, TY); a.ntx = cdiv(a.Dx, 16);
     const size_t lds = (size_t)((G::HVOX + 15) / 16) * 1024 + GN_SCRATCH_BYTES;
     auto kern = conv_fwd_kernel<T, TO, KS, STRIDE, UPS, NC, TZ, TY, SPLIT>;
-    static bool attr_done = false;
-    if (!attr_done) {
-        int e = set_lds(kern, lds);
+    static unsigned long long lds_done = 0;
+    {
+        int e = set_lds(kern, lds, lds_done);
         if (e) return e;
-        attr_done = true;
     }
     const long long nwg = (long long)a.N * a.ntz * a.nty * a.ntx * a.nchunks;
     if (nwg > 0x7fffffffLL) { set_error("conv: grid too large"); return VDM_ERR_ARG; }
@@ -1269,12 +1281,13 @@ static int launch_fwd_cfg(const ConvArgs& a0, hipStream_t s) {
     return VDM_OK;
 }
 
-static int cu_count() {
-    static int n = 0;
+static int cu_count() {                                   // of the current device (cached per device ordinal)
+    static int cached[64] = {0};
+    const int dev = current_device();
+    int n = dev < 64 ? cached[dev] : 0;
     if (n == 0) {
-        int dev = 0;
-        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0)
-            n = 256;
+        if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
+        if (dev < 64) cached[dev] = n;
     }
     return n;
 }
@@ -1392,11 +1405,10 @@ static int launch_wgrad_cfg(WgradArgs w, float* dw, float* dbias, int accumulate
     w.bslabs = dbias ? reinterpret_cast<float*>(reinterpret_cast<char*>(w.slabs) + slab_bytes) : nullptr;
     const size_t lds = (size_t)((G::HVOX + 15) / 16) * 1024 + (size_t)G::OVOX * 64;
     auto kern = conv_wgrad_kernel<T, KS, STRIDE, UPS, TZ, TY, NTA, NTB>;
-    static bool attr_done = false;
-    if (!attr_done) {
-        int e = set_lds(kern, lds);
+    static unsigned long long lds_done = 0;
+    {
+        int e = set_lds(kern, lds, lds_done);
         if (e) return e;
-        attr_done = true;
     }
     hipLaunchKernelGGL(kern, dim3(npairs * P), dim3(256), lds, s, w);
     VDM_LAUNCH_CHECK("conv_wgrad_kernel");
@@ -1432,11 +1444,10 @@ static int launch_wgrad_cls(WgradArgs w, float* dw, float* dbias, int accumulate
     w.bslabs = dbias ? reinterpret_cast<float*>(reinterpret_cast<char*>(w.slabs) + slab_bytes) : nullptr;
     const size_t lds = (size_t)((G::HVOX + 15) / 16) * 1024 + (size_t)G::OVOX * 64;
     auto kern = conv_wgrad_kernel<T, 3, 1, 2, TZ, TY>;
-    static bool attr_done = false;
-    if (!attr_done) {
-        int e = set_lds(kern, lds);
+    static unsigned long long lds_done = 0;
+    {
+        int e = set_lds(kern, lds, lds_done);
         if (e) return e;
-        attr_done = true;
     }
     hipLaunchKernelGGL(kern, dim3(npairs * P), dim3(256), lds, s, w);
     VDM_LAUNCH_CHECK("conv_wgrad_kernel(class)");
@@ -1520,11 +1531,10 @@ static int launch_cls_cfg(const ClsArgs& ca0, hipStream_t s) {
     a.ntz = cdiv(a.Dz, G::TZ); a.nty = cdiv(a.Dy, G::TY); a.ntx = cdiv(a.Dx, 16);
     const size_t lds = (size_t)((G::HVOX + 15) / 16) * 1024 + GN_SCRATCH_BYTES;
     auto kern = conv_cls_kernel<T, NC, MODE>;
-    static bool attr_done = false;
-    if (!attr_done) {
-        int e = set_lds(kern, lds);
+    static unsigned long long lds_done = 0;
+    {
+        int e = set_lds(kern, lds, lds_done);
         if (e) return e;
-        attr_done = true;
     }
     const long long nwg = (long long)a.N * a.ntz * a.nty * a.ntx * a.nchunks * (MODE == 0 ? 8 : 1);
     if (nwg > 0x7fffffffLL) { set_error("conv(class): grid too large"); return VDM_ERR_ARG; }
@@ -1730,14 +1740,15 @@ extern "C" int vdm_conv_pack_plan(const vdm_conv_desc* d, int pack_mode, const f
 extern "C" int vdm_conv_pack_many(const vdm_pack_item* items_dev, const vdm_pack_chunk* chunks_dev, int nchunks, int dtype, void* stream) {
     VDM_REQUIRE(items_dev && chunks_dev && nchunks > 0, "conv_pack_many: empty work list");
     VDM_REQUIRE(dtype == VDM_F32 || dtype == VDM_BF16, "conv_pack_many: bad dtype %d", dtype);
-    static bool masks_up = false;
-    if (!masks_up) {
+    static unsigned long long masks_up = 0;                 // per device ordinal (the symbol lives in each device's copy of the module)
+    const int dev = current_device();
+    if (dev >= 64 || !((masks_up >> dev) & 1ull)) {
         ClsMasks h[3];
         ClsTable tab;
         for (int k = 0; k < 3; ++k) build_cls(k, tab, h[k]);
         int e = check_hip(hipMemcpyToSymbol(HIP_SYMBOL(g_cls_masks), h, sizeof(h)), "hipMemcpyToSymbol(g_cls_masks)");
         if (e) return e;
-        masks_up = true;
+        if (dev < 64) masks_up |= 1ull << dev;
     }
     hipStream_t s = (hipStream_t)stream;
     if (dtype == VDM_F32)

@@ -104,7 +104,7 @@ def _contig(*ts):
 class Conv:
     """One convolution layer: descriptor factory + packed-weight buffers (fwd / dgrad order)."""
 
-    _ws = {}          # device -> shared wgrad workspace (uint8 tensor)
+    _ws = {}          # (device, stream) -> wgrad workspace (uint8 tensor): launches on one stream are ordered, streams never share
 
     def __init__(self, cin, cout, ksize=3, stride=1, upsample=0, circular=False, out_f32=False):
         self.cin, self.cout, self.ksize, self.stride, self.upsample = cin, cout, ksize, stride, upsample
@@ -240,10 +240,11 @@ class Conv:
         assert c == cpad(self.cout, dout.dtype) and x.shape[-1] == cpad(self.cin, x.dtype)
         d = self.desc(n, od, oh, ow, x.dtype)
         need = L.vdm_conv_wgrad_workspace_bytes(d)
-        ws = Conv._ws.get(x.device)
+        wkey = (x.device, _s())
+        ws = Conv._ws.get(wkey)
         if ws is None or ws.numel() < need:
             ws = torch.empty(max(need, 32 << 20), dtype=torch.uint8, device=x.device)
-            Conv._ws[x.device] = ws
+            Conv._ws[wkey] = ws
         ev = _pb()
         check(L.vdm_conv_wgrad(d, _p(x), _p(dout), _p(dw), _p(dbias), 1 if accumulate else 0, _p(ws), ws.numel(), _s()), "vdm_conv_wgrad")
         if ev is not None:
@@ -267,9 +268,9 @@ def gn_stats(x1, x2, groups, out=None):
     n, v = _nv(x1)
     if out is None:
         out = torch.empty((n, groups, 2), dtype=torch.float32, device=x1.device)
-    ws = _gn_ws.get(x1.device)
+    ws = _gn_ws.get((x1.device, _s()))
     if ws is None:
-        ws = _gn_ws[x1.device] = torch.empty(_lib.GN_STATS_WS_BYTES // 4, dtype=torch.float32, device=x1.device)
+        ws = _gn_ws[(x1.device, _s())] = torch.empty(_lib.GN_STATS_WS_BYTES // 4, dtype=torch.float32, device=x1.device)
     c2 = 0 if x2 is None else x2.shape[-1]
     p1 = getattr(x1, "gn_partials", None)       # set by Conv.fwd(..., gn=True): that source needs no pass over the tensor
     p2 = getattr(x2, "gn_partials", None) if x2 is not None else None

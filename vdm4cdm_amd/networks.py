@@ -201,15 +201,37 @@ class CUNet(nn.Module):
             out[prefix + name] = v if keep_vars else v.detach().clone()
         return out
 
+    def _convert_entry(self, name, value):
+        """A checkpoint tensor -> this layout.  Exact shape, or for conv weights the PyTorch / Lightning layout
+        [cout, cin, *k] (permuted to tap-major [taps, cout, cin]).  Anything else raises: equal element counts are not enough
+        (a reshape would silently scramble a [cout, cin, 3, 3, 3] weight)."""
+        want = self.view(name).shape
+        v = value.detach().to(torch.float32)
+        if tuple(v.shape) == tuple(want):
+            return v
+        if len(want) == 3 and v.dim() == 2 + self.dim and v.shape[0] == want[1] and v.shape[1] == want[2] \
+                and math.prod(v.shape[2:]) == want[0]:
+            return v.permute(*range(2, 2 + self.dim), 0, 1).reshape(want)
+        raise RuntimeError(f"CUNet.load_state_dict: {name} has shape {tuple(v.shape)}, expected {tuple(want)}"
+                           + (f" or (cout, cin, {'k, ' * self.dim}) = ({want[1]}, {want[2]}, ...)" if len(want) == 3 else ""))
+
     def load_state_dict(self, state_dict, strict=True):
-        missing = [k for k in self.spec.items if k not in state_dict]
-        unexpected = [k for k in state_dict if k not in self.spec.items]
+        sd = dict(state_dict)
+        # a concatenated 1^dim skip weight [cout, c1+c2, 1..] (the reference concatenates the skip tensor) -> skip / skip2
+        for b in self.blocks:
+            k1, k2 = f"{b.name}.skip.weight", f"{b.name}.skip2.weight"
+            if b.has_skip and b.c2 and k1 in sd and k2 not in sd and sd[k1].dim() == 2 + self.dim and sd[k1].shape[1] == b.c1 + b.c2:
+                w = sd[k1]
+                sd[k1], sd[k2] = w[:, :b.c1].contiguous(), w[:, b.c1:].contiguous()
+        missing = [k for k in self.spec.items if k not in sd]
+        unexpected = [k for k in sd if k not in self.spec.items]
         if strict and (missing or unexpected):
             raise RuntimeError(f"CUNet.load_state_dict: missing {missing[:5]}... unexpected {unexpected[:5]}...")
         with torch.no_grad():
             for name in self.spec.items:
-                if name in state_dict:
-                    self.view(name).copy_(state_dict[name].reshape(self.view(name).shape))
+                if name in sd:
+                    self.view(name).copy_(self._convert_entry(name, sd[name]))
+        self.mark_weights_dirty()
         return missing, unexpected
 
     # ------------------------------------------------------------------ conditioning (tiny; PyTorch)

@@ -67,7 +67,7 @@ class _Res:
             out.append((self.skip2, n + ".skip2.weight"))
         return out
 
-    def fwd(self, P, x1, x2, table, train, seed, ss):
+    def fwd(self, P, x1, x2, table, save, p, seed, ss):
         i, G, n = self.i, self.net.norm_groups, self.i.name
         skip_out = []
         if self.skip1 is not None:               # the 1x1 skip convs (HBM-bound) overlap with conv1 on the side stream
@@ -81,7 +81,6 @@ class _Res:
         a1 = ops.gn_silu_fwd(x1, x2, G, st1, P(n + ".norm1.weight"), P(n + ".norm1.bias"))
         h = self.conv1.fwd(a1, P(n + ".conv1.bias"), table[:, i.table_off:i.table_off + i.cout], gn=FUSED_GN)
         st2 = ops.gn_stats(h, None, G)
-        p = self.net.dropout_prob if train else 0.0
         a2 = ops.gn_silu_fwd(h, None, G, st2, P(n + ".norm2.weight"), P(n + ".norm2.bias"), p, seed)
         if self.skip1 is not None:
             ss.join()
@@ -91,7 +90,7 @@ class _Res:
         else:
             s = x1
         out = self.conv2.fwd(a2, P(n + ".conv2.bias"), None, s, gn=FUSED_GN)     # (every block output feeds a GroupNorm)
-        if train:
+        if save:
             self.saved = (x1, x2, st1, a1, h, st2, a2, p, seed)
         return out
 
@@ -190,9 +189,13 @@ class HipUNet:
         return self._ss
 
     # ---------------------------------------------------------------------------------------
-    def forward(self, flat, table, z, s_cond, train, seed):
-        """z, s_cond: fp32 [N, D, H, W] (single channel).  Returns eps_hat fp32 [N, D, H, W]."""
+    def forward(self, flat, table, z, s_cond, train, seed, dropout_p=None):
+        """z, s_cond: fp32 [N, D, H, W] (single channel).  Returns eps_hat fp32 [N, D, H, W].
+        train: save the activations the backward pass needs (autograd is recording).  dropout_p: dropout probability of this
+        call (None: net.dropout_prob in training mode, 0 in eval mode - the nn.Dropout / F.dropout(training=self.training)
+        semantics of the reference stack, independent of whether autograd records)."""
         net = self.net
+        p = (net.dropout_prob if net.training else 0.0) if dropout_p is None else float(dropout_p)
         dtype = torch.bfloat16 if net.precision == "bf16" else torch.float32
         self.pack_weights(flat, dtype, train)
         P = lambda name: net.view(name, flat)
@@ -202,17 +205,17 @@ class HipUNet:
         h = self.conv_in.fwd(xin, P("conv_in.bias"), gn=FUSED_GN)
         skips = []
         for i in range(L):
-            h = self.res[f"downs.{i}.block"].fwd(P, h, None, table, train, seed + 2 * i, ss)
+            h = self.res[f"downs.{i}.block"].fwd(P, h, None, table, train, p, seed + 2 * i, ss)
             if i != L - 1:
                 skips.append(h)
                 h = self.down[i].fwd(h, P(f"downs.{i}.down.bias"), gn=FUSED_GN)
         for j in range(2):
-            h = self.res[f"mid.{j}"].fwd(P, h, None, table, train, seed + 100 + j, ss)
+            h = self.res[f"mid.{j}"].fwd(P, h, None, table, train, p, seed + 100 + j, ss)
         coarse = []
         for i in reversed(range(L - 1)):
             coarse.append(h)
             u = self.up[i].fwd(h, P(f"ups.{i}.up.bias"), gn=FUSED_GN)
-            h = self.res[f"ups.{i}.block"].fwd(P, u, skips[i], table, train, seed + 200 + i, ss)
+            h = self.res[f"ups.{i}.block"].fwd(P, u, skips[i], table, train, p, seed + 200 + i, ss)
         st = ops.gn_stats(h, None, net.norm_groups)
         a = ops.gn_silu_fwd(h, None, net.norm_groups, st, P("norm_out.weight"), P("norm_out.bias"))
         eps = self.conv_out.fwd(a, P("conv_out.bias"))
@@ -281,6 +284,11 @@ class _HipUNetFn(torch.autograd.Function):
 _seed_counter = [0]
 
 
+def _dist_rank():
+    import torch.distributed as dist
+    return dist.get_rank() if dist.is_available() and dist.is_initialized() else 0
+
+
 def hip_unet_apply(net, x, s_conditioning, table):
     """x: [B, 1, D, H, W] fp32 on the GPU (NCDHW API; C == 1 so NDHWC is the same memory)."""
     if net._exec is None:
@@ -293,8 +301,11 @@ def hip_unet_apply(net, x, s_conditioning, table):
         s = s_conditioning.to(torch.float32).reshape(B, *x.shape[2:]).contiguous()
         if s.shape[0] != B:
             s = s.expand(B, *s.shape[1:]).contiguous()
+    # `train` here means "autograd records: keep the activations for backward"; the dropout probability follows net.training
+    # (HipUNet.forward), exactly like nn.Dropout in the reference stack.
     train = torch.is_grad_enabled() and (net.flat.requires_grad or table.requires_grad)
     _seed_counter[0] += 1000
-    seed = (torch.initial_seed() + _seed_counter[0]) & 0x7fffffffffffffff
+    # per-rank dropout masks under data parallelism: every rank calls seed_everything(42), so fold the rank in
+    seed = (torch.initial_seed() + _seed_counter[0] + 0x9E3779B97F4A7C15 * _dist_rank()) & 0x7fffffffffffffff
     eps = _HipUNetFn.apply(net.flat, table, z, s, net._exec, train, seed)
     return eps.view(x.shape)

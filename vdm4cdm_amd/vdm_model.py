@@ -89,11 +89,24 @@ class VDM(nn.Module):
                                   "script in the reference runs with w_cfg=None")
 
     # ---------------------------------------------------------------- loss (D10)
+    @staticmethod
+    def _rank_world():
+        import torch.distributed as dist
+        if dist.is_available() and dist.is_initialized():
+            return dist.get_rank(), dist.get_world_size()
+        return 0, 1
+
     def sample_times(self, B, device):
+        """D10 antithetic sampling t_i = (u0 + i/B) mod 1, stratified over the GLOBAL batch under data parallelism: every rank
+        seeds identically (seed_everything(42)), so u0 is the same on all ranks and rank r takes strata r*B .. r*B+B-1 of world*B -
+        the variance of the t-sampling shrinks with the world size instead of every rank drawing the same B times."""
+        rank, world = self._rank_world()
         if self.antithetic_time_sampling:
             u0 = torch.rand(1, device=device)
-            return torch.remainder(u0 + torch.arange(B, device=device, dtype=torch.float32) / B, 1.0)
-        return torch.rand(B, device=device)
+            i = torch.arange(B, device=device, dtype=torch.float32) + rank * B
+            return torch.remainder(u0 + i / (world * B), 1.0)
+        t = torch.rand(world * B, device=device)
+        return t[rank * B:(rank + 1) * B]
 
     def get_loss(self, x, times=None, eps=None, eps0=None, **kwargs):
         """Continuous-time ELBO in bits/dim.  Returns (loss, metrics dict)."""
@@ -116,10 +129,11 @@ class VDM(nn.Module):
             if self.noise_schedule != "fixed_linear":
                 raise NotImplementedError("HIP training path supports noise_schedule='fixed_linear' (all 3D scripts); "
                                           "'learned_linear' needs d loss / d z_t which the HIP backward does not emit")
+            rank, _ = self._rank_world()                   # (Philox stream id = 2*rank + {1,2}: different noise fields per rank)
             if eps is None:
-                eps = ops.randn(torch.empty_like(x), int(torch.randint(0, 2 ** 62, (1,)).item()), 1)
+                eps = ops.randn(torch.empty_like(x), int(torch.randint(0, 2 ** 62, (1,)).item()), 2 * rank + 1)
             if eps0 is None:
-                eps0 = ops.randn(torch.empty_like(x), int(torch.randint(0, 2 ** 62, (1,)).item()), 2)
+                eps0 = ops.randn(torch.empty_like(x), int(torch.randint(0, 2 ** 62, (1,)).item()), 2 * rank + 2)
             z_t = ops.diffuse(x, eps.contiguous(), self.alpha(g_t).contiguous(), self.sigma(g_t).contiguous())
             eps_hat = self.get_pred_noise(z_t, g_t, **kwargs)
             w = 0.5 * self.dgamma_dt(times) * bpd / B                      # per-sample weight of S_n
@@ -128,6 +142,10 @@ class VDM(nn.Module):
             sum_x2, sum_r2 = sums[:, 1], sums[:, 2]
         else:
             red = tuple(range(1, x.dim()))
+            rank, world = self._rank_world()
+            if (eps is None or eps0 is None) and world > 1:    # identical host seeds on all ranks: skip to this rank's draws
+                for _ in range(2 * rank):
+                    torch.randn_like(x)
             eps = torch.randn_like(x) if eps is None else eps
             eps0 = torch.randn_like(x) if eps0 is None else eps0
             z_t = self.alpha(g_t).view(bc) * x + self.sigma(g_t).view(bc) * eps
@@ -195,6 +213,8 @@ class VDM(nn.Module):
         if z is None:
             z = torch.randn(shape, device=device) if seed is None else \
                 torch.randn(shape, generator=torch.Generator().manual_seed(int(seed))).to(device)
+        else:
+            z = z.clone()                                    # the HIP path updates z in place: never the caller's tensor
         z = z.to(device=device, dtype=torch.float32).contiguous()
         if self._hip(z) and not return_all:
             return self._sample_hip(z, n_sampling_steps, noises, seed, verbose, use_graph, kwargs)
