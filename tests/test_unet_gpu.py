@@ -464,3 +464,24 @@ def test_c5_sampler_128_power_spectrum():
             assert err <= 2e-3 * ref.abs().max().item(), f"fp32 sampler err {err} vs max|ref| {ref.abs().max().item()}"
         del vdm, net
         torch.cuda.empty_cache()
+
+
+def test_dropout_follows_module_mode_not_autograd():
+    """The dropout probability follows net.training (nn.Dropout semantics of the reference stack); whether autograd records only
+    decides if activations are saved.  eval + grad enabled: no dropout, deterministic, equal to the no_grad result, and the
+    backward still works.  train + no_grad: dropout is active."""
+    net = make_net(precision="fp32", dropout=0.3, **CFGS[0]).to(DEV)
+    x, t, s, v = inputs(net, 2)
+    net.eval()
+    with torch.no_grad():
+        ref = hip_forward(net, x, t, s, v)
+    y1 = hip_forward(net, x, t, s, v)                       # eval, autograd on
+    y2 = hip_forward(net, x, t, s, v)
+    assert y1.requires_grad and torch.equal(y1, ref) and torch.equal(y2, ref)
+    y1.sum().backward()
+    assert net.flat.grad is not None and torch.isfinite(net.flat.grad).all()
+    net.train()
+    with torch.no_grad():
+        d1 = hip_forward(net, x, t, s, v)
+        d2 = hip_forward(net, x, t, s, v)
+    assert not torch.equal(d1, ref) and not torch.equal(d1, d2)
