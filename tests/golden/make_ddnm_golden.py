@@ -81,8 +81,10 @@ def operators(kind, shape, device="cpu"):
     raise ValueError(kind)
 
 
-def case_inputs(case):
-    """Everything a test needs to replay a case: product CUNet with seeded weights (CPU), measurement y, kwargs."""
+def case_inputs(case, gold=None):
+    """Everything a test needs to replay a case: product CUNet with seeded weights (CPU), measurement y, kwargs.
+    The fields y / s_conditioning / v_conditionings come from the fixture when `gold` (the loaded npz) is given: they are made with
+    FFTs here, and FFT round-off differs between host CPUs (the weights are plain seeded uniform/normal draws and do reproduce)."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     sys.path.insert(0, ROOT)
     from helpers import grf, randomize
@@ -92,6 +94,13 @@ def case_inputs(case):
                 norm_groups=8, backend="torch", precision="fp32")
     randomize(net, seed, zero_init_std=0.02)
     shape = (B, 1, D, D, D)
+    if gold is not None:
+        y = torch.from_numpy(gold[f"{name}/y"])
+        kwargs = {}
+        if cond:
+            kwargs = {"s_conditioning": torch.from_numpy(gold[f"{name}/s_conditioning"]),
+                      "v_conditionings": [torch.from_numpy(gold[f"{name}/v_conditioning"])]}
+        return net, y, kwargs
     A, AT = operators(op, shape)
     y = A(grf(shape, 300 + seed))
     kwargs = {}
@@ -159,7 +168,10 @@ def main():
         out[f"{name}/x"] = x_r.numpy()
         out[f"{name}/x_all_absmax"] = x_all.abs().amax(dim=tuple(range(1, x_all.dim()))).numpy()
         out[f"{name}/weights_check"] = np.array([flat.sum().item(), (flat ** 2).sum().item()])
-        out[f"{name}/y_check"] = np.array([y.double().sum().item(), (y.double() ** 2).sum().item()])
+        out[f"{name}/y"] = y.numpy()
+        if cond:
+            out[f"{name}/s_conditioning"] = kwargs["s_conditioning"].numpy()
+            out[f"{name}/v_conditioning"] = kwargs["v_conditionings"][0].numpy()
         out[f"{name}/noise_calls"] = np.array([ns.calls], dtype=np.int64)
         print(name, "x", tuple(x_r.shape), "max|x|", float(x_r.abs().max()), "noise draws", ns.calls)
     np.savez_compressed(OUT, **out)

@@ -77,10 +77,9 @@ def replay_ddnm_case(case, device, backend, precision="fp32"):
     from vdm4cdm_amd.networks import CUNet
     from vdm4cdm_amd.vdm_model import LightVDM
     name, D, chs, seed, B, n, l, op, cond = case
-    net0, y, kwargs = DD.case_inputs(case)
+    net0, y, kwargs = DD.case_inputs(case, DDNM_GOLD)
     flat = net0.flat.detach().double()
     np.testing.assert_allclose([flat.sum().item(), (flat ** 2).sum().item()], DDNM_GOLD[f"{name}/weights_check"], rtol=1e-9)
-    np.testing.assert_allclose([y.double().sum().item(), (y.double() ** 2).sum().item()], DDNM_GOLD[f"{name}/y_check"], rtol=1e-9)
     net = CUNet(shape=net0.shape, chs=net0.chs, s_conditioning_channels=net0.s_conditioning_channels,
                 v_conditioning_dims=net0.v_conditioning_dims, norm_groups=8, backend=backend, precision=precision)
     with torch.no_grad():
