@@ -1,0 +1,575 @@
+// conv_common.h - shared pieces of the convolution kernels (conv_fwd.hip, conv_cls.hip, conv_wgrad.hip, conv_api.hip).
+//
+// 3D convolution as implicit GEMM on the gfx950 matrix cores (K1/K3/K4/K5 of DESIGN.md).
+// Replaces torch.nn.functional.conv3d as reached from mltools' ResNetBlock / ResNetDown / up path
+// (reference call chain: SURVEY.md section 3.2; notebook frames blocks.py:129-132,166-170).
+//
+// Mapping (same for fp32 and bf16 storage; accumulation always fp32):
+//   D[cout][voxel] += W[cout][k] * X[k][voxel],   k = (tap, cin)
+//   MFMA 16x16x32 bf16 (or 16x16x4 f32): A = packed weights (global -> VGPR, fragment order),
+//   B = activations read from an LDS halo tile, D: lane (v = lane&15, q = lane>>4) owns voxel v and
+//   4*NC consecutive output channels -> 16-byte NDHWC stores.
+//   One workgroup = 4 waves = TZ x TY x 16 output voxels x (NC*16) output channels.
+//   LDS halo image: voxel-major, 64 B per halo voxel with the four 16-B pieces x-swizzled (see stage_halo_dma), filled by
+//   LDS-DMA; the 64-lane ds_read_b128 of 16 x-consecutive voxels is bank-conflict-free.
+// Translation units: conv_fwd.hip (generic fwd / dgrad kernel incl. half-chunk workgroups, tap-packed kernel for <= 8 reduction
+//   channels), conv_cls.hip (per-parity-class convs: up-sampling conv fwd / dgrad, stride-2 dgrad), conv_wgrad.hip (weight
+//   gradients + slab reduce kernels), conv_api.hip (weight packers and the C-ABI entry points).
+#pragma once
+#include <stdarg.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include "common.h"
+
+namespace vdm {
+
+static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
+static constexpr int GN_SCRATCH_BYTES = 4 * 64 * 2 * 4;      // 4 waves x (NC <= 4) * 16 channels x (sum, sumsq) floats
+
+// ---------------------------------------------------------------------------------------------
+// geometry
+// ---------------------------------------------------------------------------------------------
+template <int KS_, int STRIDE_, int TZ_, int TY_>
+struct Geo {
+    static constexpr int KS = KS_, STRIDE = STRIDE_, TZ = TZ_, TY = TY_, TX = 16;
+    static constexpr int PAD = KS / 2;
+    static constexpr int TAPS = KS * KS * KS;
+    static constexpr int HZ = (TZ - 1) * STRIDE + KS, HY = (TY - 1) * STRIDE + KS, HX = (TX - 1) * STRIDE + KS;
+    static constexpr int HVOX = HZ * HY * HX;
+    static constexpr int ROWS = TZ * TY;                 // 16-voxel MFMA columns-tiles per workgroup
+    static constexpr int NV = ROWS / 4;                  // per wave
+    static constexpr int OVOX = ROWS * 16;
+    static_assert(ROWS % 4 == 0, "rows must split over 4 waves");
+};
+
+struct ConvArgs {
+    const void* x;       // staged operand (input for fwd/wgrad, dOut for dgrad)
+    const void* w;       // packed weights
+    const float* bias;
+    const float* nbias;
+    long long nbias_stride;
+    const void* res;
+    void* out;
+    int N, Dz, Dy, Dx;   // output spatial dims
+    int Iz, Iy, Ix;      // logical input grid the taps index
+    int Sz, Sy, Sx;      // source tensor dims (== I, or I/2 when up-sampling)
+    int Cin, CinStride;  // reduction channels, channel stride of x
+    int Cout;            // output channels (exact stride of out / res)
+    int circular;
+    int ntz, nty, ntx, nchunks, nkb;
+    float* gnp;          // optional GroupNorm partials of the output: [N][ntz*nty*ntx][Cout][2] = (sum, sum of squares) per tile
+};
+
+__device__ __forceinline__ int wrap(int i, int n) {
+    i %= n;
+    return i < 0 ? i + n : i;
+}
+
+// 64 zero bytes: source of every padded / out-of-range piece of the LDS-DMA staging below.
+// (one copy per translation unit: no relocatable device code needed)
+static __device__ uint4 g_zero_page[16];
+
+// LDS image of the forward kernel: voxel-major, 64 B per halo voxel, the four 16-B pieces of a voxel stored at
+// slot = piece ^ ((hx >> 1) & 3), hx = x position inside the halo row.  With this swizzle the MFMA operand read
+// (ds_read_b128, 16 x-consecutive voxels x 4 k-chunks) is bank-conflict-free for every row alignment, and the
+// (dz, dy, row) shifts stay compile-time ds_read offsets.
+// Filled by LDS-DMA (global_load_lds_dwordx4): one wave-instruction = 16 voxels x 64 B = 1 KiB of LDS written
+// linearly; the four lanes of a voxel fetch its (permuted) pieces, i.e. whole 64-B segments of the NDHWC row.
+template <typename T, typename G, int UPS>
+__device__ __forceinline__ void stage_halo_dma(char* lds, const T* __restrict__ x, const ConvArgs& a, int n,
+                                               int oz0, int oy0, int ox0, int kb, int wave, int lane, int nwaves = 4) {
+    constexpr int EPL = DT<T>::EPL, KB = DT<T>::KB;
+    constexpr int NCHUNK = (G::HVOX + 15) / 16;
+    const int iz0 = oz0 * G::STRIDE - G::PAD, iy0 = oy0 * G::STRIDE - G::PAD, ix0 = ox0 * G::STRIDE - G::PAD;
+    const int k = lane >> 2, j = lane & 3;
+    for (int c = wave; c < NCHUNK; c += nwaves) {
+        const int hv = c * 16 + k;
+        const int hx = hv % G::HX;
+        const int t = hv / G::HX;
+        const int hy = t % G::HY;
+        const int hz = t / G::HY;
+        const int pc = j ^ ((hx >> 1) & 3);
+        int iz = iz0 + hz, iy = iy0 + hy, ix = ix0 + hx;
+        const int ci = kb * KB + pc * EPL;
+        bool ok = ci < a.Cin && hv < G::HVOX;
+        if (a.circular) {
+            iz = wrap(iz, a.Iz); iy = wrap(iy, a.Iy); ix = wrap(ix, a.Ix);
+        } else {
+            ok = ok && (unsigned)iz < (unsigned)a.Iz && (unsigned)iy < (unsigned)a.Iy && (unsigned)ix < (unsigned)a.Ix;
+        }
+        if (UPS) { iz >>= 1; iy >>= 1; ix >>= 1; }
+        const size_t off = ((((size_t)n * a.Sz + iz) * a.Sy + iy) * a.Sx + ix) * a.CinStride + ci;
+        const void* src = ok ? static_cast<const void*>(x + off) : static_cast<const void*>(g_zero_page);
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                         (__attribute__((address_space(3))) void*)(lds + c * 1024), 16, 0, 0);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// MFMA wrappers: acc[16 cout x 16 voxel] += A(16 cout x 64 B of k) * B(64 B of k x 16 voxel)
+// ---------------------------------------------------------------------------------------------
+template <typename T> __device__ __forceinline__ void mma16(f32x4& acc, const uint4& a, const uint4& b);
+template <> __device__ __forceinline__ void mma16<bf16_t>(f32x4& acc, const uint4& a, const uint4& b) {
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), acc, 0, 0, 0);
+}
+template <> __device__ __forceinline__ void mma16<float>(f32x4& acc, const uint4& a, const uint4& b) {
+    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(__builtin_bit_cast(float, a.x), __builtin_bit_cast(float, b.x), acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(__builtin_bit_cast(float, a.y), __builtin_bit_cast(float, b.y), acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(__builtin_bit_cast(float, a.z), __builtin_bit_cast(float, b.z), acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(__builtin_bit_cast(float, a.w), __builtin_bit_cast(float, b.w), acc, 0, 0, 0);
+}
+
+// XCD-aware, bijective block remap: blocks b and b+8 share an XCD (observed round-robin), so give
+// each XCD a contiguous run of spatial tiles (their halos overlap -> hits in that XCD's L2).
+__device__ __forceinline__ int xcd_remap(int bid, int nwg) {
+    const int xcd = bid & 7, q = nwg >> 3, r = nwg & 7;
+    return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+}
+
+// ---------------------------------------------------------------------------------------------
+// forward / dgrad kernel
+// ---------------------------------------------------------------------------------------------
+// Operand-read addressing (see stage_halo_dma): address = lanex[dx] + immediate((v, dz, dy) row shifts).
+// lanex[dx] = wave's first row + this lane's voxel (hx = lx*S + dx) + swizzled k-chunk slot.
+template <typename G, int NV>
+__device__ __forceinline__ void operand_lane_offsets(int (&lanex)[G::KS], int cwave, int lane) {
+    static_assert(G::TY % NV == 0, "a wave's rows must stay inside one z-slab");
+    const int lx = lane & 15, q = lane >> 4;
+    const int r0 = cwave * NV;
+    const int wavebase = (((r0 / G::TY) * G::STRIDE) * G::HY + (r0 % G::TY) * G::STRIDE) * G::HX * 64;
+#pragma unroll
+    for (int dx = 0; dx < G::KS; ++dx) {
+        const int hx = lx * G::STRIDE + dx;
+        lanex[dx] = wavebase + hx * 64 + ((q * 16) ^ ((hx & 6) << 3));
+    }
+}
+
+template <int NC> struct WPipe { static constexpr int WPD = (NC <= 2) ? 2 : 1; };   // weight prefetch depth (taps)
+
+// bf16: first WPD taps' weights (issued before the staging barrier so their latency overlaps it)
+template <int TAPS, int NC, int WPD, int NCW = NC>
+__device__ __forceinline__ void taps_prefetch_weights(uint4 (&wf)[WPD + 1][NC], const uint4* wk) {
+#pragma unroll
+    for (int p = 0; p < WPD && p < TAPS; ++p)
+#pragma unroll
+        for (int c = 0; c < NC; ++c) wf[p][c] = wk[(p * NCW + c) * 64];
+}
+
+// bf16: explicit software pipeline over the fully unrolled taps.
+//   weights (global, L2-resident)  : WPD taps ahead, ring of WPD+1 register sets
+//   activations (LDS)              : one tap ahead, two register sets of NV fragments
+// sched_barrier(0) pins [issue next operands] | [MFMAs of this tap] so the loads stay early.
+template <typename T, typename G, int NC, int NV, int WPD, int NCW = NC>
+__device__ __forceinline__ void taps_pipelined(f32x4 (&acc)[NV][NC], const char* lds, const uint4* wk,
+                                               uint4 (&wf)[WPD + 1][NC], const int (&lanex)[G::KS]) {
+    constexpr int TAPS = G::TAPS, KS = G::KS;
+    constexpr int ROWB = G::STRIDE * G::HX * 64;            // byte shift between consecutive rows v of a wave
+    uint4 af[2][NV];
+#pragma unroll
+    for (int v = 0; v < NV; ++v) af[0][v] = *reinterpret_cast<const uint4*>(lds + lanex[0] + v * ROWB);
+#pragma unroll
+    for (int tap = 0; tap < TAPS; ++tap) {
+        if (tap + WPD < TAPS) {
+#pragma unroll
+            for (int c = 0; c < NC; ++c) wf[(tap + WPD) % (WPD + 1)][c] = wk[((tap + WPD) * NCW + c) * 64];
+        }
+        if (tap + 1 < TAPS) {
+            const int t1 = tap + 1;
+            const int dz = t1 / (KS * KS), dy = (t1 / KS) % KS, dx = t1 % KS;
+            const int toff = (dz * G::HY + dy) * G::HX * 64;
+#pragma unroll
+            for (int v = 0; v < NV; ++v) af[t1 & 1][v] = *reinterpret_cast<const uint4*>(lds + lanex[dx] + v * ROWB + toff);
+        }
+#pragma unroll
+        for (int v = 0; v < NV; ++v)
+#pragma unroll
+            for (int c = 0; c < NC; ++c) mma16<T>(acc[v][c], wf[tap % (WPD + 1)][c], af[tap & 1][v]);
+        // Interleave: the NC weight loads first, then one LDS read of the NEXT tap after every NC MFMAs of THIS tap
+        // (masks: 0x8 MFMA, 0x20 VMEM read, 0x100 DS read).  Keeps the matrix pipe fed while the loads issue.
+        __builtin_amdgcn_sched_group_barrier(0x20, NC, 0);
+#pragma unroll
+        for (int v = 0; v < NV; ++v) {
+            __builtin_amdgcn_sched_group_barrier(0x8, NC, 0);
+            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    }
+}
+
+// fp32 (exact v_mfma_f32_16x16x4_f32, 1/16 of the bf16 rate): MFMA-bound.  Rolled tap loop (low register pressure), the
+// next tap's weights are loaded before this tap's MFMAs, and the 4 k-steps of a fragment pair are issued STEP-MAJOR over the
+// NV x NC independent accumulators (a dependent fp32 MFMA has 40 cycles of latency vs 32 of issue).
+template <typename T, typename G, int NC, int NV>
+__device__ __forceinline__ void taps_rolled(f32x4 (&acc)[NV][NC], const char* lds, const uint4* wk, const int (&lanex)[G::KS]) {
+    constexpr int TAPS = G::TAPS, KS = G::KS;
+    constexpr int ROWB = G::STRIDE * G::HX * 64;
+    uint4 wn[NC];
+#pragma unroll
+    for (int c = 0; c < NC; ++c) wn[c] = wk[c * 64];
+#pragma unroll 1
+    for (int tap = 0; tap < TAPS; ++tap) {
+        const int dz = tap / (KS * KS), dy = (tap / KS) % KS, dx = tap % KS;
+        const int toff = (dz * G::HY + dy) * G::HX * 64;
+        const int lx0 = (dx == 0) ? lanex[0] : ((dx == 1) ? lanex[KS > 1 ? 1 : 0] : lanex[KS > 2 ? 2 : 0]);
+        uint4 wf[NC], af[NV];
+#pragma unroll
+        for (int c = 0; c < NC; ++c) wf[c] = wn[c];
+        const int tn = tap + 1 < TAPS ? tap + 1 : tap;
+#pragma unroll
+        for (int c = 0; c < NC; ++c) wn[c] = wk[(tn * NC + c) * 64];
+#pragma unroll
+        for (int v = 0; v < NV; ++v) af[v] = *reinterpret_cast<const uint4*>(lds + lx0 + v * ROWB + toff);
+#pragma unroll
+        for (int st = 0; st < 4; ++st)
+#pragma unroll
+            for (int v = 0; v < NV; ++v)
+#pragma unroll
+                for (int c = 0; c < NC; ++c) {
+                    const uint32_t aw = st == 0 ? wf[c].x : (st == 1 ? wf[c].y : (st == 2 ? wf[c].z : wf[c].w));
+                    const uint32_t bw = st == 0 ? af[v].x : (st == 1 ? af[v].y : (st == 2 ? af[v].z : af[v].w));
+                    acc[v][c] = __builtin_amdgcn_mfma_f32_16x16x4f32(__builtin_bit_cast(float, aw), __builtin_bit_cast(float, bw), acc[v][c], 0, 0, 0);
+                }
+    }
+}
+
+// GroupNorm statistics fused into the producing conv: per-channel (sum, sum of squares) of the output values of one tile, taken
+// from the fp32 results before they are rounded for storage (the rounding errors are zero-mean: the moments of the stored tensor
+// differ by ~2^-9 / sqrt(#voxels) relative).  Lane sums over its rows -> xor-butterfly over the 16 voxel lanes -> the four waves fold through a small LDS
+// scratch in a fixed order (deterministic) -> one partial per (sample, tile, channel).  vdm_gn_stats_from_partials sums the
+// tiles and the channels of a group.  `sm` = NC*16*2*4 floats of LDS that no wave still reads as operand image.
+// sum over the 16 lanes of a DPP row (= the 16 voxels of an MFMA column block), result in every lane: 4 x v_add_f32 with a
+// rotated second operand (row_ror:8/4/2/1) - no LDS crossbar traffic
+__device__ __forceinline__ float row16_sum(float v) {
+#define VDM_ROR_ADD(n)                                                                                                          \
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x120 + (n), 0xf, 0xf, false))
+    VDM_ROR_ADD(8);
+    VDM_ROR_ADD(4);
+    VDM_ROR_ADD(2);
+    VDM_ROR_ADD(1);
+#undef VDM_ROR_ADD
+    return v;
+}
+
+template <int NC>
+__device__ __forceinline__ void gn_partials_reduce(float (&gs)[NC * 4], float (&gq)[NC * 4], float* sm, float* dst /* [Cout][2] of this tile */,
+                                                   int cout0, int Cout, int wave, int lane, int qstride = NC * 4) {
+    const int lx = lane & 15, q = lane >> 4;
+#pragma unroll
+    for (int j = 0; j < NC * 4; ++j) {
+        gs[j] = row16_sum(gs[j]);
+        gq[j] = row16_sum(gq[j]);
+    }
+    if (lx == 0) {
+#pragma unroll
+        for (int j = 0; j < NC * 4; ++j) {
+            sm[((wave * NC * 16) + q * NC * 4 + j) * 2] = gs[j];
+            sm[((wave * NC * 16) + q * NC * 4 + j) * 2 + 1] = gq[j];
+        }
+    }
+    __syncthreads();
+    const int t = wave * 64 + lane;
+    if (t < NC * 16 * 2) {
+        const int c = ((t >> 1) / (NC * 4)) * qstride + (t >> 1) % (NC * 4);      // lane group q owns NC*4 channels every qstride
+        const float tot = (sm[t] + sm[NC * 16 * 2 + t]) + (sm[2 * NC * 16 * 2 + t] + sm[3 * NC * 16 * 2 + t]);
+        if (cout0 + c < Cout) dst[(size_t)(cout0 + c) * 2 + (t & 1)] = tot;
+    }
+}
+
+// epilogue: + bias + per-sample conditioning bias + residual, cast, 16-byte NDHWC stores
+template <typename T, typename TO, typename G, int NC, int NV>
+__device__ __forceinline__ void conv_epilogue(const f32x4 (&acc)[NV][NC], const ConvArgs& a, int n, int chunk, int oz0, int oy0,
+                                              int ox0, int cwave, int lane, float* gn_sm = nullptr, int tile = 0, int cout0 = -1,
+                                              int qstride = NC * 4) {
+    constexpr int EPL = DT<T>::EPL;
+    float gs[NC * 4], gq[NC * 4];
+#pragma unroll
+    for (int j = 0; j < NC * 4; ++j) gs[j] = gq[j] = 0.f;
+    const int lx = lane & 15, q = lane >> 4;
+    if (cout0 < 0) cout0 = chunk * NC * 16;             // (half-chunk kernels pass their own origin and lane-group stride)
+    const int cbase = cout0 + q * qstride;              // first of this lane's NC*4 consecutive couts
+    float badd[NC * 4];
+#pragma unroll
+    for (int j = 0; j < NC * 4; ++j) {
+        float bv = 0.f;
+        if (cbase + j < a.Cout) {
+            if (a.bias) bv += a.bias[cbase + j];
+            if (a.nbias) bv += a.nbias[(size_t)n * a.nbias_stride + cbase + j];
+        }
+        badd[j] = bv;
+    }
+    const bool vec_ok = (a.Cout % (NC * 4) == 0) && (cbase + NC * 4 <= a.Cout);
+    TO* out = reinterpret_cast<TO*>(a.out);
+    const T* res = reinterpret_cast<const T*>(a.res);
+#pragma unroll
+    for (int v = 0; v < NV; ++v) {
+        const int r = cwave * NV + v;
+        const int oz = oz0 + r / G::TY, oy = oy0 + r % G::TY, ox = ox0 + lx;
+        if (oz >= a.Dz || oy >= a.Dy || ox >= a.Dx) continue;
+        const size_t vo = ((((size_t)n * a.Dz + oz) * a.Dy + oy) * a.Dx + ox) * a.Cout + cbase;
+        float val[NC * 4];
+#pragma unroll
+        for (int c = 0; c < NC; ++c)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) val[c * 4 + j] = acc[v][c][j] + badd[c * 4 + j];
+        if (a.gnp && !vec_ok) {                           // (scalar tail path: residual is added below, element by element)
+#pragma unroll
+            for (int j = 0; j < NC * 4; ++j)
+                if (cbase + j < a.Cout) {
+                    const float r = val[j] + (res ? ld_elem<T>(res + vo + j) : 0.f);
+                    gs[j] += r; gq[j] += r * r;
+                }
+        }
+        if (vec_ok) {
+            if (res) {
+                constexpr int RP = NC * 4 / EPL > 0 ? NC * 4 / EPL : 1;    // 16-B pieces (bf16 NC=1: half piece)
+                if (NC * 4 >= EPL) {
+#pragma unroll
+                    for (int i = 0; i < RP; ++i) {
+                        Piece<T> pr;
+                        pr.load(*reinterpret_cast<const uint4*>(res + vo + i * EPL));
+#pragma unroll
+                        for (int j = 0; j < EPL; ++j) val[i * EPL + j] += pr.f[j];
+                    }
+                } else {
+#pragma unroll
+                    for (int j = 0; j < NC * 4; ++j) val[j] += ld_elem<T>(res + vo + j);
+                }
+            }
+            if (a.gnp) {
+#pragma unroll
+                for (int j = 0; j < NC * 4; ++j) { gs[j] += val[j]; gq[j] += val[j] * val[j]; }
+            }
+            if (sizeof(TO) == 4) {
+#pragma unroll
+                for (int c = 0; c < NC; ++c)
+                    *reinterpret_cast<float4*>(reinterpret_cast<float*>(out) + vo + c * 4) =
+                        make_float4(val[c * 4], val[c * 4 + 1], val[c * 4 + 2], val[c * 4 + 3]);
+            } else {
+                uint16_t* o16 = reinterpret_cast<uint16_t*>(out) + vo;
+                if (NC == 1) {
+                    *reinterpret_cast<uint2*>(o16) = make_uint2(pack_bf16x2(val[0], val[1]), pack_bf16x2(val[2], val[3]));
+                } else {
+#pragma unroll
+                    for (int i = 0; i < NC / 2; ++i)
+                        *reinterpret_cast<uint4*>(o16 + i * 8) =
+                            make_uint4(pack_bf16x2(val[i * 8], val[i * 8 + 1]), pack_bf16x2(val[i * 8 + 2], val[i * 8 + 3]),
+                                       pack_bf16x2(val[i * 8 + 4], val[i * 8 + 5]), pack_bf16x2(val[i * 8 + 6], val[i * 8 + 7]));
+                }
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < NC * 4; ++j) {
+                if (cbase + j < a.Cout) {
+                    float o = val[j];
+                    if (res) o += ld_elem<T>(res + vo + j);
+                    st_elem<TO>(out + vo + j, o);
+                }
+            }
+        }
+    }
+    if (a.gnp)                                            // workgroup-uniform
+        gn_partials_reduce<NC>(gs, gq, gn_sm, a.gnp + ((size_t)n * (a.ntz * a.nty * a.ntx) + tile) * a.Cout * 2, cout0, a.Cout,
+                               cwave, lane, qstride);
+}
+
+struct ClsEntry { int lds_off; int dx; };                   // halo offset ((dz*HY+dy)*HX)*64 bytes and dx in 0..2
+struct ClsTable {
+    int n[8];                                                // entries per class
+    ClsEntry e[8][8];
+};
+struct ClsArgs {
+    ConvArgs c;                                              // Dz/Dy/Dx = COARSE tile index space; out dims in oD*
+    ClsTable t;
+    int oDz, oDy, oDx;                                       // output tensor spatial dims (fine for MODE_F, coarse for MODE_B)
+    int sDz, sDy, sDx;                                       // staged source tensor spatial dims
+};
+struct ClsMasks { unsigned m[64]; };
+
+struct WgradArgs {
+    ConvArgs c;          // c.x = input, c.Cin/CinStride = input channels, c.Cout = dOut channels
+    const void* dout;
+    int dout_stride;
+    float* slabs;        // [pair][P][slot]... see wgrad_reduce
+    float* bslabs;       // optional [cout block][P][CL] partial column sums of dOut (bias gradient), or NULL
+    int P;               // persistent workgroups per (cout block, cin block) pair
+    int ntiles;          // N * ntz * nty * ntx
+    int ncb, nkb;        // cout blocks, cin blocks (64 B each)
+};
+
+template <typename T> struct WG;     // 16x16 tiles per 64-byte channel block
+template <> struct WG<bf16_t> { static constexpr int NT = 2; };
+template <> struct WG<float> { static constexpr int NT = 1; };
+
+// ---------------------------------------------------------------------------------------------
+// host side (shared planning helpers; the launchers live next to their kernels)
+// ---------------------------------------------------------------------------------------------
+// output-channel tiles (of 16) per workgroup.  fp32 is MFMA-bound (weight reuse is irrelevant) and its deep-level grids are
+// small: cap at 2 so that twice as many workgroups exist.
+static int nc_for(int cout, int dtype) { return cout <= 16 ? 1 : ((cout <= 32 || dtype == VDM_F32) ? 2 : 4); }
+static int epl_of(int dtype) { return dtype == VDM_F32 ? 4 : 8; }
+static int kb_of(int dtype) { return dtype == VDM_F32 ? 16 : 32; }
+static int cpad(int c, int dtype) { const int e = epl_of(dtype); return (c + e - 1) / e * e; }
+
+static int validate(const vdm_conv_desc* d) {
+    VDM_REQUIRE(d != nullptr, "conv desc is NULL");
+    VDM_REQUIRE(d->n > 0 && d->od > 0 && d->oh > 0 && d->ow > 0, "conv: bad output dims %d %d %d %d", d->n, d->od, d->oh, d->ow);
+    VDM_REQUIRE(d->cin > 0 && d->cout > 0, "conv: bad channels cin=%d cout=%d", d->cin, d->cout);
+    VDM_REQUIRE(d->ksize == 1 || d->ksize == 3, "conv: ksize must be 1 or 3 (got %d)", d->ksize);
+    VDM_REQUIRE(d->stride == 1 || d->stride == 2, "conv: stride must be 1 or 2 (got %d)", d->stride);
+    VDM_REQUIRE(!(d->stride == 2 && d->ksize != 3), "conv: stride 2 needs ksize 3");
+    VDM_REQUIRE(!(d->upsample && (d->stride != 1 || d->ksize != 3)), "conv: upsample needs stride 1, ksize 3");
+    VDM_REQUIRE(!(d->upsample && ((d->od | d->oh | d->ow) & 1)), "conv: upsample needs even output dims");
+    VDM_REQUIRE(d->dtype == VDM_F32 || d->dtype == VDM_BF16, "conv: bad dtype %d", d->dtype);
+    VDM_REQUIRE(d->pad_mode == VDM_PAD_ZEROS || d->pad_mode == VDM_PAD_CIRCULAR, "conv: bad pad_mode %d", d->pad_mode);
+    return VDM_OK;
+}
+
+struct Plan {           // derived launch parameters of one conv in one direction
+    int taps, nc, nchunks, nkb, O, K;
+};
+static Plan plan_of(const vdm_conv_desc* d, int dgrad) {
+    Plan p;
+    p.taps = d->ksize * d->ksize * d->ksize;
+    p.O = dgrad ? d->cin : d->cout;
+    p.K = dgrad ? d->cout : d->cin;
+    p.nc = nc_for(p.O, d->dtype);
+    p.nchunks = cdiv(p.O, p.nc * 16);
+    p.nkb = cdiv(p.K, kb_of(d->dtype));
+    return p;
+}
+
+static int cu_count();
+
+static int current_device() {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0) dev = 0;
+    return dev;
+}
+
+// The dynamic-LDS limit of a kernel is a per-device attribute: `done_mask` (one static per kernel instantiation) has one bit per
+// device ordinal, so a process that drives several GPUs raises the limit on each of them.
+template <typename K>
+static int set_lds(K kernel, size_t bytes, unsigned long long& done_mask) {
+    const int dev = current_device();
+    if (dev < 64 && ((done_mask >> dev) & 1ull)) return VDM_OK;
+    int e = check_hip(hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes),
+                      "hipFuncSetAttribute(MaxDynamicSharedMemorySize)");
+    if (e) return e;
+    if (dev < 64) done_mask |= 1ull << dev;
+    return VDM_OK;
+}
+
+static int cu_count() {                                   // of the current device (cached per device ordinal)
+    static int cached[64] = {0};
+    const int dev = current_device();
+    int n = dev < 64 ? cached[dev] : 0;
+    if (n == 0) {
+        if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
+        if (dev < 64) cached[dev] = n;
+    }
+    return n;
+}
+
+// Spatial tile of the bf16 3x3x3 stride-1 kernel.  Large grids: 4x8x16 (least halo traffic).  Small grids (deep UNet levels, and
+// everything at batch 1): smaller tiles so that more workgroups exist - a workgroup runs its K-blocks strictly one after the other
+// (stage, barrier, 27 taps), so a deep-level conv is bound by that serial chain unless co-resident workgroups overlap it:
+// 2x8x16 (46 KB LDS, 3 per CU) below 2 workgroups per CU, 1x8x16 / 1x4x16 when even those leave CUs empty.
+static void small_grid_tile(const ConvArgs& a, int& tz, int& ty) {
+    const long long per_sample = (long long)a.nchunks * a.N * cdiv(a.Dx, 16);
+    const long long tiles48 = per_sample * cdiv(a.Dz, 4) * cdiv(a.Dy, 8), tiles28 = per_sample * cdiv(a.Dz, 2) * cdiv(a.Dy, 8);
+    tz = 4; ty = 8;
+    if (tiles48 >= 2LL * cu_count()) return;
+    tz = 2;
+    if (tiles28 >= cu_count()) return;
+    tz = 1;
+    if (2 * tiles28 < cu_count()) ty = 4;
+}
+
+// NC=4 conv with fewer than two workgroups per CU even on the small tiles: half-chunk workgroups (the NC=2 kernel on the same packed
+// weights; bf16 3x3x3 stride 1, not the up-sampling conv)
+static bool uses_split(const ConvArgs& a, int tz, int ty) {
+    const long long wgs = (long long)a.nchunks * a.N * cdiv(a.Dz, tz) * cdiv(a.Dy, ty) * cdiv(a.Dx, 16);
+    return tz <= 2 && wgs < 2LL * cu_count() && a.Cout % 64 == 0 && getenv("VDM4CDM_NO_SPLIT") == nullptr;
+}
+
+static bool uses_kpack(int dtype, int ks, int stride, int ups, int K, int O, int out_f32) {
+    return dtype == VDM_BF16 && ks == 3 && stride == 1 && !ups && K <= 8 && O <= 32 && !out_f32 && getenv("VDM4CDM_NO_KPACK") == nullptr;
+}
+static bool uses_kpack(const vdm_conv_desc* d, int dgrad) {
+    return uses_kpack(d->dtype, d->ksize, d->stride, d->upsample, dgrad ? d->cout : d->cin, dgrad ? d->cin : d->cout, dgrad ? 0 : d->out_f32);
+}
+
+// ---- class-conv tables -----------------------------------------------------------------------
+enum ClsKind { CLS_UP_FWD = 0, CLS_UP_DGRAD = 1, CLS_S2_DGRAD = 2 };
+
+// per-dimension entries of parity p: (coarse offset o, set of master taps merged into the entry)
+static int cls_dim_entries(int kind, int p, int o[2], unsigned tapset[2]) {
+    if (kind == CLS_S2_DGRAD) {
+        if (p == 0) { o[0] = 0; tapset[0] = 1u << 1; return 1; }
+        o[0] = +1; tapset[0] = 1u << 0; o[1] = 0; tapset[1] = 1u << 2; return 2;
+    }
+    if (p == 0) { o[0] = -1; tapset[0] = 1u << 0; o[1] = 0; tapset[1] = (1u << 1) | (1u << 2); return 2; }
+    o[0] = 0; tapset[0] = (1u << 0) | (1u << 1); o[1] = +1; tapset[1] = 1u << 2; return 2;
+}
+
+static void build_cls(int kind, ClsTable& tab, ClsMasks& masks) {
+    using G = Geo<3, 1, 4, 8>;
+    for (int i = 0; i < 64; ++i) masks.m[i] = 0;
+    for (int cl = 0; cl < 8; ++cl) {
+        const int p[3] = {(cl >> 2) & 1, (cl >> 1) & 1, cl & 1};
+        int o[3][2];
+        unsigned ts[3][2];
+        int cnt[3];
+        for (int d = 0; d < 3; ++d) cnt[d] = cls_dim_entries(kind, p[d], o[d], ts[d]);
+        int ne = 0;
+        for (int iz = 0; iz < cnt[0]; ++iz)
+            for (int iy = 0; iy < cnt[1]; ++iy)
+                for (int ix = 0; ix < cnt[2]; ++ix) {
+                    // halo coordinate read by this entry: forward-type kernels read c + o (halo origin -1 -> o + 1);
+                    // the up-conv input gradient reads the class sub-grid at c - o (-> 1 - o)
+                    const int hz = kind == CLS_UP_DGRAD ? 1 - o[0][iz] : o[0][iz] + 1;
+                    const int hy = kind == CLS_UP_DGRAD ? 1 - o[1][iy] : o[1][iy] + 1;
+                    const int hx = kind == CLS_UP_DGRAD ? 1 - o[2][ix] : o[2][ix] + 1;
+                    tab.e[cl][ne].lds_off = (hz * G::HY + hy) * G::HX * 64;
+                    tab.e[cl][ne].dx = hx;
+                    unsigned m = 0;
+                    for (int tz = 0; tz < 3; ++tz)
+                        for (int ty = 0; ty < 3; ++ty)
+                            for (int tx = 0; tx < 3; ++tx)
+                                if (((ts[0][iz] >> tz) & 1) && ((ts[1][iy] >> ty) & 1) && ((ts[2][ix] >> tx) & 1)) m |= 1u << ((tz * 3 + ty) * 3 + tx);
+                    masks.m[cl * 8 + ne] = m;
+                    ++ne;
+                }
+        tab.n[cl] = ne;
+        for (int i = ne; i < 8; ++i) tab.e[cl][i] = tab.e[cl][0];
+    }
+}
+
+static bool uses_cls(const vdm_conv_desc* d, int dgrad) { return d->ksize == 3 && (d->upsample || (dgrad && d->stride == 2)); }
+static int cls_kind(const vdm_conv_desc* d, int dgrad) { return d->upsample ? (dgrad ? CLS_UP_DGRAD : CLS_UP_FWD) : CLS_S2_DGRAD; }
+
+static void fill_dims(ConvArgs& a, const vdm_conv_desc* d) {
+    a.N = d->n; a.Dz = d->od; a.Dy = d->oh; a.Dx = d->ow;
+    a.Iz = d->od * d->stride; a.Iy = d->oh * d->stride; a.Ix = d->ow * d->stride;
+    a.Sz = d->upsample ? a.Iz / 2 : a.Iz; a.Sy = d->upsample ? a.Iy / 2 : a.Iy; a.Sx = d->upsample ? a.Ix / 2 : a.Ix;
+    a.circular = d->pad_mode == VDM_PAD_CIRCULAR;
+}
+
+// spatial tile (TZ, TY; TX = 16) that vdm_conv_fwd will use for this conv - mirrors launch_fwd / launch_fwd_geo
+static void fwd_tile_shape(const ConvArgs& a, int dtype, int out_f32, int ks, int stride, int ups, int& tz, int& ty) {
+    tz = 4; ty = 8;
+    if (stride == 2) { tz = 2; ty = 4; return; }
+    if (uses_kpack(dtype, ks, stride, ups, a.Cin, a.Cout, out_f32)) return;
+    if (ks == 3 && dtype == VDM_BF16) small_grid_tile(a, tz, ty);
+}
+
+// launchers (defined in conv_fwd.hip / conv_cls.hip / conv_wgrad.hip)
+int launch_fwd(const ConvArgs& a, int dtype, int out_f32, int ks, int stride, int ups, int nc, hipStream_t s);
+int run_cls(const vdm_conv_desc* d, int kind, const void* x, const void* w, const float* bias, const void* res, void* out,
+            int cd, int ch, int cw, hipStream_t s, float* gn_partials = nullptr);
+int launch_wgrad_any(const WgradArgs& w, float* dw, float* db, int acc, int cout, int cin, int ks, int stride, int ups, size_t ws,
+                     int dtype, hipStream_t s);
+
+}  // namespace vdm

@@ -1,0 +1,242 @@
+// conv_fwd.hip - generic forward / dgrad convolution kernel and the tap-packed kernel (see conv_common.h).
+#include "conv_common.h"
+
+namespace vdm {
+
+// ---------------------------------------------------------------------------------------------
+// forward / dgrad kernel, one tile per workgroup (all variants; small grids)
+// ---------------------------------------------------------------------------------------------
+// SPLIT (NC == 2 only): the weights are packed for 64-cout chunks (4 tiles per tap) but a workgroup takes HALF a chunk (tiles 2h,
+// 2h+1 = couts 16q + 8h .. +7 of every lane group q): twice the workgroups for the small grids of the deep levels, where a
+// workgroup's K-blocks run strictly one after the other and only co-resident workgroups overlap staging with MFMAs.
+template <typename T, typename TO, int KS, int STRIDE, int UPS, int NC, int TZ, int TY, bool SPLIT = false>
+__global__ void __launch_bounds__(256, (TZ * TY <= 16 && NC <= 2) ? 3 : 2) conv_fwd_kernel(const ConvArgs a) {
+    static_assert(!SPLIT || NC == 2, "half-chunk mode is the NC=2 kernel on NC=4 weights");
+    constexpr int NCW = SPLIT ? 4 : NC;
+    using G = Geo<KS, STRIDE, TZ, TY>;
+    constexpr int NV = G::NV, TAPS = G::TAPS;
+    extern __shared__ __attribute__((aligned(16))) char lds[];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+
+    int b = xcd_remap(blockIdx.x, gridDim.x);
+    const int tx = b % a.ntx; b /= a.ntx;
+    const int ty = b % a.nty; b /= a.nty;
+    const int tz = b % a.ntz; b /= a.ntz;
+    const int n = b % a.N;
+    const int chunk = b / a.N;
+    const int oz0 = tz * TZ, oy0 = ty * TY, ox0 = tx * 16;
+
+    f32x4 acc[NV][NC];
+#pragma unroll
+    for (int v = 0; v < NV; ++v)
+#pragma unroll
+        for (int c = 0; c < NC; ++c) acc[v][c] = f32x4{0.f, 0.f, 0.f, 0.f};
+    int lanex[KS];
+    operand_lane_offsets<G, NV>(lanex, wave, lane);
+
+    const uint4* wbase = reinterpret_cast<const uint4*>(a.w) + (size_t)(SPLIT ? chunk >> 1 : chunk) * a.nkb * TAPS * NCW * 64 +
+                         (SPLIT ? (chunk & 1) * 2 * 64 : 0) + lane;
+    const T* x = reinterpret_cast<const T*>(a.x);
+
+    for (int kb = 0; kb < a.nkb; ++kb) {
+        if (kb) __syncthreads();
+        stage_halo_dma<T, G, UPS>(lds, x, a, n, oz0, oy0, ox0, kb, wave, lane);
+        const uint4* wk = wbase + (size_t)kb * TAPS * NCW * 64;
+        if constexpr (sizeof(T) == 2) {
+            constexpr int WPD = WPipe<NC>::WPD;
+            uint4 wf[WPD + 1][NC];
+            taps_prefetch_weights<TAPS, NC, WPD, NCW>(wf, wk);
+            __syncthreads();
+            taps_pipelined<T, G, NC, NV, WPD, NCW>(acc, lds, wk, wf, lanex);
+        } else {
+            __syncthreads();
+            taps_rolled<T, G, NC, NV>(acc, lds, wk, lanex);
+        }
+    }
+    constexpr int IMG = ((G::HVOX + 15) / 16) * 1024;     // the GN scratch sits behind the operand image
+    if constexpr (SPLIT)
+        conv_epilogue<T, TO, G, NC, NV>(acc, a, n, chunk, oz0, oy0, ox0, wave, lane, reinterpret_cast<float*>(lds + IMG),
+                                        (tz * a.nty + ty) * a.ntx + tx, (chunk >> 1) * 64 + (chunk & 1) * 8, 16);
+    else
+        conv_epilogue<T, TO, G, NC, NV>(acc, a, n, chunk, oz0, oy0, ox0, wave, lane, reinterpret_cast<float*>(lds + IMG),
+                                        (tz * a.nty + ty) * a.ntx + tx);
+}
+
+// ---------------------------------------------------------------------------------------------
+// Tap-packed kernel for the convs with <= 8 input channels (conv_in: 2 -> 32; input gradient of conv_out: 1 -> 32), bf16.
+// One 16-byte piece holds ALL channels of a voxel, so the 32-deep K of an MFMA is filled with 4 TAPS x 8 channels instead of
+// one tap x 32 channels of which 24..31 are padding: 7 tap groups instead of 27 taps (3.9x fewer MFMAs), an LDS image of
+// 16 B per halo voxel (17 KB), one LDS-DMA lane per voxel.  Lane (voxel lx, k-chunk q) reads the voxel shifted by tap 4g+q;
+// the packed weights hold W[tap 4g+q][cout][ci] in the matching A-fragment slot (zero for tap >= 27, ci >= Cin).
+// These convs are bound by writing / reading the 32-channel tensor (HBM), not by MFMA.
+// ---------------------------------------------------------------------------------------------
+template <typename TO, int NC>
+__global__ void __launch_bounds__(256, 4) conv_kpack_kernel(const ConvArgs a) {
+    using T = bf16_t;
+    using G = Geo<3, 1, 4, 8>;
+    constexpr int NV = G::NV, NG = (G::TAPS + 3) / 4;
+    constexpr int NCH = (G::HVOX + 63) / 64;               // DMA chunks of 64 voxels (1 KiB)
+    constexpr int ROWB = G::HX * 16;
+    extern __shared__ __attribute__((aligned(16))) char lds[];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+
+    int b = xcd_remap(blockIdx.x, gridDim.x);
+    const int tx = b % a.ntx; b /= a.ntx;
+    const int ty = b % a.nty; b /= a.nty;
+    const int tz = b % a.ntz; b /= a.ntz;
+    const int n = b % a.N;
+    const int chunk = b / a.N;
+    const int oz0 = tz * G::TZ, oy0 = ty * G::TY, ox0 = tx * 16;
+
+    // stage the halo: one lane per voxel
+    const T* x = reinterpret_cast<const T*>(a.x);
+    for (int c = wave; c < NCH; c += 4) {
+        const int hv = c * 64 + lane;
+        const int hx = hv % G::HX;
+        const int t = hv / G::HX;
+        const int hy = t % G::HY;
+        const int hz = t / G::HY;
+        int iz = oz0 - 1 + hz, iy = oy0 - 1 + hy, ix = ox0 - 1 + hx;
+        bool ok = hv < G::HVOX;
+        if (a.circular) {
+            iz = wrap(iz, a.Iz); iy = wrap(iy, a.Iy); ix = wrap(ix, a.Ix);
+        } else {
+            ok = ok && (unsigned)iz < (unsigned)a.Iz && (unsigned)iy < (unsigned)a.Iy && (unsigned)ix < (unsigned)a.Ix;
+        }
+        const size_t off = ((((size_t)n * a.Sz + iz) * a.Sy + iy) * a.Sx + ix) * a.CinStride;
+        const void* src = ok ? static_cast<const void*>(x + off) : static_cast<const void*>(g_zero_page);
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                         (__attribute__((address_space(3))) void*)(lds + c * 1024), 16, 0, 0);
+    }
+    // weights of this cout chunk: NG x NC fragments
+    uint4 wf[NG][NC];
+    {
+        const uint4* wk = reinterpret_cast<const uint4*>(a.w) + (size_t)chunk * NG * NC * 64 + lane;
+#pragma unroll
+        for (int g = 0; g < NG; ++g)
+#pragma unroll
+            for (int c = 0; c < NC; ++c) wf[g][c] = wk[(g * NC + c) * 64];
+    }
+    // operand addresses: wave's first row + this lane's voxel + the shift of tap 4g + q
+    const int lx = lane & 15, q = lane >> 4;
+    const int r0 = wave * NV;
+    const int base = (((r0 / G::TY) * G::HY + (r0 % G::TY)) * G::HX + lx) * 16;
+    int goff[NG];
+#pragma unroll
+    for (int g = 0; g < NG; ++g) {
+        const int tap = 4 * g + q;
+        const int dz = tap / 9, dy = (tap / 3) % 3, dx = tap % 3;
+        goff[g] = tap < G::TAPS ? base + ((dz * G::HY + dy) * G::HX + dx) * 16 : base;      // (tap 27: zero weights)
+    }
+    f32x4 acc[NV][NC];
+#pragma unroll
+    for (int v = 0; v < NV; ++v)
+#pragma unroll
+        for (int c = 0; c < NC; ++c) acc[v][c] = f32x4{0.f, 0.f, 0.f, 0.f};
+    __syncthreads();
+#pragma unroll
+    for (int g = 0; g < NG; ++g) {
+        uint4 af[NV];
+#pragma unroll
+        for (int v = 0; v < NV; ++v) af[v] = *reinterpret_cast<const uint4*>(lds + goff[g] + v * ROWB);
+#pragma unroll
+        for (int v = 0; v < NV; ++v)
+#pragma unroll
+            for (int c = 0; c < NC; ++c) mma16<T>(acc[v][c], wf[g][c], af[v]);
+    }
+    constexpr int IMG = NCH * 1024;
+    conv_epilogue<T, TO, G, NC, NV>(acc, a, n, chunk, oz0, oy0, ox0, wave, lane, reinterpret_cast<float*>(lds + IMG),
+                                    (tz * a.nty + ty) * a.ntx + tx);
+}
+
+template <typename T, typename TO, int KS, int STRIDE, int UPS, int NC, int TZ, int TY, bool SPLIT = false>
+static int launch_fwd_cfg(const ConvArgs& a0, hipStream_t s) {
+    using G = Geo<KS, STRIDE, TZ, TY>;
+    ConvArgs a = a0;
+    if (SPLIT) a.nchunks *= 2;
+    a.ntz = cdiv(a.Dz, TZ); a.nty = cdiv(a.Dy, TY); a.ntx = cdiv(a.Dx, 16);
+    const size_t lds = (size_t)((G::HVOX + 15) / 16) * 1024 + GN_SCRATCH_BYTES;
+    auto kern = conv_fwd_kernel<T, TO, KS, STRIDE, UPS, NC, TZ, TY, SPLIT>;
+    static unsigned long long lds_done = 0;
+    {
+        int e = set_lds(kern, lds, lds_done);
+        if (e) return e;
+    }
+    const long long nwg = (long long)a.N * a.ntz * a.nty * a.ntx * a.nchunks;
+    if (nwg > 0x7fffffffLL) { set_error("conv: grid too large"); return VDM_ERR_ARG; }
+    hipLaunchKernelGGL(kern, dim3((unsigned)nwg), dim3(256), lds, s, a);
+    VDM_LAUNCH_CHECK("conv_fwd_kernel");
+    return VDM_OK;
+}
+
+template <typename T, typename TO, int KS, int STRIDE, int UPS, int NC>
+static int launch_fwd_geo(const ConvArgs& a, hipStream_t s) {
+    if constexpr (STRIDE == 2)
+        return launch_fwd_cfg<T, TO, KS, STRIDE, UPS, NC, 2, 4>(a, s);
+    else if constexpr (KS == 3 && sizeof(T) == 2) {
+        int tz, ty;
+        small_grid_tile(a, tz, ty);
+        if constexpr (NC == 4 && UPS == 0 && sizeof(TO) == 2) {
+            if (uses_split(a, tz, ty)) {
+                if (tz == 1) return ty == 4 ? launch_fwd_cfg<T, TO, KS, STRIDE, UPS, 2, 1, 4, true>(a, s) : launch_fwd_cfg<T, TO, KS, STRIDE, UPS, 2, 1, 8, true>(a, s);
+                return launch_fwd_cfg<T, TO, KS, STRIDE, UPS, 2, 2, 8, true>(a, s);
+            }
+        }
+        if (tz == 1) return ty == 4 ? launch_fwd_cfg<T, TO, KS, STRIDE, UPS, NC, 1, 4>(a, s) : launch_fwd_cfg<T, TO, KS, STRIDE, UPS, NC, 1, 8>(a, s);
+        if (tz == 2) return launch_fwd_cfg<T, TO, KS, STRIDE, UPS, NC, 2, 8>(a, s);
+        return launch_fwd_cfg<T, TO, KS, STRIDE, UPS, NC, 4, 8>(a, s);
+    } else
+        return launch_fwd_cfg<T, TO, KS, STRIDE, UPS, NC, 4, 8>(a, s);
+}
+
+template <typename T, typename TO, int KS, int STRIDE, int UPS>
+static int launch_fwd_nc(const ConvArgs& a, int nc, hipStream_t s) {
+    switch (nc) {
+        case 1: return launch_fwd_geo<T, TO, KS, STRIDE, UPS, 1>(a, s);
+        case 2: return launch_fwd_geo<T, TO, KS, STRIDE, UPS, 2>(a, s);
+        default: return launch_fwd_geo<T, TO, KS, STRIDE, UPS, 4>(a, s);
+    }
+}
+
+template <typename T, typename TO>
+static int launch_fwd_variant(const ConvArgs& a, int ks, int stride, int ups, int nc, hipStream_t s) {
+    if (ks == 1) return launch_fwd_nc<T, TO, 1, 1, 0>(a, nc, s);
+    if (stride == 2) return launch_fwd_nc<T, TO, 3, 2, 0>(a, nc, s);
+    if (ups) return launch_fwd_nc<T, TO, 3, 1, 1>(a, nc, s);
+    return launch_fwd_nc<T, TO, 3, 1, 0>(a, nc, s);
+}
+
+
+template <int NC>
+static int launch_kpack(const ConvArgs& a0, hipStream_t s) {
+    using G = Geo<3, 1, 4, 8>;
+    ConvArgs a = a0;
+    a.ntz = cdiv(a.Dz, G::TZ); a.nty = cdiv(a.Dy, G::TY); a.ntx = cdiv(a.Dx, 16);
+    const size_t lds = (size_t)((G::HVOX + 63) / 64) * 1024 + GN_SCRATCH_BYTES;
+    const long long nwg = (long long)a.N * a.ntz * a.nty * a.ntx * a.nchunks;
+    if (nwg > 0x7fffffffLL) { set_error("conv: grid too large"); return VDM_ERR_ARG; }
+    hipLaunchKernelGGL((conv_kpack_kernel<bf16_t, NC>), dim3((unsigned)nwg), dim3(256), lds, s, a);
+    VDM_LAUNCH_CHECK("conv_kpack_kernel");
+    return VDM_OK;
+}
+
+int launch_fwd(const ConvArgs& a, int dtype, int out_f32, int ks, int stride, int ups, int nc, hipStream_t s) {
+    if (uses_kpack(dtype, ks, stride, ups, a.Cin, a.Cout, out_f32)) return nc == 1 ? launch_kpack<1>(a, s) : launch_kpack<2>(a, s);
+    if (dtype == VDM_F32) return launch_fwd_variant<float, float>(a, ks, stride, ups, nc, s);
+    if (out_f32) {
+        if (!(ks == 3 && stride == 1 && !ups && nc == 1)) {
+            set_error("conv: out_f32 with bf16 input is only built for ksize 3, stride 1, cout <= 16");
+            return VDM_ERR_UNSUPPORTED;
+        }
+        return launch_fwd_geo<bf16_t, float, 3, 1, 0, 1>(a, s);
+    }
+    return launch_fwd_variant<bf16_t, bf16_t>(a, ks, stride, ups, nc, s);
+}
+
+}  // namespace vdm
