@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define VDM_ABI_VERSION 3
+#define VDM_ABI_VERSION 4
 
 typedef enum { VDM_OK = 0, VDM_ERR_ARG = -1, VDM_ERR_HIP = -2, VDM_ERR_UNSUPPORTED = -3 } vdm_status;
 typedef enum { VDM_F32 = 0, VDM_BF16 = 1 } vdm_dtype;
@@ -95,6 +95,27 @@ int vdm_conv_fwd(const vdm_conv_desc* d, const void* x, const void* w_packed_fwd
  * up-sampled intermediate). */
 int vdm_conv_dgrad(const vdm_conv_desc* d, const void* dout, const void* w_packed_dgrad, const void* residual, void* dx,
                    void* stream); /* dx = dgrad (+ residual, same shape as dx, may be NULL) */
+/* The same input gradient for a conv whose INPUT was y = dropout(silu(groupnorm(x))) [NB blocks.py:129-132: net1 / net2 =
+ * Sequential(GroupNorm, SiLU, (Dropout,) Conv)], with the first half of that GroupNorm's backward folded into the epilogue:
+ * instead of dL/dy the kernel stores dyh = dL/dy * keep/(1-p) * silu'(yhat) (same shape and dtype) and reduces, per spatial tile
+ * and channel, partials[n][tile][cin][2] = (sum dyh, sum dyh * xhat), tile < vdm_conv_dgrad_gn_tiles(d) - one read of x instead of
+ * a separate two-tensor reduction pass, in a fixed order (no float atomics).  vdm_gn_bwd_finalize + vdm_gn_bwd_apply finish the
+ * GroupNorm backward.  Only for ksize 3, stride 1, no up-sampling (every conv behind a GroupNorm on the path). */
+typedef struct vdm_gn_fold {
+    const void* x1;          /* GroupNorm input, first c1 channels  [n][od][oh][ow][c1] */
+    const void* x2;          /* ... remaining c2 channels (skip concat), or NULL */
+    int32_t c1, c2, groups;  /* c1 + c2 == cin of the conv */
+    const float* stats;      /* [n][groups][2] raw moments of x (vdm_gn_stats) */
+    const float* gamma;      /* [cin] */
+    const float* beta;       /* [cin] */
+    float eps;
+    float inv_keep;          /* 1 / (1 - p) when keep_mask is given */
+    const uint8_t* keep_mask; /* dropout keep bits written by vdm_gn_silu_fwd, or NULL (no dropout) */
+    float* partials;         /* out */
+} vdm_gn_fold;
+int vdm_conv_dgrad_gn_tiles(const vdm_conv_desc* d);
+int vdm_conv_dgrad_gn(const vdm_conv_desc* d, const void* dout, const void* w_packed_dgrad, void* dyh, const vdm_gn_fold* fold,
+                      void* stream);
 /* dw[taps][cout][cin] (fp32) = sum over voxels; workspace holds per-workgroup partial slabs.
  * dbias (optional, ksize 3 only): dbias[cout] = sum over samples and voxels of dout (the conv bias gradient), computed
  * from the dOut tiles the kernel stages anyway.  accumulate != 0 adds to dw / dbias instead of overwriting. */
@@ -120,13 +141,16 @@ int vdm_conv_wgrad(const vdm_conv_desc* d, const void* x, const void* dout, floa
 #define VDM_GN_STATS_WS_BYTES (2048 * 2 * 64 * 4)
 /* part1 / part2 (may be NULL): per-tile channel partials of that source written by vdm_conv_fwd (tilesK tiles per sample);
  * the source's groups are then summed from them and xK is not read (xK may be NULL). */
+/* chsum (may be NULL; needs every source given as partials): chsum[n][c1+c2] = sum_v x[n][v][c], the per-channel sums. */
 int vdm_gn_stats(const void* x1, int c1, const void* x2, int c2, int n, int64_t voxels, int groups,
                  int dtype, float* stats, float* workspace, const float* part1, int tiles1, const float* part2, int tiles2,
-                 void* stream);
-/* y[n][v][c1+c2] = dropout(silu(gn(concat(x1,x2)))) ; keep-mask from Philox(seed, element index). */
+                 float* chsum, void* stream);
+/* y[n][v][c1+c2] = dropout(silu(gn(concat(x1,x2)))) ; keep-mask from Philox(seed, element index).
+ * keep_mask (may be NULL): with dropout_p > 0 the keep bits are also written, one byte per 16-byte piece of y
+ * ([n][voxels][(c1+c2) / (4 fp32 | 8 bf16)], bit j = channel j of the piece), for vdm_conv_dgrad_gn. */
 int vdm_gn_silu_fwd(const void* x1, int c1, const void* x2, int c2, int n, int64_t voxels, int groups,
                     int dtype, const float* stats, const float* gamma, const float* beta, float eps,
-                    float dropout_p, uint64_t seed, void* y, void* stream);
+                    float dropout_p, uint64_t seed, void* y, uint8_t* keep_mask, void* stream);
 /* Backward of the above.  dy is the gradient w.r.t. y.  Writes dx1 (and dx2), ADDS into
  * dgamma/dbeta [c] (caller zeroes); optional add1 / add2 (shaped like x1 / x2) are added to dx1 / dx2
  * (residual-path gradients); optional colsum[n*colsum_stride + c] += sum_v dx (caller zeroes; bias and
@@ -137,15 +161,20 @@ int vdm_gn_silu_bwd(const void* x1, int c1, const void* x2, int c2, int n, int64
                     void* dx2, float* dgamma, float* dbeta, float* colsum, int64_t colsum_stride, float* red_ws,
                     void* stream);
 
+/* Second half of the GroupNorm backward after vdm_conv_dgrad_gn (all in fixed summation order: bit-reproducible).
+ * finalize: chan[n][c][2] = sum over tiles of the partials; red[n][g][2] = sum_c gamma_c chan[n][c];
+ *           colsum (may be NULL; needs chsum of vdm_gn_stats): colsum[n*colsum_stride + c] = sum_v dx[n][v][c], analytically
+ *           (the conditioning-table / conv-bias gradient of the ResNetBlock: h = conv1(..) + bias + sum_k Linear_k(cond_k)).
+ * apply:    dx = rstd * (gamma * dyh - m1 - xhat * m2) (+ add1 / add2: residual-path gradients), m = red / (voxels * C/groups);
+ *           dgamma[c] = sum_n chan[n][c][1], dbeta[c] = sum_n chan[n][c][0] (written, not accumulated).  dx1 may alias dyh. */
+int vdm_gn_bwd_finalize(const float* partials, int tiles, int n, int c, int groups, int64_t voxels, const float* stats,
+                        const float* gamma, float eps, const float* chsum, float* red, float* chan, float* colsum,
+                        int64_t colsum_stride, void* stream);
+int vdm_gn_bwd_apply(const void* x1, int c1, const void* x2, int c2, int n, int64_t voxels, int groups, int dtype,
+                     const float* stats, const float* gamma, float eps, const void* dyh, const float* red, const float* chan,
+                     const void* add1, const void* add2, void* dx1, void* dx2, float* dgamma, float* dbeta, void* stream);
+
 /* ---- small tensor ops on the path ------------------------------------------------------------ */
-/* out[n*out_stride + c] += sum_v x[n][v][c]   (conv bias gradients; caller zeroes). */
-int vdm_colsum(const void* x, int n, int64_t voxels, int c, int dtype, float* out, int64_t out_stride, void* stream);
-/* fine[n][2z+a][2y+b][2x+c][ch] = (a|b|c)==0 ? coarse[n][z][y][x][ch] : 0  (stride-2 dgrad helper). */
-int vdm_dilate2(const void* coarse, void* fine, int n, int cd, int ch, int cw, int c, int dtype, void* stream);
-/* coarse = sum of the 2x2x2 children of fine (backward of nearest x2 up-sampling). */
-int vdm_pool2_sum(const void* fine, void* coarse, int n, int cd, int ch, int cw, int c, int dtype, void* stream);
-/* dst = (dst_dtype) src, n elements. */
-int vdm_cast(const void* src, int src_dtype, void* dst, int dst_dtype, int64_t n, void* stream);
 /* out[n][v][cpad] <- channels {a[n][v], b[n][v] (b may be NULL)} zero-padded to cpad; a,b fp32. */
 int vdm_pack_input(const float* a, const float* b, int64_t nvox, int cpad, int dtype, void* out, void* stream);
 
@@ -155,8 +184,9 @@ int vdm_diffuse(const float* x, const float* eps, const float* alpha, const floa
                 float* z_t, void* stream);
 /* sums[n][3] += {sum (eps-eps_hat)^2, sum x^2, sum (x - z0r)^2} with z0r = x + (sigma0/alpha0) eps0;
  * d_eps_hat = coef[n] * (eps_hat - eps)   (coef folds bpd * gamma'(t) / B).  Caller zeroes sums. */
+/* workspace: >= 2048 * 3 floats (per-workgroup partials, folded in a fixed order: the loss is bit-reproducible). */
 int vdm_loss_terms(const float* x, const float* eps, const float* eps_hat, const float* eps0, float sigma0_over_alpha0,
-                   const float* coef, int n, int64_t per, float* sums, float* d_eps_hat, void* stream);
+                   const float* coef, int n, int64_t per, float* sums, float* d_eps_hat, float* workspace, void* stream);
 
 /* ---- K9: ancestral update [NB vdm_model.py:370-378] ----------------------------------------
  * z <- ratio*(z - c_sigma_t*eps_hat) + scale*noise ; the four scalars are read from the DEVICE table
@@ -170,8 +200,8 @@ int vdm_randn(float* out, int64_t n, uint64_t seed, uint64_t stream_id, void* st
 int vdm_step_inc(int32_t* step_ptr, void* stream);
 
 /* ---- K10: global gradient norm [REF trainVDM3D128_c_c_from_field_name_thick_lowbatch.py:45] -- */
-/* out[0] += sum x^2 (caller zeroes). */
-int vdm_sumsq(const float* x, int64_t n, float* out, void* stream);
+/* out[0] += sum x^2 (caller zeroes).  workspace: >= 2048 floats (fixed-order fold: bit-reproducible). */
+int vdm_sumsq(const float* x, int64_t n, float* out, float* workspace, void* stream);
 
 #ifdef __cplusplus
 }

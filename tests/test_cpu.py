@@ -220,7 +220,7 @@ def test_cabi_exports_every_declared_symbol(hip_lib):
     for name in sorted(declared):
         assert hasattr(hip_lib, name), f"libvdm4cdm_hip.so does not export {name}"
     assert declared == set(_lib.SIGNATURES), f"ctypes table out of sync: {declared ^ set(_lib.SIGNATURES)}"
-    assert hip_lib.vdm_abi_version() == 3
+    assert hip_lib.vdm_abi_version() == 4
 
 
 def test_cabi_argument_errors_do_not_need_a_gpu(hip_lib):

@@ -376,27 +376,109 @@ def test_gn_dropout_consistency():
     assert (dx.cpu() - xr.grad).abs().max().item() <= 1e-4
 
 
+
+# ------------------------------------------------------------------------------------------ fused GroupNorm backward
+FOLD_CASES = [  # name, N, (D,H,W), producer cin, c1, c2 (GroupNorm over c1+c2 channels), conv cout, groups, dropout p, circular
+    ("l0_32", 2, (8, 8, 16), 32, 32, 0, 32, 8, 0.1, False),          # NC=2 lanes (8 channels), dropout, 4x8x16 tiles
+    ("l0_concat", 1, (6, 9, 20), 32, 32, 32, 32, 8, 0.0, False),      # two-source GroupNorm (64 ch, NC=4), ragged tiles
+    ("deep_128", 2, (4, 4, 16), 64, 128, 0, 128, 8, 0.25, True),      # NC=4 / half-chunk workgroups on a small grid
+    ("c16", 1, (8, 8, 16), 16, 16, 0, 32, 8, 0.1, False),             # NC=1 lanes (4 channels: half a bf16 piece)
+    ("out_1", 2, (8, 8, 16), 32, 32, 0, 1, 8, 0.0, False),            # conv_out: 1 output channel -> tap-packed dgrad kernel
+    ("concat_16", 1, (4, 8, 16), 16, 16, 16, 16, 8, 0.0, False),      # 32-channel concat of 16 + 16 (NC=2 lanes)
+]
+
+
+@pytest.mark.parametrize("dtype", DTYPES, ids=["f32", "bf16"])
+@pytest.mark.parametrize("case", FOLD_CASES, ids=[c[0] for c in FOLD_CASES])
+def test_gn_bwd_folded_into_dgrad(case, dtype):
+    """Conv.dgrad_gn + gn_bwd_fused (GroupNorm+SiLU+dropout backward with the reduction folded into the dgrad epilogue, analytic
+    column sums, no atomics) against torch.autograd of  x -> dropout(silu(group_norm(x))) -> conv3d  on the CPU in fp32.
+    The GroupNorm input x is produced by a HIP conv with gn=True so that the forward partials / per-channel sums exist; the
+    dropout mask of the reference is the one the forward kernel wrote (keep bytes)."""
+    ops = _ops()
+    name, N, sp, pcin, c1, c2, cout, G, p, circ = case
+    C = c1 + c2
+    D, H, W = sp
+    epl = ops.epl(dtype)
+
+    def produce(cx, seed):          # GroupNorm input tensor of cx channels, written by a conv epilogue (partials attached)
+        cv = ops.Conv(pcin, cx, 3, circular=circ)
+        cv.pack(rnd((27, cx, pcin), seed, dtype, scale=1.0 / math.sqrt(27 * pcin)).to(DEV), dtype, need_dgrad=False)
+        x0 = to_dev(rnd((N, D, H, W, ops.cpad(pcin, dtype)), seed + 1, dtype), dtype)
+        return cv.fwd(x0, (0.3 * rnd((cx,), seed + 2)).to(DEV), gn=True)
+    x1 = produce(c1, 10)
+    x2 = produce(c2, 20) if c2 else None
+    gamma = 1.0 + 0.3 * rnd((C,), 3)
+    beta = 0.2 * rnd((C,), 4)
+    st = ops.gn_stats(x1, x2, G, chsum=True)
+    assert st.chsum is not None and st.chsum.shape == (N, C)
+    y = ops.gn_silu_fwd(x1, x2, G, st, gamma.to(DEV), beta.to(DEV), p, 777, want_mask=True)
+    # keep mask bytes -> [N, V, C] multiplier
+    V = D * H * W
+    if p > 0:
+        mb = y.keep_mask.cpu().to(torch.int32)
+        assert mb.shape == (N, V, C // epl)
+        bits = ((mb[..., None] >> torch.arange(epl)) & 1).reshape(N, V, C).float()
+        assert abs(bits.mean().item() - (1 - p)) < 0.03
+        yc, bsh = y.float().cpu(), bits.reshape(y.shape)
+        assert (yc[bsh == 0] == 0).all(), "a dropped element must be stored as zero"
+        assert ((yc != 0) & (bsh == 1)).float().sum().item() >= 0.999 * (bsh == 1).float().sum().item()
+        mult = (bits / (1 - p)).reshape(N, D, H, W, C)
+    else:
+        assert y.keep_mask is None
+        mult = torch.ones(N, D, H, W, C)
+    # conv on y
+    w = rnd((27, cout, C), 30, dtype, scale=1.0 / math.sqrt(27 * C))
+    conv = ops.Conv(C, cout, 3, circular=circ)
+    conv.pack(w.to(DEV), dtype, need_dgrad=True)
+    dout = rnd((N, D, H, W, cout), 31, dtype)
+    dd = torch.zeros((N, D, H, W, ops.cpad(cout, dtype)), dtype=dtype, device=DEV)
+    dd[..., :cout] = dout.to(dtype).to(DEV)
+    add1 = rnd((N, D, H, W, c1), 6, dtype)
+    add2 = rnd((N, D, H, W, c2), 7, dtype) if c2 else None
+
+    # reference
+    xc = torch.cat([x1.float().cpu()] + ([x2.float().cpu()] if c2 else []), -1).requires_grad_(True)
+    gr, br = gamma.clone().requires_grad_(True), beta.clone().requires_grad_(True)
+    yr = F.silu(F.group_norm(xc.permute(0, 4, 1, 2, 3), G, gr, br, 1e-5)).permute(0, 2, 3, 4, 1) * mult
+    ref_conv(yr, w, None, None, None, 3, 1, 0, circ).backward(dout)
+    gx = xc.grad
+
+    assert conv.gn_fold_ok(c1, c2, dtype)
+    dyh = conv.dgrad_gn(dd, x1, x2, G, st, gamma.to(DEV), beta.to(DEV), keep_mask=y.keep_mask, dropout_p=p)
+    assert dyh.shape == (N, D, H, W, C) and dyh.gnb_partials.shape[2:] == (C, 2)
+    dgam = torch.full((C,), float("nan"), device=DEV)
+    dbet = torch.full((C,), float("nan"), device=DEV)
+    cs = torch.zeros(N, C + 5, device=DEV)
+    dx1, dx2 = ops.gn_bwd_fused(x1, x2, G, st, gamma.to(DEV), dyh, dgam, dbet, add1=to_dev(add1, dtype),
+                                add2=(to_dev(add2, dtype) if c2 else None), colsum=cs[:, 2:2 + C])
+    scale = max(gx.abs().max().item(), 1e-6)
+    tol = (2e-4 if dtype == torch.float32 else 2.0 ** -6) * scale + ew_tol(dtype, add1)
+    e1 = (dx1.float().cpu() - (gx[..., :c1] + add1)).abs().max().item()
+    assert e1 <= tol, f"{name}: dx1 err {e1} > {tol}"
+    if c2:
+        e2 = (dx2.float().cpu() - (gx[..., c1:] + add2)).abs().max().item()
+        assert e2 <= tol, f"{name}: dx2 err {e2} > {tol}"
+    rt = 2e-3 if dtype == torch.float32 else 3e-2
+    assert torch.allclose(dgam.cpu(), gr.grad, rtol=rt, atol=rt * gr.grad.abs().max().item()), f"{name}: dgamma"
+    assert torch.allclose(dbet.cpu(), br.grad, rtol=rt, atol=rt * br.grad.abs().max().item()), f"{name}: dbeta"
+    cref = gx.reshape(N, V, C).sum(1)
+    assert torch.allclose(cs[:, 2:2 + C].cpu(), cref, rtol=rt, atol=rt * cref.abs().max().item() + 1e-3), f"{name}: analytic colsum"
+    assert cs[:, :2].abs().max().item() == 0 and cs[:, 2 + C:].abs().max().item() == 0
+    # bit-reproducible: a second run gives identical bits
+    dyh2 = conv.dgrad_gn(dd, x1, x2, G, st, gamma.to(DEV), beta.to(DEV), keep_mask=y.keep_mask, dropout_p=p)
+    dgam2, dbet2 = torch.empty_like(dgam), torch.empty_like(dbet)
+    cs2 = torch.zeros_like(cs)
+    r1, r2 = ops.gn_bwd_fused(x1, x2, G, st, gamma.to(DEV), dyh2, dgam2, dbet2, add1=to_dev(add1, dtype),
+                              add2=(to_dev(add2, dtype) if c2 else None), colsum=cs2[:, 2:2 + C],
+                              dx1=(torch.empty_like(x1) if c2 else None))
+    assert torch.equal(r1, dx1) and torch.equal(dgam, dgam2) and torch.equal(dbet, dbet2) and torch.equal(cs, cs2)
+
+
 # ------------------------------------------------------------------------------------------ small ops
 @pytest.mark.parametrize("dtype", DTYPES, ids=["f32", "bf16"])
 def test_small_ops(dtype):
     ops = _ops()
-    x = rnd((2, 4, 6, 8, 32), 1, dtype)
-    d = to_dev(x, dtype)
-    out = torch.zeros(32, device=DEV)
-    ops.colsum(d, out, 0)
-    assert torch.allclose(out.cpu(), x.sum((0, 1, 2, 3)), rtol=1e-4, atol=1e-3)
-    out2 = torch.zeros(2, 40, device=DEV)
-    ops.colsum(d, out2[:, 4:36])
-    assert torch.allclose(out2[:, 4:36].cpu(), x.sum((1, 2, 3)), rtol=1e-4, atol=1e-3)
-    fine = ops.dilate2(d).float().cpu()
-    assert fine.shape == (2, 8, 12, 16, 32)
-    assert torch.equal(fine[:, ::2, ::2, ::2], x) and fine.abs().sum().item() == pytest.approx(x.abs().sum().item(), rel=1e-5)
-    pooled = ops.pool2_sum(to_dev(fine, dtype)).float().cpu()
-    assert torch.allclose(pooled, x, atol=1e-6)
-    y = rnd((2, 4, 4, 8, 16), 2, dtype)
-    pr = ops.pool2_sum(to_dev(y, dtype)).float().cpu()
-    ref = y.reshape(2, 2, 2, 2, 2, 4, 2, 16).sum((2, 4, 6))
-    assert (pr - ref).abs().max().item() <= ew_tol(dtype, ref) * 2
     a, b = rnd((2, 4, 4, 4), 3), rnd((2, 4, 4, 4), 4)
     pk = ops.pack_input(a.to(DEV), b.to(DEV), dtype).float().cpu()
     assert pk.shape[-1] == ops.cpad(2, dtype)

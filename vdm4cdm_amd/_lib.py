@@ -36,10 +36,17 @@ class PackChunk(C.Structure):
     _fields_ = [("item", C.c_int32), ("count", C.c_int32), ("first", C.c_int64)]
 
 
+class GnFold(C.Structure):
+    """vdm_gn_fold"""
+    _fields_ = [("x1", C.c_void_p), ("x2", C.c_void_p), ("c1", C.c_int32), ("c2", C.c_int32), ("groups", C.c_int32),
+                ("stats", C.c_void_p), ("gamma", C.c_void_p), ("beta", C.c_void_p), ("eps", C.c_float), ("inv_keep", C.c_float),
+                ("keep_mask", C.c_void_p), ("partials", C.c_void_p)]
+
+
 PACK_CHUNK = 16384                   # VDM_PACK_CHUNK
 _p, _i, _i64, _u64, _f, _sz = C.c_void_p, C.c_int, C.c_int64, C.c_uint64, C.c_float, C.c_size_t
 _D = C.POINTER(ConvDesc)
-ABI_VERSION = 3                      # VDM_ABI_VERSION of include/vdm4cdm_hip.h this binding was written for
+ABI_VERSION = 4                      # VDM_ABI_VERSION of include/vdm4cdm_hip.h this binding was written for
 
 # name -> (restype, argtypes); mirrors include/vdm4cdm_hip.h one to one
 SIGNATURES = {
@@ -53,23 +60,23 @@ SIGNATURES = {
     "vdm_conv_gn_tiles": (_i, [_D]),
     "vdm_conv_fwd": (_i, [_D, _p, _p, _p, _p, _i64, _p, _p, _p, _p]),
     "vdm_conv_dgrad": (_i, [_D, _p, _p, _p, _p, _p]),
+    "vdm_conv_dgrad_gn_tiles": (_i, [_D]),
+    "vdm_conv_dgrad_gn": (_i, [_D, _p, _p, _p, C.POINTER(GnFold), _p]),
     "vdm_conv_kernel_variant": (_i, [_D, _i]),
     "vdm_conv_wgrad_workspace_bytes": (_sz, [_D]),
     "vdm_conv_wgrad": (_i, [_D, _p, _p, _p, _p, _i, _p, _sz, _p]),
-    "vdm_gn_stats": (_i, [_p, _i, _p, _i, _i, _i64, _i, _i, _p, _p, _p, _i, _p, _i, _p]),
-    "vdm_gn_silu_fwd": (_i, [_p, _i, _p, _i, _i, _i64, _i, _i, _p, _p, _p, _f, _f, _u64, _p, _p]),
+    "vdm_gn_stats": (_i, [_p, _i, _p, _i, _i, _i64, _i, _i, _p, _p, _p, _i, _p, _i, _p, _p]),
+    "vdm_gn_silu_fwd": (_i, [_p, _i, _p, _i, _i, _i64, _i, _i, _p, _p, _p, _f, _f, _u64, _p, _p, _p]),
     "vdm_gn_silu_bwd": (_i, [_p, _i, _p, _i, _i, _i64, _i, _i, _p, _p, _p, _f, _f, _u64, _p, _p, _p, _p, _p, _p, _p, _p, _i64, _p, _p]),
-    "vdm_colsum": (_i, [_p, _i, _i64, _i, _i, _p, _i64, _p]),
-    "vdm_dilate2": (_i, [_p, _p, _i, _i, _i, _i, _i, _i, _p]),
-    "vdm_pool2_sum": (_i, [_p, _p, _i, _i, _i, _i, _i, _i, _p]),
-    "vdm_cast": (_i, [_p, _i, _p, _i, _i64, _p]),
+    "vdm_gn_bwd_finalize": (_i, [_p, _i, _i, _i, _i, _i64, _p, _p, _f, _p, _p, _p, _p, _i64, _p]),
+    "vdm_gn_bwd_apply": (_i, [_p, _i, _p, _i, _i, _i64, _i, _i, _p, _p, _f, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p]),
     "vdm_pack_input": (_i, [_p, _p, _i64, _i, _i, _p, _p]),
     "vdm_diffuse": (_i, [_p, _p, _p, _p, _i, _i64, _p, _p]),
-    "vdm_loss_terms": (_i, [_p, _p, _p, _p, _f, _p, _i, _i64, _p, _p, _p]),
+    "vdm_loss_terms": (_i, [_p, _p, _p, _p, _f, _p, _i, _i64, _p, _p, _p, _p]),
     "vdm_ancestral_step": (_i, [_p, _p, _p, _p, _p, _u64, _i64, _p]),
     "vdm_randn": (_i, [_p, _i64, _u64, _u64, _p]),
     "vdm_step_inc": (_i, [_p, _p]),
-    "vdm_sumsq": (_i, [_p, _i64, _p, _p]),
+    "vdm_sumsq": (_i, [_p, _i64, _p, _p, _p]),
 }
 
 

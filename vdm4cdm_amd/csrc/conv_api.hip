@@ -302,6 +302,46 @@ extern "C" int vdm_conv_dgrad(const vdm_conv_desc* d, const void* dout, const vo
     return launch_fwd(a, d->dtype, 0, d->ksize, 1, 0, p.nc, (hipStream_t)stream);
 }
 
+static void dgrad_args(ConvArgs& a, const vdm_conv_desc* d) {
+    const Plan p = plan_of(d, 1);
+    a.N = d->n; a.Dz = d->od; a.Dy = d->oh; a.Dx = d->ow;
+    a.Iz = a.Sz = d->od; a.Iy = a.Sy = d->oh; a.Ix = a.Sx = d->ow;       // dgrad runs on the output grid
+    a.circular = d->pad_mode == VDM_PAD_CIRCULAR;
+    a.Cin = d->cout; a.CinStride = cpad(d->cout, d->dtype); a.Cout = d->cin;
+    a.nchunks = p.nchunks; a.nkb = p.nkb;
+}
+
+extern "C" int vdm_conv_dgrad_gn_tiles(const vdm_conv_desc* d) {
+    if (validate(d) != VDM_OK || d->ksize != 3 || d->stride != 1 || d->upsample) return 0;
+    ConvArgs a{};
+    dgrad_args(a, d);
+    int tz, ty;
+    fwd_tile_shape(a, d->dtype, 0, 3, 1, 0, tz, ty);
+    return cdiv(a.Dz, tz) * cdiv(a.Dy, ty) * cdiv(a.Dx, 16);
+}
+
+extern "C" int vdm_conv_dgrad_gn(const vdm_conv_desc* d, const void* dout, const void* w_packed_dgrad, void* dyh, const vdm_gn_fold* f,
+                                 void* stream) {
+    int e = validate(d);
+    if (e) return e;
+    VDM_REQUIRE(dout && w_packed_dgrad && dyh && f, "conv_dgrad_gn: NULL pointer");
+    VDM_REQUIRE(d->ksize == 3 && d->stride == 1 && !d->upsample, "conv_dgrad_gn: only the 3x3x3 stride-1 conv feeds a GroupNorm backward");
+    VDM_REQUIRE(f->x1 && f->stats && f->gamma && f->beta && f->partials && f->groups > 0, "conv_dgrad_gn: NULL pointer in the fold");
+    const int C = d->cin;
+    const Plan p = plan_of(d, 1);
+    VDM_REQUIRE(f->c1 + f->c2 == C && (f->c2 == 0 || f->x2), "conv_dgrad_gn: c1 + c2 must equal the conv's input channels (%d)", C);
+    VDM_REQUIRE(C % f->groups == 0 && C % (p.nc * 4) == 0 && C % epl_of(d->dtype) == 0, "conv_dgrad_gn: channel count %d not supported", C);
+    VDM_REQUIRE(f->c2 == 0 || f->c1 % (p.nc * 4) == 0, "conv_dgrad_gn: a lane's %d channels would straddle the concat boundary", p.nc * 4);
+    ConvArgs a{};
+    a.x = dout; a.w = w_packed_dgrad; a.out = dyh; a.gnp = f->partials;
+    dgrad_args(a, d);
+    a.gx1 = f->x1; a.gx2 = f->x2; a.gc1 = f->c1; a.gc2 = f->c2; a.gG = f->groups;
+    a.gstats = f->stats; a.ggamma = f->gamma; a.gbeta = f->beta; a.gmask = f->keep_mask;
+    a.geps = f->eps; a.ginv_keep = f->keep_mask ? f->inv_keep : 1.0f;
+    a.gcnt = (float)((double)d->od * d->oh * d->ow * (C / f->groups));
+    return launch_fwd_gnb(a, d->dtype, p.nc, (hipStream_t)stream);
+}
+
 extern "C" int vdm_conv_kernel_variant(const vdm_conv_desc* d, int dgrad) {
     if (validate(d)) return -1;
     if (uses_cls(d, dgrad)) return VDM_CONV_VARIANT_CLASS;

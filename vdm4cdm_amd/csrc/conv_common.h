@@ -60,6 +60,17 @@ struct ConvArgs {
     int circular;
     int ntz, nty, ntx, nchunks, nkb;
     float* gnp;          // optional GroupNorm partials of the output: [N][ntz*nty*ntx][Cout][2] = (sum, sum of squares) per tile
+    // GroupNorm backward folded into a dgrad epilogue (conv_epilogue_gnb): the conv result is dL/dy of y = drop(silu(gn(x)));
+    // the epilogue turns it into dyh = dL/dy * keep * silu'(yhat), stores THAT, and reduces per tile and channel
+    // (sum dyh, sum dyh*xhat) into gnp.  x = concat(gx1 [c1 ch], gx2 [c2 ch]) is the GroupNorm input.
+    const void* gx1;
+    const void* gx2;
+    const float* gstats;             // [N][G][2] raw moments of x
+    const float* ggamma;
+    const float* gbeta;
+    const unsigned char* gmask;      // optional dropout keep bits, one byte per 16-byte piece of y: [N][V][C/EPL]
+    int gc1, gc2, gG;
+    float geps, gcnt, ginv_keep;     // gcnt = voxels * channels per group
 };
 
 __device__ __forceinline__ int wrap(int i, int n) {
@@ -374,6 +385,115 @@ __device__ __forceinline__ void conv_epilogue(const f32x4 (&acc)[NV][NC], const 
                                cwave, lane, qstride);
 }
 
+// ---------------------------------------------------------------------------------------------
+// dgrad epilogue with the GroupNorm+SiLU(+dropout) backward reduction folded in (see ConvArgs::gx1).
+// Per output element: xhat = (x - mean) * rstd, yhat = xhat * gamma + beta, s = sigmoid(yhat),
+//   dyh = acc * keep/(1-p) * s * (1 + yhat * (1 - s));   S1[c] += dyh;  S2[c] += dyh * xhat;   store dyh.
+// The per-(tile, channel) sums go through the same fixed-order fold as the forward statistics (gn_partials_reduce):
+// the backward pass stays bit-reproducible and needs no float atomics.  vdm_gn_bwd_finalize sums the tiles.
+// A lane's NC*4 consecutive channels are processed in sub-chunks of <= 8 (one bf16 piece): the per-channel constants of a
+// sub-chunk (32 registers) are loaded once and reused over the NV rows.
+// ---------------------------------------------------------------------------------------------
+template <typename T, int SUB>
+__device__ __forceinline__ void ld_sub(const T* p, float (&f)[SUB]) {
+    constexpr int EPL = DT<T>::EPL;
+    if constexpr (SUB >= EPL) {
+#pragma unroll
+        for (int i = 0; i < SUB / EPL; ++i) {
+            Piece<T> pc;
+            pc.load(*reinterpret_cast<const uint4*>(p + i * EPL));
+#pragma unroll
+            for (int j = 0; j < EPL; ++j) f[i * EPL + j] = pc.f[j];
+        }
+    } else {                                              // bf16, 4 channels: half a piece
+        const uint2 u = *reinterpret_cast<const uint2*>(p);
+        f[0] = __builtin_bit_cast(float, u.x << 16); f[1] = __builtin_bit_cast(float, u.x & 0xffff0000u);
+        f[2] = __builtin_bit_cast(float, u.y << 16); f[3] = __builtin_bit_cast(float, u.y & 0xffff0000u);
+    }
+}
+template <typename T, int SUB>
+__device__ __forceinline__ void st_sub(T* p, const float (&f)[SUB]) {
+    constexpr int EPL = DT<T>::EPL;
+    if constexpr (SUB >= EPL) {
+#pragma unroll
+        for (int i = 0; i < SUB / EPL; ++i) {
+            Piece<T> pc;
+#pragma unroll
+            for (int j = 0; j < EPL; ++j) pc.f[j] = f[i * EPL + j];
+            *reinterpret_cast<uint4*>(p + i * EPL) = pc.store();
+        }
+    } else {
+        *reinterpret_cast<uint2*>(p) = make_uint2(pack_bf16x2(f[0], f[1]), pack_bf16x2(f[2], f[3]));
+    }
+}
+
+template <typename T, typename G, int NC, int NV>
+__device__ __forceinline__ void conv_epilogue_gnb(const f32x4 (&acc)[NV][NC], const ConvArgs& a, int n, int chunk, int oz0, int oy0,
+                                                  int ox0, int cwave, int lane, float* gn_sm, int tile, int cout0 = -1,
+                                                  int qstride = NC * 4) {
+    constexpr int EPL = DT<T>::EPL;
+    constexpr int CH = NC * 4;                             // channels per lane
+    constexpr int SUB = CH >= 8 ? 8 : 4;                   // channels per sub-chunk
+    constexpr int NSUB = CH / SUB;
+    constexpr int NB = SUB >= EPL ? SUB / EPL : 1;         // mask bytes (= 16-byte pieces) per sub-chunk
+    const int lx = lane & 15, q = lane >> 4;
+    if (cout0 < 0) cout0 = chunk * NC * 16;
+    const int cbase = cout0 + q * qstride;
+    const int C = a.Cout, gs = C / a.gG, PPV = C / EPL;
+    float gsum[CH], gsq[CH];                               // S1, S2
+#pragma unroll
+    for (int j = 0; j < CH; ++j) gsum[j] = gsq[j] = 0.f;
+    const bool lane_ok = cbase + CH <= C;                  // (host: C % (NC*4) == 0 and no lane straddles c1)
+    const bool first = cbase < a.gc1;
+    const T* xsrc = reinterpret_cast<const T*>(first ? a.gx1 : a.gx2);
+    const int xc = first ? a.gc1 : a.gc2, xoff = first ? cbase : cbase - a.gc1;
+    T* out = reinterpret_cast<T*>(a.out);
+#pragma unroll
+    for (int sc = 0; sc < NSUB; ++sc) {
+        float rs[SUB], mr[SUB], gam[SUB], bet[SUB];
+#pragma unroll
+        for (int j = 0; j < SUB; ++j) {
+            const int c = lane_ok ? cbase + sc * SUB + j : 0;
+            const int g = c / gs;
+            const float sum = a.gstats[((size_t)n * a.gG + g) * 2], sq = a.gstats[((size_t)n * a.gG + g) * 2 + 1];
+            const float mean = sum / a.gcnt;
+            const float var = fmaxf(sq / a.gcnt - mean * mean, 0.f);
+            const float rstd = rsqrtf(var + a.geps);
+            rs[j] = rstd; mr[j] = -mean * rstd; gam[j] = a.ggamma[c]; bet[j] = a.gbeta[c];
+        }
+#pragma unroll
+        for (int v = 0; v < NV; ++v) {
+            const int r = cwave * NV + v;
+            const int oz = oz0 + r / G::TY, oy = oy0 + r % G::TY, ox = ox0 + lx;
+            if (oz >= a.Dz || oy >= a.Dy || ox >= a.Dx || !lane_ok) continue;
+            const size_t vox = (((size_t)n * a.Dz + oz) * a.Dy + oy) * a.Dx + ox;
+            float xv[SUB];
+            ld_sub<T, SUB>(xsrc + vox * xc + xoff + sc * SUB, xv);
+            unsigned mb[NB];
+#pragma unroll
+            for (int b = 0; b < NB; ++b) mb[b] = a.gmask ? a.gmask[vox * PPV + (cbase + sc * SUB) / EPL + b] : 0xffu;
+            float d[SUB];
+#pragma unroll
+            for (int j = 0; j < SUB; ++j) {
+                const int jj = sc * SUB + j;               // channel inside the lane: accumulator (jj / 4, jj % 4)
+                const float xh = fmaf(xv[j], rs[j], mr[j]);
+                const float yh = fmaf(xh, gam[j], bet[j]);
+                const float sg = 1.0f / (1.0f + __expf(-yh));
+                const float ds = sg * fmaf(yh, 1.0f - sg, 1.0f);
+                const int bit = SUB >= EPL ? j % EPL : (cbase + jj) % EPL;
+                const float keep = ((mb[SUB >= EPL ? j / EPL : 0] >> bit) & 1u) ? a.ginv_keep : 0.f;
+                const float dd = acc[v][jj >> 2][jj & 3] * (ds * keep);
+                d[j] = dd;
+                gsum[jj] += dd;
+                gsq[jj] = fmaf(dd, xh, gsq[jj]);
+            }
+            st_sub<T, SUB>(out + vox * C + cbase + sc * SUB, d);
+        }
+    }
+    gn_partials_reduce<NC>(gsum, gsq, gn_sm, a.gnp + ((size_t)n * (a.ntz * a.nty * a.ntx) + tile) * a.Cout * 2, cout0, a.Cout, cwave,
+                           lane, qstride);
+}
+
 struct ClsEntry { int lds_off; int dx; };                   // halo offset ((dz*HY+dy)*HX)*64 bytes and dx in 0..2
 struct ClsTable {
     int n[8];                                                // entries per class
@@ -567,6 +687,7 @@ static void fwd_tile_shape(const ConvArgs& a, int dtype, int out_f32, int ks, in
 
 // launchers (defined in conv_fwd.hip / conv_cls.hip / conv_wgrad.hip)
 int launch_fwd(const ConvArgs& a, int dtype, int out_f32, int ks, int stride, int ups, int nc, hipStream_t s);
+int launch_fwd_gnb(const ConvArgs& a, int dtype, int nc, hipStream_t s);
 int run_cls(const vdm_conv_desc* d, int kind, const void* x, const void* w, const float* bias, const void* res, void* out,
             int cd, int ch, int cw, hipStream_t s, float* gn_partials = nullptr);
 int launch_wgrad_any(const WgradArgs& w, float* dw, float* db, int acc, int cout, int cin, int ks, int stride, int ups, size_t ws,

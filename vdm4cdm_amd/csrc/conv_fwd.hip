@@ -9,7 +9,8 @@ namespace vdm {
 // SPLIT (NC == 2 only): the weights are packed for 64-cout chunks (4 tiles per tap) but a workgroup takes HALF a chunk (tiles 2h,
 // 2h+1 = couts 16q + 8h .. +7 of every lane group q): twice the workgroups for the small grids of the deep levels, where a
 // workgroup's K-blocks run strictly one after the other and only co-resident workgroups overlap staging with MFMAs.
-template <typename T, typename TO, int KS, int STRIDE, int UPS, int NC, int TZ, int TY, bool SPLIT = false>
+// GNB: the GroupNorm+SiLU backward reduction is folded into the epilogue (dgrad launches that feed a GroupNorm: conv_epilogue_gnb).
+template <typename T, typename TO, int KS, int STRIDE, int UPS, int NC, int TZ, int TY, bool SPLIT = false, bool GNB = false>
 __global__ void __launch_bounds__(256, (TZ * TY <= 16 && NC <= 2) ? 3 : 2) conv_fwd_kernel(const ConvArgs a) {
     static_assert(!SPLIT || NC == 2, "half-chunk mode is the NC=2 kernel on NC=4 weights");
     constexpr int NCW = SPLIT ? 4 : NC;
@@ -57,12 +58,18 @@ __global__ void __launch_bounds__(256, (TZ * TY <= 16 && NC <= 2) ? 3 : 2) conv_
         }
     }
     constexpr int IMG = ((G::HVOX + 15) / 16) * 1024;     // the GN scratch sits behind the operand image
-    if constexpr (SPLIT)
-        conv_epilogue<T, TO, G, NC, NV>(acc, a, n, chunk, oz0, oy0, ox0, wave, lane, reinterpret_cast<float*>(lds + IMG),
-                                        (tz * a.nty + ty) * a.ntx + tx, (chunk >> 1) * 64 + (chunk & 1) * 8, 16);
+    float* gn_sm = reinterpret_cast<float*>(lds + IMG);
+    const int tile = (tz * a.nty + ty) * a.ntx + tx;
+    if constexpr (GNB) {
+        static_assert(sizeof(T) == sizeof(TO), "the folded GroupNorm backward stores dyh in the activation dtype");
+        if constexpr (SPLIT)
+            conv_epilogue_gnb<T, G, NC, NV>(acc, a, n, chunk, oz0, oy0, ox0, wave, lane, gn_sm, tile, (chunk >> 1) * 64 + (chunk & 1) * 8, 16);
+        else
+            conv_epilogue_gnb<T, G, NC, NV>(acc, a, n, chunk, oz0, oy0, ox0, wave, lane, gn_sm, tile);
+    } else if constexpr (SPLIT)
+        conv_epilogue<T, TO, G, NC, NV>(acc, a, n, chunk, oz0, oy0, ox0, wave, lane, gn_sm, tile, (chunk >> 1) * 64 + (chunk & 1) * 8, 16);
     else
-        conv_epilogue<T, TO, G, NC, NV>(acc, a, n, chunk, oz0, oy0, ox0, wave, lane, reinterpret_cast<float*>(lds + IMG),
-                                        (tz * a.nty + ty) * a.ntx + tx);
+        conv_epilogue<T, TO, G, NC, NV>(acc, a, n, chunk, oz0, oy0, ox0, wave, lane, gn_sm, tile);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -73,8 +80,8 @@ __global__ void __launch_bounds__(256, (TZ * TY <= 16 && NC <= 2) ? 3 : 2) conv_
 // the packed weights hold W[tap 4g+q][cout][ci] in the matching A-fragment slot (zero for tap >= 27, ci >= Cin).
 // These convs are bound by writing / reading the 32-channel tensor (HBM), not by MFMA.
 // ---------------------------------------------------------------------------------------------
-template <typename TO, int NC>
-__global__ void __launch_bounds__(256, 4) conv_kpack_kernel(const ConvArgs a) {
+template <typename TO, int NC, bool GNB = false>
+__global__ void __launch_bounds__(256, GNB ? 3 : 4) conv_kpack_kernel(const ConvArgs a) {
     using T = bf16_t;
     using G = Geo<3, 1, 4, 8>;
     constexpr int NV = G::NV, NG = (G::TAPS + 3) / 4;
@@ -151,18 +158,22 @@ __global__ void __launch_bounds__(256, 4) conv_kpack_kernel(const ConvArgs a) {
             for (int c = 0; c < NC; ++c) mma16<T>(acc[v][c], wf[g][c], af[v]);
     }
     constexpr int IMG = NCH * 1024;
-    conv_epilogue<T, TO, G, NC, NV>(acc, a, n, chunk, oz0, oy0, ox0, wave, lane, reinterpret_cast<float*>(lds + IMG),
-                                    (tz * a.nty + ty) * a.ntx + tx);
+    if constexpr (GNB)
+        conv_epilogue_gnb<T, G, NC, NV>(acc, a, n, chunk, oz0, oy0, ox0, wave, lane, reinterpret_cast<float*>(lds + IMG),
+                                        (tz * a.nty + ty) * a.ntx + tx);
+    else
+        conv_epilogue<T, TO, G, NC, NV>(acc, a, n, chunk, oz0, oy0, ox0, wave, lane, reinterpret_cast<float*>(lds + IMG),
+                                        (tz * a.nty + ty) * a.ntx + tx);
 }
 
-template <typename T, typename TO, int KS, int STRIDE, int UPS, int NC, int TZ, int TY, bool SPLIT = false>
+template <typename T, typename TO, int KS, int STRIDE, int UPS, int NC, int TZ, int TY, bool SPLIT = false, bool GNB = false>
 static int launch_fwd_cfg(const ConvArgs& a0, hipStream_t s) {
     using G = Geo<KS, STRIDE, TZ, TY>;
     ConvArgs a = a0;
     if (SPLIT) a.nchunks *= 2;
     a.ntz = cdiv(a.Dz, TZ); a.nty = cdiv(a.Dy, TY); a.ntx = cdiv(a.Dx, 16);
     const size_t lds = (size_t)((G::HVOX + 15) / 16) * 1024 + GN_SCRATCH_BYTES;
-    auto kern = conv_fwd_kernel<T, TO, KS, STRIDE, UPS, NC, TZ, TY, SPLIT>;
+    auto kern = conv_fwd_kernel<T, TO, KS, STRIDE, UPS, NC, TZ, TY, SPLIT, GNB>;
     static unsigned long long lds_done = 0;
     {
         int e = set_lds(kern, lds, lds_done);
@@ -175,7 +186,7 @@ static int launch_fwd_cfg(const ConvArgs& a0, hipStream_t s) {
     return VDM_OK;
 }
 
-template <typename T, typename TO, int KS, int STRIDE, int UPS, int NC>
+template <typename T, typename TO, int KS, int STRIDE, int UPS, int NC, bool GNB = false>
 static int launch_fwd_geo(const ConvArgs& a, hipStream_t s) {
     if constexpr (STRIDE == 2)
         return launch_fwd_cfg<T, TO, KS, STRIDE, UPS, NC, 2, 4>(a, s);
@@ -184,23 +195,23 @@ static int launch_fwd_geo(const ConvArgs& a, hipStream_t s) {
         small_grid_tile(a, tz, ty);
         if constexpr (NC == 4 && UPS == 0 && sizeof(TO) == 2) {
             if (uses_split(a, tz, ty)) {
-                if (tz == 1) return ty == 4 ? launch_fwd_cfg<T, TO, KS, STRIDE, UPS, 2, 1, 4, true>(a, s) : launch_fwd_cfg<T, TO, KS, STRIDE, UPS, 2, 1, 8, true>(a, s);
-                return launch_fwd_cfg<T, TO, KS, STRIDE, UPS, 2, 2, 8, true>(a, s);
+                if (tz == 1) return ty == 4 ? launch_fwd_cfg<T, TO, KS, STRIDE, UPS, 2, 1, 4, true, GNB>(a, s) : launch_fwd_cfg<T, TO, KS, STRIDE, UPS, 2, 1, 8, true, GNB>(a, s);
+                return launch_fwd_cfg<T, TO, KS, STRIDE, UPS, 2, 2, 8, true, GNB>(a, s);
             }
         }
-        if (tz == 1) return ty == 4 ? launch_fwd_cfg<T, TO, KS, STRIDE, UPS, NC, 1, 4>(a, s) : launch_fwd_cfg<T, TO, KS, STRIDE, UPS, NC, 1, 8>(a, s);
-        if (tz == 2) return launch_fwd_cfg<T, TO, KS, STRIDE, UPS, NC, 2, 8>(a, s);
-        return launch_fwd_cfg<T, TO, KS, STRIDE, UPS, NC, 4, 8>(a, s);
+        if (tz == 1) return ty == 4 ? launch_fwd_cfg<T, TO, KS, STRIDE, UPS, NC, 1, 4, false, GNB>(a, s) : launch_fwd_cfg<T, TO, KS, STRIDE, UPS, NC, 1, 8, false, GNB>(a, s);
+        if (tz == 2) return launch_fwd_cfg<T, TO, KS, STRIDE, UPS, NC, 2, 8, false, GNB>(a, s);
+        return launch_fwd_cfg<T, TO, KS, STRIDE, UPS, NC, 4, 8, false, GNB>(a, s);
     } else
-        return launch_fwd_cfg<T, TO, KS, STRIDE, UPS, NC, 4, 8>(a, s);
+        return launch_fwd_cfg<T, TO, KS, STRIDE, UPS, NC, 4, 8, false, GNB>(a, s);
 }
 
-template <typename T, typename TO, int KS, int STRIDE, int UPS>
+template <typename T, typename TO, int KS, int STRIDE, int UPS, bool GNB = false>
 static int launch_fwd_nc(const ConvArgs& a, int nc, hipStream_t s) {
     switch (nc) {
-        case 1: return launch_fwd_geo<T, TO, KS, STRIDE, UPS, 1>(a, s);
-        case 2: return launch_fwd_geo<T, TO, KS, STRIDE, UPS, 2>(a, s);
-        default: return launch_fwd_geo<T, TO, KS, STRIDE, UPS, 4>(a, s);
+        case 1: return launch_fwd_geo<T, TO, KS, STRIDE, UPS, 1, GNB>(a, s);
+        case 2: return launch_fwd_geo<T, TO, KS, STRIDE, UPS, 2, GNB>(a, s);
+        default: return launch_fwd_geo<T, TO, KS, STRIDE, UPS, 4, GNB>(a, s);
     }
 }
 
@@ -213,7 +224,7 @@ static int launch_fwd_variant(const ConvArgs& a, int ks, int stride, int ups, in
 }
 
 
-template <int NC>
+template <int NC, bool GNB = false>
 static int launch_kpack(const ConvArgs& a0, hipStream_t s) {
     using G = Geo<3, 1, 4, 8>;
     ConvArgs a = a0;
@@ -221,7 +232,7 @@ static int launch_kpack(const ConvArgs& a0, hipStream_t s) {
     const size_t lds = (size_t)((G::HVOX + 63) / 64) * 1024 + GN_SCRATCH_BYTES;
     const long long nwg = (long long)a.N * a.ntz * a.nty * a.ntx * a.nchunks;
     if (nwg > 0x7fffffffLL) { set_error("conv: grid too large"); return VDM_ERR_ARG; }
-    hipLaunchKernelGGL((conv_kpack_kernel<bf16_t, NC>), dim3((unsigned)nwg), dim3(256), lds, s, a);
+    hipLaunchKernelGGL((conv_kpack_kernel<bf16_t, NC, GNB>), dim3((unsigned)nwg), dim3(256), lds, s, a);
     VDM_LAUNCH_CHECK("conv_kpack_kernel");
     return VDM_OK;
 }
@@ -237,6 +248,13 @@ int launch_fwd(const ConvArgs& a, int dtype, int out_f32, int ks, int stride, in
         return launch_fwd_geo<bf16_t, float, 3, 1, 0, 1>(a, s);
     }
     return launch_fwd_variant<bf16_t, bf16_t>(a, ks, stride, ups, nc, s);
+}
+
+// dgrad of a 3x3x3 stride-1 conv with the GroupNorm+SiLU backward reduction folded into the epilogue (ConvArgs::gx1 ... set)
+int launch_fwd_gnb(const ConvArgs& a, int dtype, int nc, hipStream_t s) {
+    if (uses_kpack(dtype, 3, 1, 0, a.Cin, a.Cout, 0)) return nc == 1 ? launch_kpack<1, true>(a, s) : launch_kpack<2, true>(a, s);
+    if (dtype == VDM_F32) return launch_fwd_nc<float, float, 3, 1, 0, true>(a, nc, s);
+    return launch_fwd_nc<bf16_t, bf16_t, 3, 1, 0, true>(a, nc, s);
 }
 
 }  // namespace vdm

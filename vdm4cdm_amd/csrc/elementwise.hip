@@ -139,36 +139,48 @@ __global__ void __launch_bounds__(256) gn_stats_finalize_kernel(const float* __r
     }
 }
 
-// Same, from the per-tile channel partials a conv epilogue wrote (conv.hip, gn_partials_reduce): part[n][tile][C][2].
-// stats[n][g0 + g][k] = sum over tiles and over the gs channels of group g.  One block per (sample, group); thread t takes
-// the (tile, channel) pairs t, t+256, ... and a fixed LDS tree folds the 256 partial sums (deterministic).
+// Same, from the per-tile channel partials a conv epilogue wrote (conv_common.h, gn_partials_reduce): part[n][tile][C][2].
+// stats[n][g0 + g][k] = sum over tiles and over the gs channels of group g.  One block per (sample, group).  Thread t < S
+// (S = the largest multiple of gs <= 256) owns channel t % gs and takes the tiles t / gs, t / gs + S / gs, ...; the S partial
+// sums are folded per channel and then over the channels in a fixed order (deterministic).  chsum (optional): the per-channel
+// sums chsum[n][c0 + c] = sum_v x[n][v][c] (the analytic column sums of the GroupNorm backward need them).
 __global__ void __launch_bounds__(256) gn_stats_from_partials_kernel(const float* __restrict__ part, int tiles, int C, int gs, int G,
-                                                                     int g0, float* __restrict__ stats) {
+                                                                     int g0, float* __restrict__ stats, float* __restrict__ chsum,
+                                                                     int chsum_stride, int c0) {
     const int gc = C / gs;
     const int n = blockIdx.x / gc, g = blockIdx.x % gc;
     const float2* p2 = reinterpret_cast<const float2*>(part) + (size_t)n * tiles * C + (size_t)g * gs;
+    const int per = 256 / gs, S = per * gs;                 // tiles in flight per sweep, active threads
+    const int t = threadIdx.x, c = t % gs, b0 = t / gs;
     float s0 = 0.f, s1 = 0.f;
-    const int total = tiles * gs;
-    constexpr int U = 8;                                   // independent loads in flight per thread (the kernel is pure latency)
-    for (int i0 = threadIdx.x; i0 < total; i0 += 256 * U) {
-        float2 v[U];
+    if (t < S) {
+        constexpr int U = 8;                                // independent loads in flight per thread (the kernel is pure latency)
+        for (int b = b0; b < tiles; b += per * U) {
+            float2 v[U];
 #pragma unroll
-        for (int u = 0; u < U; ++u) {
-            const int i = i0 + u * 256;
-            const int b = i / gs, c = i - b * gs;
-            v[u] = i < total ? p2[(size_t)b * C + c] : make_float2(0.f, 0.f);
+            for (int u = 0; u < U; ++u) {
+                const int bb = b + u * per;
+                v[u] = bb < tiles ? p2[(size_t)bb * C + c] : make_float2(0.f, 0.f);
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u) { s0 += v[u].x; s1 += v[u].y; }
         }
-#pragma unroll
-        for (int u = 0; u < U; ++u) { s0 += v[u].x; s1 += v[u].y; }
     }
     __shared__ float sm[2][256];
-    sm[0][threadIdx.x] = s0; sm[1][threadIdx.x] = s1;
+    sm[0][t] = s0; sm[1][t] = s1;
     __syncthreads();
-    for (int w = 128; w > 0; w >>= 1) {
-        if ((int)threadIdx.x < w) { sm[0][threadIdx.x] += sm[0][threadIdx.x + w]; sm[1][threadIdx.x] += sm[1][threadIdx.x + w]; }
-        __syncthreads();
+    if (t < gs) {                                           // per-channel totals, fixed order
+        float a0 = 0.f, a1 = 0.f;
+        for (int j = 0; j < per; ++j) { a0 += sm[0][t + j * gs]; a1 += sm[1][t + j * gs]; }
+        if (chsum) chsum[(size_t)n * chsum_stride + c0 + g * gs + t] = a0;
+        sm[0][t] = a0; sm[1][t] = a1;                       // (slot t < gs is only read by this thread above)
     }
-    if (threadIdx.x < 2) stats[((size_t)n * G + g0 + g) * 2 + threadIdx.x] = sm[threadIdx.x][0];
+    __syncthreads();
+    if (t < 2) {
+        float tot = 0.f;
+        for (int j = 0; j < gs; ++j) tot += sm[t][j];
+        stats[((size_t)n * G + g0 + g) * 2 + t] = tot;
+    }
 }
 
 // per-(n, channel) affine of GN: y = x * A + B with A = rstd*gamma, B = beta - mean*rstd*gamma
@@ -197,6 +209,8 @@ struct GnArgs {
     long long colsum_stride;
     float* dgamma; float* dbeta; float* colsum; float* red;
     int blocks_per_n;
+    unsigned char* mask;     // fwd (optional out): dropout keep bits, one byte per 16-byte piece of y
+    const float* chan;       // bwd apply (fused path): per-sample channel sums [n][C][2] of (dyh, dyh*xhat)
 };
 
 template <typename T>
@@ -228,6 +242,7 @@ __global__ void __launch_bounds__(256) gn_silu_fwd_kernel(const GnArgs a) {
         Piece<T> p;
         p.load(raw);
         uint32_t rnd[4];
+        unsigned keepbits = 0;
 #pragma unroll
         for (int j = 0; j < EPL; ++j) {
             float o = silu_f(p.f[j] * A[j] + B[j]);
@@ -236,11 +251,14 @@ __global__ void __launch_bounds__(256) gn_silu_fwd_kernel(const GnArgs a) {
                     const uint64_t e4 = ((uint64_t)n * a.V * C + (uint64_t)i * EPL + j) >> 2;
                     Philox::gen((uint32_t)e4, (uint32_t)(e4 >> 32), 0x5eedu, 0u, (uint32_t)a.seed, (uint32_t)(a.seed >> 32), rnd);
                 }
-                o *= u32_to_unit(rnd[j & 3]) > a.p ? inv_keep : 0.f;
+                const bool keep = u32_to_unit(rnd[j & 3]) > a.p;
+                keepbits |= (keep ? 1u : 0u) << j;
+                o *= keep ? inv_keep : 0.f;
             }
             p.f[j] = o;
         }
         *reinterpret_cast<uint4*>(y + i * EPL) = p.store();
+        if (drop && a.mask) a.mask[(size_t)n * npieces + i] = (unsigned char)keepbits;
     }
 }
 
@@ -425,104 +443,130 @@ __global__ void __launch_bounds__(256) gn_silu_bwd_apply_kernel(const GnArgs a) 
     }
 }
 
-// out[n][c] += sum_v x[n][v][c]
+// ---------------------------------------------------------------------------------------------
+// GroupNorm backward, fused form: the dgrad conv that produced dL/dy already stored dyh = dL/dy * keep * silu'(yhat) and
+// reduced per (tile, channel) partial sums of (dyh, dyh * xhat) in its epilogue (conv_common.h, conv_epilogue_gnb).
+// finalize: one block per (sample, group) sums the tiles per channel in a fixed order ->
+//   chan[n][c] = {T1, T2};  red[n][g] = {sum_c gamma_c T1_c, sum_c gamma_c T2_c};
+//   colsum[n][c] = sum_v dx = rstd * (gamma_c T1_c - V m1 - m2 * rstd * (chsum[n][c] - V mean))   (analytic, optional)
+// apply: dx = rstd * (gamma * dyh - m1 - xhat * m2) (+ add), m = red / cnt; block 0 also writes dgamma / dbeta = sum_n chan.
+// No float atomics anywhere: the backward pass is bit-reproducible.
+// ---------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) gn_bwd_finalize_kernel(const float* __restrict__ part, int tiles, int C, int gs, int64_t V,
+                                                              const float* __restrict__ stats, const float* __restrict__ gamma,
+                                                              float eps, const float* __restrict__ chsum, float* __restrict__ red,
+                                                              float* __restrict__ chan, float* __restrict__ colsum,
+                                                              long long colsum_stride) {
+    const int G = C / gs;
+    const int n = blockIdx.x / G, g = blockIdx.x % G;
+    const float2* p2 = reinterpret_cast<const float2*>(part) + (size_t)n * tiles * C + (size_t)g * gs;
+    const int per = 256 / gs, S = per * gs;
+    const int t = threadIdx.x, c = t % gs, b0 = t / gs;
+    float s0 = 0.f, s1 = 0.f;
+    if (t < S) {
+        constexpr int U = 8;
+        for (int b = b0; b < tiles; b += per * U) {
+            float2 v[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int bb = b + u * per;
+                v[u] = bb < tiles ? p2[(size_t)bb * C + c] : make_float2(0.f, 0.f);
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u) { s0 += v[u].x; s1 += v[u].y; }
+        }
+    }
+    __shared__ float sm[2][256];
+    __shared__ float gr[2];
+    sm[0][t] = s0; sm[1][t] = s1;
+    __syncthreads();
+    float T1 = 0.f, T2 = 0.f, gam = 0.f;
+    if (t < gs) {
+        for (int j = 0; j < per; ++j) { T1 += sm[0][t + j * gs]; T2 += sm[1][t + j * gs]; }
+        gam = gamma[g * gs + t];
+        chan[((size_t)n * C + g * gs + t) * 2] = T1;
+        chan[((size_t)n * C + g * gs + t) * 2 + 1] = T2;
+        sm[0][t] = gam * T1; sm[1][t] = gam * T2;
+    }
+    __syncthreads();
+    if (t < 2) {
+        float tot = 0.f;
+        for (int j = 0; j < gs; ++j) tot += sm[t][j];
+        red[((size_t)n * G + g) * 2 + t] = tot;
+        gr[t] = tot;
+    }
+    if (colsum == nullptr) return;                          // (uniform)
+    __syncthreads();
+    if (t < gs) {
+        const float cnt = (float)V * gs;
+        const float sum = stats[((size_t)n * G + g) * 2], sq = stats[((size_t)n * G + g) * 2 + 1];
+        const float mean = sum / cnt;
+        const float rstd = rsqrtf(fmaxf(sq / cnt - mean * mean, 0.f) + eps);
+        const float m1 = gr[0] / cnt, m2 = gr[1] / cnt;
+        const float xhsum = rstd * (chsum[(size_t)n * C + g * gs + t] - (float)V * mean);
+        colsum[(size_t)n * colsum_stride + g * gs + t] = rstd * (gam * T1 - (float)V * m1 - m2 * xhsum);
+    }
+}
+
 template <typename T>
-__global__ void __launch_bounds__(256) colsum_kernel(const T* __restrict__ x, int C, int64_t V, float* __restrict__ out,
-                                                    long long out_stride, int blocks_per_n) {
+__global__ void __launch_bounds__(256) gn_bwd_apply_kernel(const GnArgs a) {
     constexpr int EPL = DT<T>::EPL;
-    const int PPV = C / EPL;
-    const int n = blockIdx.x / blocks_per_n, bn = blockIdx.x % blocks_per_n;
-    const int64_t npieces = V * PPV, stride = (int64_t)blocks_per_n * 256;
-    const uint4* xp = reinterpret_cast<const uint4*>(x + (size_t)n * V * C);
+    const int C = a.c1 + a.c2, gs = C / a.G, PPV = C / EPL, P1 = a.c1 / EPL;
+    const int n = blockIdx.x / a.blocks_per_n, bn = blockIdx.x % a.blocks_per_n;
+    if (blockIdx.x == 0) {                                  // parameter gradients: sum over the samples, fixed order
+        for (int c = threadIdx.x; c < C; c += 256) {
+            float db = 0.f, dg = 0.f;
+            for (int k = 0; k < a.n; ++k) { db += a.chan[((size_t)k * C + c) * 2]; dg += a.chan[((size_t)k * C + c) * 2 + 1]; }
+            a.dbeta[c] = db;
+            a.dgamma[c] = dg;
+        }
+    }
+    const int64_t npieces = a.V * PPV;
+    const int64_t stride = (int64_t)a.blocks_per_n * 256;
+    const float cnt = (float)a.V * gs;
+    const T* x1 = reinterpret_cast<const T*>(a.x1) + (size_t)n * a.V * a.c1;
+    const T* x2 = a.x2 ? reinterpret_cast<const T*>(a.x2) + (size_t)n * a.V * a.c2 : nullptr;
+    const T* dy = reinterpret_cast<const T*>(a.dy) + (size_t)n * a.V * C;          // dyh
+    const T* add1 = a.add1 ? reinterpret_cast<const T*>(a.add1) + (size_t)n * a.V * a.c1 : nullptr;
+    const T* add2 = a.add2 ? reinterpret_cast<const T*>(a.add2) + (size_t)n * a.V * a.c2 : nullptr;
+    const T* addp = pc_is_first(a, DT<T>::EPL, blockIdx.x, threadIdx.x) ? add1 : add2;
+    T* dx1 = reinterpret_cast<T*>(a.dx1) + (size_t)n * a.V * a.c1;
+    T* dx2 = a.dx2 ? reinterpret_cast<T*>(a.dx2) + (size_t)n * a.V * a.c2 : nullptr;
     const int64_t start = (int64_t)bn * 256 + threadIdx.x;
     const int pc = (int)(start % PPV);
-    float s[EPL];
+    // dx = dyh * P + x * Q + R   with  P = rstd gamma, Q = -rstd^2 m2, R = rstd (mean rstd m2 - m1)
+    float Pc[EPL], Qc[EPL], Rc[EPL];
 #pragma unroll
-    for (int j = 0; j < EPL; ++j) s[j] = 0.f;
+    for (int j = 0; j < EPL; ++j) {
+        const int c = pc * EPL + j, g = c / gs;
+        float A, B, mean, rstd;
+        const float gam = a.gamma[c];
+        gn_affine(a.stats, n, a.G, g, cnt, a.eps, gam, 0.f, A, B, mean, rstd);
+        const float m1 = a.red[((size_t)n * a.G + g) * 2] / cnt, m2 = a.red[((size_t)n * a.G + g) * 2 + 1] / cnt;
+        Pc[j] = A;
+        Qc[j] = -rstd * rstd * m2;
+        Rc[j] = rstd * (mean * rstd * m2 - m1);
+    }
     for (int64_t i = start; i < npieces; i += stride) {
-        Piece<T> p;
-        p.load(xp[i]);
+        const int64_t v = i / PPV;
+        const uint4 raw = pc < P1 ? *reinterpret_cast<const uint4*>(x1 + v * a.c1 + pc * EPL)
+                                  : *reinterpret_cast<const uint4*>(x2 + v * a.c2 + (pc - P1) * EPL);
+        Piece<T> px, pd, pa;
+        px.load(raw);
+        pd.load(*reinterpret_cast<const uint4*>(dy + i * EPL));
+        if (addp) pa.load(pc < P1 ? *reinterpret_cast<const uint4*>(addp + v * a.c1 + pc * EPL)
+                                  : *reinterpret_cast<const uint4*>(addp + v * a.c2 + (pc - P1) * EPL));
 #pragma unroll
-        for (int j = 0; j < EPL; ++j) s[j] += p.f[j];
-    }
-    __shared__ float shc[512];
-    for (int i = threadIdx.x; i < C; i += 256) shc[i] = 0.f;
-    __syncthreads();
-    bool writer = true;
-    if ((64 % PPV) == 0) {
-        for (int off = 32; off >= PPV; off >>= 1) {
-#pragma unroll
-            for (int j = 0; j < EPL; ++j) s[j] += __shfl_xor(s[j], off, 64);
+        for (int j = 0; j < EPL; ++j) {
+            float o = fmaf(pd.f[j], Pc[j], fmaf(px.f[j], Qc[j], Rc[j]));
+            if (addp) o += pa.f[j];
+            px.f[j] = o;
         }
-        writer = (int)(threadIdx.x & 63) < PPV;
+        if (pc < P1)
+            *reinterpret_cast<uint4*>(dx1 + v * a.c1 + pc * EPL) = px.store();
+        else
+            *reinterpret_cast<uint4*>(dx2 + v * a.c2 + (pc - P1) * EPL) = px.store();
     }
-    if (writer) {
-#pragma unroll
-        for (int j = 0; j < EPL; ++j) atomicAdd(&shc[pc * EPL + j], s[j]);
-    }
-    __syncthreads();
-    for (int i = threadIdx.x; i < C; i += 256) atomicAdd(&out[(size_t)n * out_stride + i], shc[i]);
-}
-
-// ---------------------------------------------------------------------------------------------
-// dilate2 / pool2_sum (piece granularity)
-// ---------------------------------------------------------------------------------------------
-template <typename T>
-__global__ void __launch_bounds__(256) dilate2_kernel(const T* __restrict__ coarse, T* __restrict__ fine, int N, int cd, int ch,
-                                                     int cw, int C) {
-    constexpr int EPL = DT<T>::EPL;
-    const int PPV = C / EPL;
-    const int fd = 2 * cd, fh = 2 * ch, fw = 2 * cw;
-    const int64_t total = (int64_t)N * fd * fh * fw * PPV;
-    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
-        int64_t r = i;
-        const int pc = r % PPV; r /= PPV;
-        const int x = r % fw; r /= fw;
-        const int y = r % fh; r /= fh;
-        const int z = r % fd; r /= fd;
-        const int n = (int)r;
-        uint4 v = make_uint4(0, 0, 0, 0);
-        if (((x | y | z) & 1) == 0)
-            v = *reinterpret_cast<const uint4*>(coarse + ((((int64_t)n * cd + (z >> 1)) * ch + (y >> 1)) * cw + (x >> 1)) * C + pc * EPL);
-        *reinterpret_cast<uint4*>(fine + i * EPL) = v;
-    }
-}
-
-template <typename T>
-__global__ void __launch_bounds__(256) pool2_sum_kernel(const T* __restrict__ fine, T* __restrict__ coarse, int N, int cd, int ch,
-                                                       int cw, int C) {
-    constexpr int EPL = DT<T>::EPL;
-    const int PPV = C / EPL;
-    const int fh = 2 * ch, fw = 2 * cw, fd = 2 * cd;
-    const int64_t total = (int64_t)N * cd * ch * cw * PPV;
-    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
-        int64_t r = i;
-        const int pc = r % PPV; r /= PPV;
-        const int x = r % cw; r /= cw;
-        const int y = r % ch; r /= ch;
-        const int z = r % cd; r /= cd;
-        const int n = (int)r;
-        float s[EPL];
-#pragma unroll
-        for (int j = 0; j < EPL; ++j) s[j] = 0.f;
-#pragma unroll
-        for (int k = 0; k < 8; ++k) {
-            const int fz = 2 * z + (k >> 2), fy = 2 * y + ((k >> 1) & 1), fx = 2 * x + (k & 1);
-            Piece<T> p;
-            p.load(*reinterpret_cast<const uint4*>(fine + ((((int64_t)n * fd + fz) * fh + fy) * fw + fx) * C + pc * EPL));
-#pragma unroll
-            for (int j = 0; j < EPL; ++j) s[j] += p.f[j];
-        }
-        Piece<T> o;
-#pragma unroll
-        for (int j = 0; j < EPL; ++j) o.f[j] = s[j];
-        *reinterpret_cast<uint4*>(coarse + i * EPL) = o.store();
-    }
-}
-
-template <typename TS, typename TD>
-__global__ void __launch_bounds__(256) cast_kernel(const TS* __restrict__ s, TD* __restrict__ d, int64_t n) {
-    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) st_elem<TD>(d + i, ld_elem<TS>(s + i));
 }
 
 template <typename T>
@@ -557,9 +601,11 @@ __global__ void __launch_bounds__(256) diffuse_kernel(const float* __restrict__ 
             z[(size_t)n * per + i] = al * x[(size_t)n * per + i] + si * eps[(size_t)n * per + i];
 }
 
+// per-block partial sums -> part[(n * blocks_per_n + bn) * 3 + k]; loss_terms_finalize_kernel folds them in a fixed order
+// (no float atomics: the loss is bit-reproducible).
 __global__ void __launch_bounds__(256) loss_terms_kernel(const float* __restrict__ x, const float* __restrict__ eps,
                                                         const float* __restrict__ eh, const float* __restrict__ eps0, float s0a0,
-                                                        const float* __restrict__ coef, int64_t per, float* __restrict__ sums,
+                                                        const float* __restrict__ coef, int64_t per, float* __restrict__ part,
                                                         float* __restrict__ deh, int blocks_per_n) {
     const int n = blockIdx.x / blocks_per_n, bn = blockIdx.x % blocks_per_n;
     const float cf = coef[n];
@@ -577,10 +623,28 @@ __global__ void __launch_bounds__(256) loss_terms_kernel(const float* __restrict
     __shared__ float sm[12];
     block_sum<3>(acc, sm);
     if (threadIdx.x == 0) {
-        atomicAdd(&sums[n * 3 + 0], acc[0]);
-        atomicAdd(&sums[n * 3 + 1], acc[1]);
-        atomicAdd(&sums[n * 3 + 2], acc[2]);
+        part[(size_t)blockIdx.x * 3 + 0] = acc[0];
+        part[(size_t)blockIdx.x * 3 + 1] = acc[1];
+        part[(size_t)blockIdx.x * 3 + 2] = acc[2];
     }
+}
+
+// out[i] (+)= sum_b part[(i / width * blocks + b) * width + i % width]: fixed-order fold of per-block partials.  One block per
+// output: thread t sums the partials t, t + 256, ..., then a fixed LDS tree (deterministic).
+__global__ void __launch_bounds__(256) fold_partials_kernel(const float* __restrict__ part, int blocks, int width, float* __restrict__ out,
+                                                           int accumulate) {
+    const int i = blockIdx.x;
+    const float* p = part + (size_t)(i / width) * blocks * width + i % width;
+    float s = 0.f;
+    for (int b = threadIdx.x; b < blocks; b += 256) s += p[(size_t)b * width];
+    __shared__ float sm[256];
+    sm[threadIdx.x] = s;
+    __syncthreads();
+    for (int w = 128; w > 0; w >>= 1) {
+        if ((int)threadIdx.x < w) sm[threadIdx.x] += sm[threadIdx.x + w];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) out[i] = accumulate ? out[i] + sm[0] : sm[0];
 }
 
 __device__ __forceinline__ void box_muller(uint32_t u0, uint32_t u1, float& n0, float& n1) {
@@ -635,7 +699,7 @@ __global__ void __launch_bounds__(256) ancestral_kernel(float* __restrict__ z, c
 
 __global__ void step_inc_kernel(int32_t* p) { *p += 1; }
 
-__global__ void __launch_bounds__(256) sumsq_kernel(const float* __restrict__ x, int64_t n, float* __restrict__ out) {
+__global__ void __launch_bounds__(256) sumsq_kernel(const float* __restrict__ x, int64_t n, float* __restrict__ part) {
     float acc[1] = {0.f};
     const int64_t n4 = n >> 2;
     const float4* x4 = reinterpret_cast<const float4*>(x);
@@ -647,7 +711,7 @@ __global__ void __launch_bounds__(256) sumsq_kernel(const float* __restrict__ x,
         for (int64_t i = (n4 << 2) + threadIdx.x; i < n; i += 256) acc[0] += x[i] * x[i];
     __shared__ float sm[4];
     block_sum<1>(acc, sm);
-    if (threadIdx.x == 0) atomicAdd(out, acc[0]);
+    if (threadIdx.x == 0) part[blockIdx.x] = acc[0];
 }
 
 // blocks per sample such that blocks*256 is a multiple of pieces-per-voxel (fixed piece column per thread)
@@ -681,11 +745,13 @@ static int gn_common_check(int c1, int c2, int n, int64_t voxels, int groups, in
 }
 
 extern "C" int vdm_gn_stats(const void* x1, int c1, const void* x2, int c2, int n, int64_t voxels, int groups, int dtype, float* stats,
-                            float* workspace, const float* part1, int tiles1, const float* part2, int tiles2, void* stream) {
+                            float* workspace, const float* part1, int tiles1, const float* part2, int tiles2, float* chsum,
+                            void* stream) {
     int e = gn_common_check(c1, c2, n, voxels, groups, dtype, "gn_stats");
     if (e) return e;
     VDM_REQUIRE(stats && workspace && (x1 || part1) && (c2 == 0 || x2 || part2), "gn_stats: NULL pointer");
     VDM_REQUIRE((!part1 || tiles1 > 0) && (!part2 || tiles2 > 0), "gn_stats: partials need a positive tile count");
+    VDM_REQUIRE(!chsum || (part1 && (c2 == 0 || part2)), "gn_stats: per-channel sums are produced from conv partials only");
     hipStream_t s = (hipStream_t)stream;
     const int epl = dtype == VDM_F32 ? 4 : 8;
     const int gs = (c1 + c2) / groups;
@@ -697,7 +763,8 @@ extern "C" int vdm_gn_stats(const void* x1, int c1, const void* x2, int c2, int 
     for (int k = 0; k < 2; ++k) {
         if (cs[k] == 0) continue;
         if (parts[k]) {                                   // statistics already reduced per tile by the producing conv
-            hipLaunchKernelGGL(gn_stats_from_partials_kernel, dim3(n * (cs[k] / gs)), dim3(256), 0, s, parts[k], tiles[k], cs[k], gs, groups, g0, stats);
+            hipLaunchKernelGGL(gn_stats_from_partials_kernel, dim3(n * (cs[k] / gs)), dim3(256), 0, s, parts[k], tiles[k], cs[k], gs, groups, g0, stats,
+                               chsum, c1 + c2, g0 * gs);
             VDM_LAUNCH_CHECK("gn_stats_from_partials_kernel");
             g0 += cs[k] / gs;
             continue;
@@ -728,13 +795,14 @@ static GnArgs gn_args(const void* x1, int c1, const void* x2, int c2, int n, int
 
 extern "C" int vdm_gn_silu_fwd(const void* x1, int c1, const void* x2, int c2, int n, int64_t voxels, int groups, int dtype,
                                const float* stats, const float* gamma, const float* beta, float eps, float dropout_p, uint64_t seed,
-                               void* y, void* stream) {
+                               void* y, uint8_t* keep_mask, void* stream) {
     int e = gn_common_check(c1, c2, n, voxels, groups, dtype, "gn_silu_fwd");
     if (e) return e;
     VDM_REQUIRE(x1 && stats && gamma && beta && y && (c2 == 0 || x2), "gn_silu_fwd: NULL pointer");
     VDM_REQUIRE(dropout_p >= 0.f && dropout_p < 1.f, "gn_silu_fwd: dropout_p out of range");
     GnArgs a = gn_args(x1, c1, x2, c2, n, voxels, groups, dtype, stats, gamma, beta, eps, dropout_p, seed);
     a.y = y;
+    a.mask = keep_mask;
     hipStream_t s = (hipStream_t)stream;
     if (dtype == VDM_F32)
         hipLaunchKernelGGL(gn_silu_fwd_kernel<float>, dim3(a.blocks_per_n * n), dim3(256), 0, s, a);
@@ -767,61 +835,34 @@ extern "C" int vdm_gn_silu_bwd(const void* x1, int c1, const void* x2, int c2, i
     return VDM_OK;
 }
 
-extern "C" int vdm_colsum(const void* x, int n, int64_t voxels, int c, int dtype, float* out, int64_t out_stride, void* stream) {
-    const int epl = dtype == VDM_F32 ? 4 : 8;
-    VDM_REQUIRE(x && out && n > 0 && voxels > 0 && c > 0 && c <= 512 && c % epl == 0, "colsum: bad arguments (c=%d)", c);
-    const int ppv = c / epl;
-    const int bpn = blocks_per_sample(voxels * ppv, ppv, n);
-    hipStream_t s = (hipStream_t)stream;
-    if (dtype == VDM_F32)
-        hipLaunchKernelGGL(colsum_kernel<float>, dim3(bpn * n), dim3(256), 0, s, (const float*)x, c, voxels, out, (long long)out_stride, bpn);
-    else
-        hipLaunchKernelGGL(colsum_kernel<bf16_t>, dim3(bpn * n), dim3(256), 0, s, (const bf16_t*)x, c, voxels, out, (long long)out_stride, bpn);
-    VDM_LAUNCH_CHECK("colsum_kernel");
+extern "C" int vdm_gn_bwd_finalize(const float* partials, int tiles, int n, int c, int groups, int64_t voxels, const float* stats,
+                                   const float* gamma, float eps, const float* chsum, float* red, float* chan, float* colsum,
+                                   int64_t colsum_stride, void* stream) {
+    VDM_REQUIRE(partials && stats && gamma && red && chan, "gn_bwd_finalize: NULL pointer");
+    VDM_REQUIRE(tiles > 0 && n > 0 && groups > 0 && c > 0 && c % groups == 0 && voxels > 0, "gn_bwd_finalize: bad sizes");
+    VDM_REQUIRE(c / groups <= 256, "gn_bwd_finalize: more than 256 channels per group");
+    VDM_REQUIRE(!colsum || chsum, "gn_bwd_finalize: the analytic column sums need the per-channel sums of the GroupNorm input");
+    hipLaunchKernelGGL(gn_bwd_finalize_kernel, dim3(n * groups), dim3(256), 0, (hipStream_t)stream, partials, tiles, c, c / groups, voxels,
+                       stats, gamma, eps, chsum, red, chan, colsum, (long long)colsum_stride);
+    VDM_LAUNCH_CHECK("gn_bwd_finalize_kernel");
     return VDM_OK;
 }
 
-extern "C" int vdm_dilate2(const void* coarse, void* fine, int n, int cd, int ch, int cw, int c, int dtype, void* stream) {
-    const int epl = dtype == VDM_F32 ? 4 : 8;
-    VDM_REQUIRE(coarse && fine && n > 0 && cd > 0 && ch > 0 && cw > 0 && c % epl == 0, "dilate2: bad arguments");
-    const int64_t total = (int64_t)n * cd * ch * cw * 8 * (c / epl);
+extern "C" int vdm_gn_bwd_apply(const void* x1, int c1, const void* x2, int c2, int n, int64_t voxels, int groups, int dtype,
+                                const float* stats, const float* gamma, float eps, const void* dyh, const float* red, const float* chan,
+                                const void* add1, const void* add2, void* dx1, void* dx2, float* dgamma, float* dbeta, void* stream) {
+    int e = gn_common_check(c1, c2, n, voxels, groups, dtype, "gn_bwd_apply");
+    if (e) return e;
+    VDM_REQUIRE(x1 && stats && gamma && dyh && red && chan && dx1 && dgamma && dbeta && (c2 == 0 || (x2 && dx2)), "gn_bwd_apply: NULL pointer");
+    GnArgs a = gn_args(x1, c1, x2, c2, n, voxels, groups, dtype, stats, gamma, gamma, eps, 0.f, 0);
+    a.dy = dyh; a.add1 = add1; a.add2 = add2; a.dx1 = dx1; a.dx2 = dx2; a.dgamma = dgamma; a.dbeta = dbeta;
+    a.red = const_cast<float*>(red); a.chan = chan;
     hipStream_t s = (hipStream_t)stream;
     if (dtype == VDM_F32)
-        hipLaunchKernelGGL(dilate2_kernel<float>, dim3(grid_for(total, 256 * 4)), dim3(256), 0, s, (const float*)coarse, (float*)fine, n, cd, ch, cw, c);
+        hipLaunchKernelGGL(gn_bwd_apply_kernel<float>, dim3(a.blocks_per_n * n), dim3(256), 0, s, a);
     else
-        hipLaunchKernelGGL(dilate2_kernel<bf16_t>, dim3(grid_for(total, 256 * 4)), dim3(256), 0, s, (const bf16_t*)coarse, (bf16_t*)fine, n, cd, ch, cw, c);
-    VDM_LAUNCH_CHECK("dilate2_kernel");
-    return VDM_OK;
-}
-
-extern "C" int vdm_pool2_sum(const void* fine, void* coarse, int n, int cd, int ch, int cw, int c, int dtype, void* stream) {
-    const int epl = dtype == VDM_F32 ? 4 : 8;
-    VDM_REQUIRE(coarse && fine && n > 0 && cd > 0 && ch > 0 && cw > 0 && c % epl == 0, "pool2_sum: bad arguments");
-    const int64_t total = (int64_t)n * cd * ch * cw * (c / epl);
-    hipStream_t s = (hipStream_t)stream;
-    if (dtype == VDM_F32)
-        hipLaunchKernelGGL(pool2_sum_kernel<float>, dim3(grid_for(total, 256 * 2)), dim3(256), 0, s, (const float*)fine, (float*)coarse, n, cd, ch, cw, c);
-    else
-        hipLaunchKernelGGL(pool2_sum_kernel<bf16_t>, dim3(grid_for(total, 256 * 2)), dim3(256), 0, s, (const bf16_t*)fine, (bf16_t*)coarse, n, cd, ch, cw, c);
-    VDM_LAUNCH_CHECK("pool2_sum_kernel");
-    return VDM_OK;
-}
-
-extern "C" int vdm_cast(const void* src, int sd, void* dst, int dd, int64_t n, void* stream) {
-    VDM_REQUIRE(src && dst && n >= 0, "cast: bad arguments");
-    hipStream_t s = (hipStream_t)stream;
-    const unsigned g = grid_for(n, 256 * 4);
-    if (sd == VDM_F32 && dd == VDM_BF16)
-        hipLaunchKernelGGL((cast_kernel<float, bf16_t>), dim3(g), dim3(256), 0, s, (const float*)src, (bf16_t*)dst, n);
-    else if (sd == VDM_BF16 && dd == VDM_F32)
-        hipLaunchKernelGGL((cast_kernel<bf16_t, float>), dim3(g), dim3(256), 0, s, (const bf16_t*)src, (float*)dst, n);
-    else if (sd == VDM_F32 && dd == VDM_F32)
-        hipLaunchKernelGGL((cast_kernel<float, float>), dim3(g), dim3(256), 0, s, (const float*)src, (float*)dst, n);
-    else {
-        set_error("cast: unsupported dtype pair %d -> %d", sd, dd);
-        return VDM_ERR_UNSUPPORTED;
-    }
-    VDM_LAUNCH_CHECK("cast_kernel");
+        hipLaunchKernelGGL(gn_bwd_apply_kernel<bf16_t>, dim3(a.blocks_per_n * n), dim3(256), 0, s, a);
+    VDM_LAUNCH_CHECK("gn_bwd_apply_kernel");
     return VDM_OK;
 }
 
@@ -855,11 +896,12 @@ extern "C" int vdm_diffuse(const float* x, const float* eps, const float* alpha,
 }
 
 extern "C" int vdm_loss_terms(const float* x, const float* eps, const float* eps_hat, const float* eps0, float s0a0, const float* coef,
-                              int n, int64_t per, float* sums, float* d_eps_hat, void* stream) {
-    VDM_REQUIRE(x && eps && eps_hat && eps0 && coef && sums && d_eps_hat && n > 0 && per > 0, "loss_terms: bad arguments");
+                              int n, int64_t per, float* sums, float* d_eps_hat, float* workspace, void* stream) {
+    VDM_REQUIRE(x && eps && eps_hat && eps0 && coef && sums && d_eps_hat && workspace && n > 0 && per > 0, "loss_terms: bad arguments");
     const int bpn = bpn_for(per, n);
-    hipLaunchKernelGGL(loss_terms_kernel, dim3(bpn * n), dim3(256), 0, (hipStream_t)stream, x, eps, eps_hat, eps0, s0a0, coef, per, sums,
+    hipLaunchKernelGGL(loss_terms_kernel, dim3(bpn * n), dim3(256), 0, (hipStream_t)stream, x, eps, eps_hat, eps0, s0a0, coef, per, workspace,
                        d_eps_hat, bpn);
+    hipLaunchKernelGGL(fold_partials_kernel, dim3(n * 3), dim3(256), 0, (hipStream_t)stream, (const float*)workspace, bpn, 3, sums, 1);
     VDM_LAUNCH_CHECK("loss_terms_kernel");
     return VDM_OK;
 }
@@ -886,10 +928,12 @@ extern "C" int vdm_step_inc(int32_t* step_ptr, void* stream) {
     return VDM_OK;
 }
 
-extern "C" int vdm_sumsq(const float* x, int64_t n, float* out, void* stream) {
-    VDM_REQUIRE(x && out && n > 0, "sumsq: bad arguments");
+extern "C" int vdm_sumsq(const float* x, int64_t n, float* out, float* workspace, void* stream) {
+    VDM_REQUIRE(x && out && workspace && n > 0, "sumsq: bad arguments");
     VDM_REQUIRE(((uintptr_t)x & 15) == 0, "sumsq: x must be 16-byte aligned");
-    hipLaunchKernelGGL(sumsq_kernel, dim3(grid_for(n, 256 * 16)), dim3(256), 0, (hipStream_t)stream, x, n, out);
+    const unsigned g = grid_for(n, 256 * 16);
+    hipLaunchKernelGGL(sumsq_kernel, dim3(g), dim3(256), 0, (hipStream_t)stream, x, n, workspace);
+    hipLaunchKernelGGL(fold_partials_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, (const float*)workspace, (int)g, 1, out, 1);
     VDM_LAUNCH_CHECK("sumsq_kernel");
     return VDM_OK;
 }

@@ -9,7 +9,7 @@ import ctypes as C
 import torch
 
 from . import _lib
-from ._lib import ConvDesc, PACK_DGRAD, PACK_FWD, VDM_BF16, VDM_F32, check
+from ._lib import ConvDesc, GnFold, PACK_DGRAD, PACK_FWD, VDM_BF16, VDM_F32, check
 
 GN_EPS = 1e-5
 
@@ -232,6 +232,42 @@ class Conv:
                 dout.numel() * es + out.numel() * es + (residual.numel() * es if residual is not None else 0))
         return out
 
+    def gn_fold_ok(self, c1, c2, dtype):
+        """Can dgrad_gn be used for a GroupNorm over concat(c1, c2) = this conv's input channels?  (a lane's 4*NC consecutive
+        channels must not straddle the concat boundary; 3x3x3 stride-1 convs only)"""
+        span = 4 * _nc_for(self.cin, dtype)
+        return (self.ksize == 3 and self.stride == 1 and not self.upsample and c1 + c2 == self.cin and self.cin % span == 0
+                and (c2 == 0 or c1 % span == 0) and self.cin % epl(dtype) == 0)
+
+    def dgrad_gn(self, dout, x1, x2, groups, stats, gamma, beta, keep_mask=None, dropout_p=0.0, out=None):
+        """Input gradient of a conv whose input was drop(silu(gn(concat(x1, x2)))), with the GroupNorm backward reduction folded
+        into the epilogue.  Returns dyh = dL/dy * keep/(1-p) * silu'(yhat) with `.gnb_partials` ([N, tiles, cin, 2]: per-tile
+        sums of dyh and dyh * xhat) for gn_bwd_finalize."""
+        L = _lib.lib()
+        _contig(dout, x1, x2, stats, gamma, beta, keep_mask)
+        n, od, oh, ow, c = dout.shape
+        assert c == cpad(self.cout, dout.dtype)
+        c1, c2 = x1.shape[-1], (0 if x2 is None else x2.shape[-1])
+        assert self.gn_fold_ok(c1, c2, dout.dtype), "dgrad_gn: unsupported channel split"
+        assert tuple(x1.shape[:-1]) == (n, od, oh, ow) and x1.dtype == dout.dtype
+        if out is None:
+            out = torch.empty((n, od, oh, ow, self.cin), dtype=dout.dtype, device=dout.device)
+        d = self.desc(n, od, oh, ow, dout.dtype)
+        tiles = L.vdm_conv_dgrad_gn_tiles(d)
+        part = torch.empty((n, tiles, self.cin, 2), dtype=torch.float32, device=dout.device)
+        f = GnFold(x1=_p(x1), x2=_p(x2), c1=c1, c2=c2, groups=groups, stats=_p(stats), gamma=_p(gamma), beta=_p(beta), eps=GN_EPS,
+                   inv_keep=1.0 / (1.0 - dropout_p) if keep_mask is not None else 1.0, keep_mask=_p(keep_mask), partials=_p(part))
+        ev = _pb("conv3")
+        check(L.vdm_conv_dgrad_gn(d, _p(dout), _p(self.wd), _p(out), C.byref(f), _s()), "vdm_conv_dgrad_gn")
+        out.gnb_partials = part
+        if ev is not None:
+            es = dout.element_size()
+            var = L.vdm_conv_kernel_variant(d, 1)
+            key = "conv_kpack_kernel" if var == 2 else (f"conv_fwd_kernel<{_tname(dout.dtype)},k3,s1,NC2,split>" if var == 3 else
+                                                        f"conv_fwd_kernel<{_tname(dout.dtype)},k3,s1,NC{_nc_for(self.cin, dout.dtype)}>")
+            _pe(ev, key + "+gnb", 2.0 * n * od * oh * ow * 27 * self.cin * self.cout, dout.numel() * es + 2 * out.numel() * es)
+        return out
+
     def wgrad(self, x, dout, dw, dbias=None, accumulate=False):
         """dw (fp32 view [taps, cout, cin]) = sum_v dout[v] (x) x[v + tap];  dbias (optional, ksize 3): sum_v dout[v]."""
         L = _lib.lib()
@@ -262,7 +298,9 @@ def _nv(x):
 _gn_ws = {}
 
 
-def gn_stats(x1, x2, groups, out=None):
+def gn_stats(x1, x2, groups, out=None, chsum=False):
+    """stats[n][g] = (sum, sum of squares) of concat(x1, x2).  chsum=True (sources produced by Conv.fwd(gn=True) only): also the
+    per-channel sums, attached as `out.chsum` ([N, C] fp32)."""
     L = _lib.lib()
     _contig(x1, x2)
     n, v = _nv(x1)
@@ -274,15 +312,21 @@ def gn_stats(x1, x2, groups, out=None):
     c2 = 0 if x2 is None else x2.shape[-1]
     p1 = getattr(x1, "gn_partials", None)       # set by Conv.fwd(..., gn=True): that source needs no pass over the tensor
     p2 = getattr(x2, "gn_partials", None) if x2 is not None else None
+    cs = None
+    if chsum and p1 is not None and (x2 is None or p2 is not None):
+        cs = torch.empty((n, x1.shape[-1] + c2), dtype=torch.float32, device=x1.device)
     ev = _pb()
     check(L.vdm_gn_stats(_p(x1), x1.shape[-1], _p(x2), c2, n, v, groups, dt_id(x1.dtype), _p(out), _p(ws),
-                         _p(p1), 0 if p1 is None else p1.shape[1], _p(p2), 0 if p2 is None else p2.shape[1], _s()), "vdm_gn_stats")
+                         _p(p1), 0 if p1 is None else p1.shape[1], _p(p2), 0 if p2 is None else p2.shape[1], _p(cs), _s()), "vdm_gn_stats")
+    out.chsum = cs
     _pe(ev, "gn_stats", 0.0, (x1.numel() * x1.element_size() if p1 is None else 0)
         + (x2.numel() * x2.element_size() if (x2 is not None and p2 is None) else 0))
     return out
 
 
-def gn_silu_fwd(x1, x2, groups, stats, gamma, beta, dropout_p=0.0, seed=0, out=None):
+def gn_silu_fwd(x1, x2, groups, stats, gamma, beta, dropout_p=0.0, seed=0, out=None, want_mask=False):
+    """want_mask (with dropout_p > 0): the dropout keep bits are also written, one byte per 16-byte piece, attached as
+    `out.keep_mask` (consumed by Conv.dgrad_gn)."""
     L = _lib.lib()
     _contig(x1, x2, gamma, beta, stats)
     n, v = _nv(x1)
@@ -290,9 +334,13 @@ def gn_silu_fwd(x1, x2, groups, stats, gamma, beta, dropout_p=0.0, seed=0, out=N
     c2 = 0 if x2 is None else x2.shape[-1]
     if out is None:
         out = torch.empty(x1.shape[:-1] + (c1 + c2,), dtype=x1.dtype, device=x1.device)
+    mask = None
+    if want_mask and dropout_p > 0.0:
+        mask = torch.empty((n, v, (c1 + c2) // epl(x1.dtype)), dtype=torch.uint8, device=x1.device)
     ev = _pb()
     check(L.vdm_gn_silu_fwd(_p(x1), c1, _p(x2), c2, n, v, groups, dt_id(x1.dtype), _p(stats), _p(gamma), _p(beta), GN_EPS,
-                            float(dropout_p), int(seed), _p(out), _s()), "vdm_gn_silu_fwd")
+                            float(dropout_p), int(seed), _p(out), _p(mask), _s()), "vdm_gn_silu_fwd")
+    out.keep_mask = mask
     _pe(ev, "gn_silu_fwd", 0.0, 2.0 * out.numel() * out.element_size())
     return out
 
@@ -322,36 +370,35 @@ def gn_silu_bwd(x1, x2, groups, stats, gamma, beta, dy, dgamma, dbeta, add1=None
     return dx1, dx2
 
 
-def colsum(x, out, out_stride=None):
-    """out[n*out_stride + c] += sum over voxels of x[n, ..., c].  out: fp32 [N, >=c] view (row stride honoured),
-    or with out_stride=0 a [c] vector that receives the sum over samples too (bias gradients)."""
+def gn_bwd_fused(x1, x2, groups, stats, gamma, dyh, dgamma, dbeta, add1=None, add2=None, colsum=None, dx1=None, dx2=None):
+    """Second half of the GroupNorm+SiLU backward after Conv.dgrad_gn (dyh carries `.gnb_partials`).  Writes dgamma / dbeta,
+    colsum (optional [N, >=C] fp32 view, row stride honoured; needs stats.chsum) and returns (dx1, dx2).  No float atomics."""
     L = _lib.lib()
-    _contig(x)
-    n, v = _nv(x)
-    assert out.dtype == torch.float32
-    if out_stride is None:
-        assert out.dim() == 2 and out.stride(1) == 1 and out.shape[0] == n
-        out_stride = out.stride(0)
-    check(L.vdm_colsum(_p(x), n, v, x.shape[-1], dt_id(x.dtype), _p(out), out_stride, _s()), "vdm_colsum")
-    return out
-
-
-def dilate2(coarse):
-    L = _lib.lib()
-    _contig(coarse)
-    n, d, h, w, c = coarse.shape
-    fine = torch.empty((n, 2 * d, 2 * h, 2 * w, c), dtype=coarse.dtype, device=coarse.device)
-    check(L.vdm_dilate2(_p(coarse), _p(fine), n, d, h, w, c, dt_id(coarse.dtype), _s()), "vdm_dilate2")
-    return fine
-
-
-def pool2_sum(fine):
-    L = _lib.lib()
-    _contig(fine)
-    n, d, h, w, c = fine.shape
-    coarse = torch.empty((n, d // 2, h // 2, w // 2, c), dtype=fine.dtype, device=fine.device)
-    check(L.vdm_pool2_sum(_p(fine), _p(coarse), n, d // 2, h // 2, w // 2, c, dt_id(fine.dtype), _s()), "vdm_pool2_sum")
-    return coarse
+    _contig(x1, x2, dyh, add1, add2, gamma, dgamma, dbeta, stats)
+    n, v = _nv(x1)
+    c1 = x1.shape[-1]
+    c2 = 0 if x2 is None else x2.shape[-1]
+    C_ = c1 + c2
+    part = dyh.gnb_partials
+    assert part is not None and part.shape[0] == n and part.shape[2] == C_ and dyh.shape[-1] == C_
+    red = torch.empty((n, groups, 2), dtype=torch.float32, device=x1.device)
+    chan = torch.empty((n, C_, 2), dtype=torch.float32, device=x1.device)
+    cstride, chsum = 0, None
+    if colsum is not None:
+        assert colsum.dtype == torch.float32 and colsum.stride(1) == 1 and colsum.shape[0] == n
+        cstride, chsum = colsum.stride(0), getattr(stats, "chsum", None)
+        assert chsum is not None, "gn_bwd_fused: colsum needs the per-channel sums (gn_stats(..., chsum=True))"
+    if dx1 is None:
+        dx1 = dyh if x2 is None else torch.empty_like(x1)
+    if x2 is not None and dx2 is None:
+        dx2 = torch.empty_like(x2)
+    ev = _pb()
+    check(L.vdm_gn_bwd_finalize(_p(part), part.shape[1], n, C_, groups, v, _p(stats), _p(gamma), GN_EPS, _p(chsum), _p(red), _p(chan),
+                                _p(colsum), cstride, _s()), "vdm_gn_bwd_finalize")
+    check(L.vdm_gn_bwd_apply(_p(x1), c1, _p(x2), c2, n, v, groups, dt_id(x1.dtype), _p(stats), _p(gamma), GN_EPS, _p(dyh), _p(red), _p(chan),
+                             _p(add1), _p(add2), _p(dx1), _p(dx2), _p(dgamma), _p(dbeta), _s()), "vdm_gn_bwd_apply")
+    _pe(ev, "gn_bwd(finalize+apply)", 0.0, (3.0 + (1.0 if add1 is not None else 0.0)) * dyh.numel() * dyh.element_size())
+    return dx1, dx2
 
 
 def pack_input(a, b, dtype, out=None):
@@ -376,12 +423,24 @@ def diffuse(x, eps, alpha, sigma, out=None):
     return out
 
 
+_red_ws = {}
+
+
+def _reduce_ws(device):
+    """per-(device, stream) scratch of the fixed-order two-stage reductions (loss terms, gradient norm)"""
+    key = (device, _s())
+    ws = _red_ws.get(key)
+    if ws is None:
+        ws = _red_ws[key] = torch.empty(2048 * 3, dtype=torch.float32, device=device)
+    return ws
+
+
 def loss_terms(x, eps, eps_hat, eps0, sigma0_over_alpha0, coef, sums, d_eps_hat):
     L = _lib.lib()
     _contig(x, eps, eps_hat, eps0, coef, sums, d_eps_hat)
     n = x.shape[0]
     check(L.vdm_loss_terms(_p(x), _p(eps), _p(eps_hat), _p(eps0), float(sigma0_over_alpha0), _p(coef), n, x.numel() // n,
-                           _p(sums), _p(d_eps_hat), _s()), "vdm_loss_terms")
+                           _p(sums), _p(d_eps_hat), _p(_reduce_ws(x.device)), _s()), "vdm_loss_terms")
 
 
 def ancestral_step(z, eps_hat, noise, coef, step_ptr, seed):
@@ -407,7 +466,7 @@ def sumsq(x, out):
     L = _lib.lib()
     _contig(x)
     assert x.dtype == torch.float32 and out.dtype == torch.float32
-    check(L.vdm_sumsq(_p(x), x.numel(), _p(out), _s()), "vdm_sumsq")
+    check(L.vdm_sumsq(_p(x), x.numel(), _p(out), _p(_reduce_ws(x.device)), _s()), "vdm_sumsq")
     return out
 
 

@@ -16,6 +16,9 @@ from .hip_ops import Conv
 
 # GroupNorm statistics from the producing conv's epilogue (VDM4CDM_FUSED_GN=0: separate gn_stats passes, for A/B timing)
 FUSED_GN = os.environ.get("VDM4CDM_FUSED_GN", "1") != "0"
+# GroupNorm backward reduction folded into the producing dgrad conv's epilogue (VDM4CDM_FUSED_GNB=0: separate reduce pass with
+# float atomics, for A/B timing).  Needs the forward partials (FUSED_GN) for the analytic conditioning-table gradient.
+FUSED_GNB = FUSED_GN and os.environ.get("VDM4CDM_FUSED_GNB", "1") != "0"
 
 
 class SideStream:
@@ -80,8 +83,8 @@ class _Res:
         st1 = ops.gn_stats(x1, x2, G)
         a1 = ops.gn_silu_fwd(x1, x2, G, st1, P(n + ".norm1.weight"), P(n + ".norm1.bias"))
         h = self.conv1.fwd(a1, P(n + ".conv1.bias"), table[:, i.table_off:i.table_off + i.cout], gn=FUSED_GN)
-        st2 = ops.gn_stats(h, None, G)
-        a2 = ops.gn_silu_fwd(h, None, G, st2, P(n + ".norm2.weight"), P(n + ".norm2.bias"), p, seed)
+        st2 = ops.gn_stats(h, None, G, chsum=save and FUSED_GNB)
+        a2 = ops.gn_silu_fwd(h, None, G, st2, P(n + ".norm2.weight"), P(n + ".norm2.bias"), p, seed, want_mask=save and FUSED_GNB)
         if self.skip1 is not None:
             ss.join()
             s = skip_out[0]
@@ -91,15 +94,17 @@ class _Res:
             s = x1
         out = self.conv2.fwd(a2, P(n + ".conv2.bias"), None, s, gn=FUSED_GN)     # (every block output feeds a GroupNorm)
         if save:
-            self.saved = (x1, x2, st1, a1, h, st2, a2, p, seed)
+            self.saved = (x1, x2, st1, a1, h, st2, a2, p, seed, a2.keep_mask)
         return out
 
     def bwd(self, P, GP, dout, dtable, ss):
         """dout: gradient of the block output.  Returns (dx1, dx2).  Fills parameter grads via GP(name).
         ss: SideStream for the weight-gradient kernels."""
         i, G, n = self.i, self.net.norm_groups, self.i.name
-        x1, x2, st1, a1, h, st2, a2, p, seed = self.saved
+        x1, x2, st1, a1, h, st2, a2, p, seed, mask2 = self.saved
         self.saved = None
+        fused = (FUSED_GNB and getattr(st2, "chsum", None) is not None and (p == 0.0 or mask2 is not None)
+                 and self.conv2.gn_fold_ok(i.cout, 0, h.dtype) and self.conv1.gn_fold_ok(i.c1, i.c2, h.dtype))
 
         skip_grads = []
         if self.skip1 is not None:             # input gradients of the 1x1 skip convs: independent of the main chain until norm1
@@ -116,14 +121,22 @@ class _Res:
                 if self.skip2 is not None:
                     self.skip2.wgrad(x2, dout, GP(n + ".skip2.weight"))
         ss.run(side_conv2, a2, dout, x1, x2)
-        da2 = self.conv2.dgrad(dout)
-        dh, _ = ops.gn_silu_bwd(h, None, G, st2, P(n + ".norm2.weight"), P(n + ".norm2.bias"), da2,
-                                GP(n + ".norm2.weight"), GP(n + ".norm2.bias"),
-                                colsum=dtable[:, i.table_off:i.table_off + i.cout], dropout_p=p, seed=seed, dx1=da2)
+        tcols = dtable[:, i.table_off:i.table_off + i.cout]
+        if fused:      # dgrad epilogue: dyh = da2 * keep * silu'(.) + per-tile sums; then one finalize + one apply pass (no atomics)
+            dyh2 = self.conv2.dgrad_gn(dout, h, None, G, st2, P(n + ".norm2.weight"), P(n + ".norm2.bias"), keep_mask=mask2, dropout_p=p)
+            dh, _ = ops.gn_bwd_fused(h, None, G, st2, P(n + ".norm2.weight"), dyh2, GP(n + ".norm2.weight"), GP(n + ".norm2.bias"),
+                                     colsum=tcols)
+        else:
+            da2 = self.conv2.dgrad(dout)
+            dh, _ = ops.gn_silu_bwd(h, None, G, st2, P(n + ".norm2.weight"), P(n + ".norm2.bias"), da2,
+                                    GP(n + ".norm2.weight"), GP(n + ".norm2.bias"), colsum=tcols, dropout_p=p, seed=seed, dx1=da2)
         del a2
         # conv1
         ss.run(lambda: self.conv1.wgrad(a1, dh, GP(n + ".conv1.weight")), a1, dh)
-        da1 = self.conv1.dgrad(dh)
+        if fused:
+            dyh1 = self.conv1.dgrad_gn(dh, x1, x2, G, st1, P(n + ".norm1.weight"), P(n + ".norm1.bias"))
+        else:
+            da1 = self.conv1.dgrad(dh)
         del a1, dh
         # skip path
         add1 = add2 = None
@@ -136,9 +149,11 @@ class _Res:
                         t.record_stream(torch.cuda.current_stream())
         else:
             add1 = dout
-        dx1, dx2 = ops.gn_silu_bwd(x1, x2, G, st1, P(n + ".norm1.weight"), P(n + ".norm1.bias"), da1,
-                                   GP(n + ".norm1.weight"), GP(n + ".norm1.bias"), add1=add1, add2=add2)
-        return dx1, dx2
+        if fused:
+            return ops.gn_bwd_fused(x1, x2, G, st1, P(n + ".norm1.weight"), dyh1, GP(n + ".norm1.weight"), GP(n + ".norm1.bias"),
+                                    add1=add1, add2=add2)
+        return ops.gn_silu_bwd(x1, x2, G, st1, P(n + ".norm1.weight"), P(n + ".norm1.bias"), da1,
+                               GP(n + ".norm1.weight"), GP(n + ".norm1.bias"), add1=add1, add2=add2)
 
 
 class HipUNet:
@@ -240,9 +255,13 @@ class HipUNet:
         dpad = ops.pack_input(d_eps.contiguous(), None, dtype)
         ss.run(lambda: self.conv_out.wgrad(a, dpad, GP("conv_out.weight")), a, dpad)
         GP("conv_out.bias").copy_(d_eps.sum().reshape(1))
-        da = self.conv_out.dgrad(dpad)
-        dh, _ = ops.gn_silu_bwd(h_last, None, net.norm_groups, st, P("norm_out.weight"), P("norm_out.bias"), da,
-                                GP("norm_out.weight"), GP("norm_out.bias"), dx1=da)
+        if FUSED_GNB and self.conv_out.gn_fold_ok(net.chs[0], 0, dtype):
+            dyh = self.conv_out.dgrad_gn(dpad, h_last, None, net.norm_groups, st, P("norm_out.weight"), P("norm_out.bias"))
+            dh, _ = ops.gn_bwd_fused(h_last, None, net.norm_groups, st, P("norm_out.weight"), dyh, GP("norm_out.weight"), GP("norm_out.bias"))
+        else:
+            da = self.conv_out.dgrad(dpad)
+            dh, _ = ops.gn_silu_bwd(h_last, None, net.norm_groups, st, P("norm_out.weight"), P("norm_out.bias"), da,
+                                    GP("norm_out.weight"), GP("norm_out.bias"), dx1=da)
         dskips = [None] * (L - 1)
         for i in range(L - 1):
             du, dskips[i] = self.res[f"ups.{i}.block"].bwd(P, GP, dh, dtable, ss)
