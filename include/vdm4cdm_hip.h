@@ -98,7 +98,7 @@ int vdm_conv_dgrad(const vdm_conv_desc* d, const void* dout, const void* w_packe
 /* The same input gradient for a conv whose INPUT was y = dropout(silu(groupnorm(x))) [NB blocks.py:129-132: net1 / net2 =
  * Sequential(GroupNorm, SiLU, (Dropout,) Conv)], with the first half of that GroupNorm's backward folded into the epilogue:
  * instead of dL/dy the kernel stores dyh = dL/dy * keep/(1-p) * silu'(yhat) (same shape and dtype) and reduces, per spatial tile
- * and channel, partials[n][tile][cin][2] = (sum dyh, sum dyh * xhat), tile < vdm_conv_dgrad_gn_tiles(d) - one read of x instead of
+ * and channel, partials[n][tile][cin][2] = (sum dyh, sum dyh * x), tile < vdm_conv_dgrad_gn_tiles(d) - one read of x instead of
  * a separate two-tensor reduction pass, in a fixed order (no float atomics).  vdm_gn_bwd_finalize + vdm_gn_bwd_apply finish the
  * GroupNorm backward.  Only for ksize 3, stride 1, no up-sampling (every conv behind a GroupNorm on the path). */
 typedef struct vdm_gn_fold {

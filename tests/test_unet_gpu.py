@@ -426,7 +426,8 @@ def test_c4_192_training_step_properties():
     for name in net.spec.items:
         assert net.view(name, g).abs().max().item() > 0, f"no gradient reached {name}"
     assert torch.equal(outs[0][0], outs[1][0]), "loss differs between two identical steps"
-    assert torch.equal(outs[0][1], outs[1][1]), f"gradient not bit-reproducible: max|d| {(outs[0][1] - outs[1][1]).abs().max().item()}"
+    diff = [name for name in net.spec.items if not torch.equal(net.view(name, outs[0][1]), net.view(name, outs[1][1]))]
+    assert not diff, f"gradient not bit-reproducible in {len(diff)} tensors: {diff[:12]}"
 
 
 def test_c5_sampler_128_power_spectrum():

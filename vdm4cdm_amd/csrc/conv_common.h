@@ -62,7 +62,7 @@ struct ConvArgs {
     float* gnp;          // optional GroupNorm partials of the output: [N][ntz*nty*ntx][Cout][2] = (sum, sum of squares) per tile
     // GroupNorm backward folded into a dgrad epilogue (conv_epilogue_gnb): the conv result is dL/dy of y = drop(silu(gn(x)));
     // the epilogue turns it into dyh = dL/dy * keep * silu'(yhat), stores THAT, and reduces per tile and channel
-    // (sum dyh, sum dyh*xhat) into gnp.  x = concat(gx1 [c1 ch], gx2 [c2 ch]) is the GroupNorm input.
+    // (sum dyh, sum dyh*x) into gnp.  x = concat(gx1 [c1 ch], gx2 [c2 ch]) is the GroupNorm input.
     const void* gx1;
     const void* gx2;
     const float* gstats;             // [N][G][2] raw moments of x
@@ -395,23 +395,6 @@ __device__ __forceinline__ void conv_epilogue(const f32x4 (&acc)[NV][NC], const 
 // sub-chunk (32 registers) are loaded once and reused over the NV rows.
 // ---------------------------------------------------------------------------------------------
 template <typename T, int SUB>
-__device__ __forceinline__ void ld_sub(const T* p, float (&f)[SUB]) {
-    constexpr int EPL = DT<T>::EPL;
-    if constexpr (SUB >= EPL) {
-#pragma unroll
-        for (int i = 0; i < SUB / EPL; ++i) {
-            Piece<T> pc;
-            pc.load(*reinterpret_cast<const uint4*>(p + i * EPL));
-#pragma unroll
-            for (int j = 0; j < EPL; ++j) f[i * EPL + j] = pc.f[j];
-        }
-    } else {                                              // bf16, 4 channels: half a piece
-        const uint2 u = *reinterpret_cast<const uint2*>(p);
-        f[0] = __builtin_bit_cast(float, u.x << 16); f[1] = __builtin_bit_cast(float, u.x & 0xffff0000u);
-        f[2] = __builtin_bit_cast(float, u.y << 16); f[3] = __builtin_bit_cast(float, u.y & 0xffff0000u);
-    }
-}
-template <typename T, int SUB>
 __device__ __forceinline__ void st_sub(T* p, const float (&f)[SUB]) {
     constexpr int EPL = DT<T>::EPL;
     if constexpr (SUB >= EPL) {
@@ -427,65 +410,165 @@ __device__ __forceinline__ void st_sub(T* p, const float (&f)[SUB]) {
     }
 }
 
+// Everything the folded epilogue reads from memory, as registers: the raw x pieces of the lane's NV rows, the dropout keep bytes
+// and the per-channel affine of -yhat log2(e) = x * A + B (yhat = (x - mean) rstd gamma + beta).  gnb_issue() runs BEFORE the tap loop
+// when the registers allow it (NC <= 2: the loads then retire behind the staging barrier, their latency is never exposed) or right
+// after it (NC = 4: the operand registers of the tap loop are free by then).
+// The second sum is taken against the RAW x (S2raw = sum dyh * x); vdm_gn_bwd_finalize converts the tile totals,
+// sum dyh * xhat = rstd * (S2raw - mean * S1), so the inner loop needs neither xhat nor the per-group constants.
+template <typename T, int NC, int NV>
+struct GnbRegs {
+    static constexpr int EPL = DT<T>::EPL;
+    static constexpr int CH = NC * 4;                       // channels per lane
+    static constexpr int SUB = CH >= 8 ? 8 : 4;             // channels per sub-chunk (<= one bf16 piece)
+    static constexpr int NSUB = CH / SUB;
+    static constexpr int XQ = (SUB * (int)sizeof(T) + 15) / 16;   // 16-byte words per sub-chunk load (bf16: 1, fp32 SUB=8: 2)
+    static constexpr int NBT = CH >= EPL ? CH / EPL : 1;    // keep-mask bytes (= 16-byte pieces of y) per lane and row (<= 4)
+    uint4 x[NV][NSUB][XQ];
+    uint32_t mb[NV];                                        // the NBT keep bytes of the row, byte k = piece k of the lane
+    float A[CH], B[CH];
+};
+
+template <typename T, int NC, int NV>
+struct GnbLane {                                            // where this lane's channels live
+    const T* xsrc; int xc, xoff, cbase; bool lane_ok;
+    __device__ __forceinline__ GnbLane(const ConvArgs& a, int lane, int cout0, int qstride) {
+        const int q = lane >> 4;
+        const int cbase0 = cout0 + q * qstride;
+        lane_ok = cbase0 + NC * 4 <= a.Cout;
+        cbase = lane_ok ? cbase0 : 0;                       // (idle lanes read valid memory, their results are discarded)
+        const bool first = cbase < a.gc1;
+        xsrc = reinterpret_cast<const T*>(first ? a.gx1 : a.gx2);
+        xc = first ? a.gc1 : a.gc2;
+        xoff = first ? cbase : cbase - a.gc1;
+    }
+};
+
 template <typename T, typename G, int NC, int NV>
-__device__ __forceinline__ void conv_epilogue_gnb(const f32x4 (&acc)[NV][NC], const ConvArgs& a, int n, int chunk, int oz0, int oy0,
-                                                  int ox0, int cwave, int lane, float* gn_sm, int tile, int cout0 = -1,
-                                                  int qstride = NC * 4) {
-    constexpr int EPL = DT<T>::EPL;
-    constexpr int CH = NC * 4;                             // channels per lane
-    constexpr int SUB = CH >= 8 ? 8 : 4;                   // channels per sub-chunk
-    constexpr int NSUB = CH / SUB;
-    constexpr int NB = SUB >= EPL ? SUB / EPL : 1;         // mask bytes (= 16-byte pieces) per sub-chunk
+__device__ __forceinline__ void gnb_issue_row(GnbRegs<T, NC, NV>& r, const GnbLane<T, NC, NV>& L, const ConvArgs& a, int n, int oz0,
+                                              int oy0, int ox0, int cwave, int lane, int v) {
+    using R = GnbRegs<T, NC, NV>;
+    constexpr int EPL = R::EPL, SUB = R::SUB, NSUB = R::NSUB;
+    const int PPV = a.Cout / EPL;
+    const int row = cwave * NV + v;
+    int oz = oz0 + row / G::TY, oy = oy0 + row % G::TY, ox = ox0 + (lane & 15);
+    if (oz >= a.Dz || oy >= a.Dy || ox >= a.Dx) { oz = oy = ox = 0; }
+    const size_t vox = (((size_t)n * a.Dz + oz) * a.Dy + oy) * a.Dx + ox;
+#pragma unroll
+    for (int sc = 0; sc < NSUB; ++sc) {
+        const T* px = L.xsrc + vox * L.xc + L.xoff + sc * SUB;
+        if constexpr (SUB * sizeof(T) >= 16) {
+#pragma unroll
+            for (int k = 0; k < R::XQ; ++k) r.x[v][sc][k] = reinterpret_cast<const uint4*>(px)[k];
+        } else {
+            const uint2 u = *reinterpret_cast<const uint2*>(px);
+            r.x[v][sc][0] = make_uint4(u.x, u.y, 0u, 0u);
+        }
+    }
+    uint32_t m = 0xffffffffu;
+    if (a.gmask) {
+        const unsigned char* pm = a.gmask + vox * PPV + L.cbase / EPL;
+        m = 0;
+#pragma unroll
+        for (int k = 0; k < R::NBT; ++k) m |= (uint32_t)pm[k] << (8 * k);
+    }
+    r.mb[v] = m;
+}
+
+template <typename T, int NC, int NV>
+__device__ __forceinline__ void gnb_issue_consts(GnbRegs<T, NC, NV>& r, const GnbLane<T, NC, NV>& L, const ConvArgs& a, int n) {
+    const int gs = a.Cout / a.gG;
+#pragma unroll
+    for (int j = 0; j < NC * 4; ++j) {
+        const int c = L.cbase + j;
+        const int g = c / gs;
+        const float sum = a.gstats[((size_t)n * a.gG + g) * 2], sq = a.gstats[((size_t)n * a.gG + g) * 2 + 1];
+        const float mean = sum / a.gcnt;
+        const float var = fmaxf(sq / a.gcnt - mean * mean, 0.f);
+        const float rstd = rsqrtf(var + a.geps);
+        const float A = rstd * a.ggamma[c];
+        r.A[j] = -1.44269504089f * A;                       // yl = -yhat * log2(e) = x * A' + B'  (sigmoid = 1 / (1 + 2^yl))
+        r.B[j] = -1.44269504089f * (a.gbeta[c] - mean * A);
+    }
+}
+
+// everything up front (NC <= 2, before the tap loop)
+template <typename T, typename G, int NC, int NV>
+__device__ __forceinline__ void gnb_issue(GnbRegs<T, NC, NV>& r, const ConvArgs& a, int n, int oz0, int oy0, int ox0, int cwave, int lane,
+                                          int cout0, int qstride) {
+    const GnbLane<T, NC, NV> L(a, lane, cout0, qstride);
+#pragma unroll
+    for (int v = 0; v < NV; ++v) gnb_issue_row<T, G, NC, NV>(r, L, a, n, oz0, oy0, ox0, cwave, lane, v);
+    gnb_issue_consts<T, NC, NV>(r, L, a, n);
+}
+
+template <typename T, int SUB, int XQ>
+__device__ __forceinline__ void raw_unpack(const uint4 (&q)[XQ], float (&f)[SUB]) {
+    if constexpr (sizeof(T) == 4) {
+#pragma unroll
+        for (int k = 0; k < XQ; ++k) {
+            f[4 * k] = __builtin_bit_cast(float, q[k].x); f[4 * k + 1] = __builtin_bit_cast(float, q[k].y);
+            f[4 * k + 2] = __builtin_bit_cast(float, q[k].z); f[4 * k + 3] = __builtin_bit_cast(float, q[k].w);
+        }
+    } else {
+        const uint32_t w[4] = {q[0].x, q[0].y, q[0].z, q[0].w};
+#pragma unroll
+        for (int i = 0; i < SUB / 2; ++i) {
+            f[2 * i] = __builtin_bit_cast(float, w[i] << 16);
+            f[2 * i + 1] = __builtin_bit_cast(float, w[i] & 0xffff0000u);
+        }
+    }
+}
+
+// PREFETCHED: gnb_issue() already ran (before the tap loop).  Otherwise the rows are fetched here through a rolling window of PD
+// rows (the lane's accumulators die row by row, which makes room for the x pieces still in flight).
+template <typename T, typename G, int NC, int NV, bool PREFETCHED>
+__device__ __forceinline__ void conv_epilogue_gnb(const f32x4 (&acc)[NV][NC], const ConvArgs& a, GnbRegs<T, NC, NV>& r, int n,
+                                                  int oz0, int oy0, int ox0, int cwave, int lane, float* gn_sm, int tile, int cout0,
+                                                  int qstride) {
+    using R = GnbRegs<T, NC, NV>;
+    constexpr int EPL = R::EPL, CH = R::CH, SUB = R::SUB, NSUB = R::NSUB;
+    constexpr int PD = NV < 3 ? NV : 3;                    // (4 rows in flight spill the NC = 4, 4x8x16 kernel)
     const int lx = lane & 15, q = lane >> 4;
-    if (cout0 < 0) cout0 = chunk * NC * 16;
     const int cbase = cout0 + q * qstride;
-    const int C = a.Cout, gs = C / a.gG, PPV = C / EPL;
-    float gsum[CH], gsq[CH];                               // S1, S2
+    const int C = a.Cout;
+    const GnbLane<T, NC, NV> L(a, lane, cout0, qstride);
+    if constexpr (!PREFETCHED) {
+#pragma unroll
+        for (int v = 0; v < PD; ++v) gnb_issue_row<T, G, NC, NV>(r, L, a, n, oz0, oy0, ox0, cwave, lane, v);
+        gnb_issue_consts<T, NC, NV>(r, L, a, n);
+    }
+    float gsum[CH], gsq[CH];                               // S1 = sum dyh, S2raw = sum dyh * x
 #pragma unroll
     for (int j = 0; j < CH; ++j) gsum[j] = gsq[j] = 0.f;
     const bool lane_ok = cbase + CH <= C;                  // (host: C % (NC*4) == 0 and no lane straddles c1)
-    const bool first = cbase < a.gc1;
-    const T* xsrc = reinterpret_cast<const T*>(first ? a.gx1 : a.gx2);
-    const int xc = first ? a.gc1 : a.gc2, xoff = first ? cbase : cbase - a.gc1;
     T* out = reinterpret_cast<T*>(a.out);
 #pragma unroll
-    for (int sc = 0; sc < NSUB; ++sc) {
-        float rs[SUB], mr[SUB], gam[SUB], bet[SUB];
-#pragma unroll
-        for (int j = 0; j < SUB; ++j) {
-            const int c = lane_ok ? cbase + sc * SUB + j : 0;
-            const int g = c / gs;
-            const float sum = a.gstats[((size_t)n * a.gG + g) * 2], sq = a.gstats[((size_t)n * a.gG + g) * 2 + 1];
-            const float mean = sum / a.gcnt;
-            const float var = fmaxf(sq / a.gcnt - mean * mean, 0.f);
-            const float rstd = rsqrtf(var + a.geps);
-            rs[j] = rstd; mr[j] = -mean * rstd; gam[j] = a.ggamma[c]; bet[j] = a.gbeta[c];
+    for (int v = 0; v < NV; ++v) {
+        if constexpr (!PREFETCHED) {
+            if (v + PD < NV) gnb_issue_row<T, G, NC, NV>(r, L, a, n, oz0, oy0, ox0, cwave, lane, v + PD);
         }
+        const int row = cwave * NV + v;
+        const int oz = oz0 + row / G::TY, oy = oy0 + row % G::TY, ox = ox0 + lx;
+        if (oz >= a.Dz || oy >= a.Dy || ox >= a.Dx || !lane_ok) continue;
+        const size_t vox = (((size_t)n * a.Dz + oz) * a.Dy + oy) * a.Dx + ox;
+        const uint32_t mb = r.mb[v];
 #pragma unroll
-        for (int v = 0; v < NV; ++v) {
-            const int r = cwave * NV + v;
-            const int oz = oz0 + r / G::TY, oy = oy0 + r % G::TY, ox = ox0 + lx;
-            if (oz >= a.Dz || oy >= a.Dy || ox >= a.Dx || !lane_ok) continue;
-            const size_t vox = (((size_t)n * a.Dz + oz) * a.Dy + oy) * a.Dx + ox;
-            float xv[SUB];
-            ld_sub<T, SUB>(xsrc + vox * xc + xoff + sc * SUB, xv);
-            unsigned mb[NB];
-#pragma unroll
-            for (int b = 0; b < NB; ++b) mb[b] = a.gmask ? a.gmask[vox * PPV + (cbase + sc * SUB) / EPL + b] : 0xffu;
-            float d[SUB];
+        for (int sc = 0; sc < NSUB; ++sc) {
+            float xv[SUB], d[SUB];
+            raw_unpack<T, SUB, R::XQ>(r.x[v][sc], xv);
 #pragma unroll
             for (int j = 0; j < SUB; ++j) {
                 const int jj = sc * SUB + j;               // channel inside the lane: accumulator (jj / 4, jj % 4)
-                const float xh = fmaf(xv[j], rs[j], mr[j]);
-                const float yh = fmaf(xh, gam[j], bet[j]);
-                const float sg = 1.0f / (1.0f + __expf(-yh));
-                const float ds = sg * fmaf(yh, 1.0f - sg, 1.0f);
-                const int bit = SUB >= EPL ? j % EPL : (cbase + jj) % EPL;
-                const float keep = ((mb[SUB >= EPL ? j / EPL : 0] >> bit) & 1u) ? a.ginv_keep : 0.f;
+                const float yl = fmaf(xv[j], r.A[jj], r.B[jj]);
+                const float sg = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(yl));     // v_exp_f32 + v_rcp_f32 (1 ulp each)
+                const float ds = sg * fmaf(-0.69314718056f * yl, 1.0f - sg, 1.0f);             // silu'(y) = s (1 + y (1 - s))
+                const int bit = CH >= EPL ? (jj / EPL) * 8 + jj % EPL : (cbase + jj) % EPL;
+                const float keep = ((mb >> bit) & 1u) ? a.ginv_keep : 0.f;
                 const float dd = acc[v][jj >> 2][jj & 3] * (ds * keep);
                 d[j] = dd;
                 gsum[jj] += dd;
-                gsq[jj] = fmaf(dd, xh, gsq[jj]);
+                gsq[jj] = fmaf(dd, xv[j], gsq[jj]);
             }
             st_sub<T, SUB>(out + vox * C + cbase + sc * SUB, d);
         }

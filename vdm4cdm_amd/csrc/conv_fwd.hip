@@ -41,6 +41,11 @@ __global__ void __launch_bounds__(256, (TZ * TY <= 16 && NC <= 2) ? 3 : 2) conv_
     const uint4* wbase = reinterpret_cast<const uint4*>(a.w) + (size_t)(SPLIT ? chunk >> 1 : chunk) * a.nkb * TAPS * NCW * 64 +
                          (SPLIT ? (chunk & 1) * 2 * 64 : 0) + lane;
     const T* x = reinterpret_cast<const T*>(a.x);
+    // folded GroupNorm backward: what the epilogue reads from memory is fetched up front when the registers allow it (NC <= 2):
+    // the loads retire behind the first staging barrier instead of stalling the epilogue
+    const int e_cout0 = SPLIT ? (chunk >> 1) * 64 + (chunk & 1) * 8 : chunk * NC * 16, e_qstride = SPLIT ? 16 : NC * 4;
+    GnbRegs<T, NC, GNB ? NV : 1> gr;
+    if constexpr (GNB && NC <= 2) gnb_issue<T, G, NC, NV>(gr, a, n, oz0, oy0, ox0, wave, lane, e_cout0, e_qstride);
 
     for (int kb = 0; kb < a.nkb; ++kb) {
         if (kb) __syncthreads();
@@ -62,10 +67,7 @@ __global__ void __launch_bounds__(256, (TZ * TY <= 16 && NC <= 2) ? 3 : 2) conv_
     const int tile = (tz * a.nty + ty) * a.ntx + tx;
     if constexpr (GNB) {
         static_assert(sizeof(T) == sizeof(TO), "the folded GroupNorm backward stores dyh in the activation dtype");
-        if constexpr (SPLIT)
-            conv_epilogue_gnb<T, G, NC, NV>(acc, a, n, chunk, oz0, oy0, ox0, wave, lane, gn_sm, tile, (chunk >> 1) * 64 + (chunk & 1) * 8, 16);
-        else
-            conv_epilogue_gnb<T, G, NC, NV>(acc, a, n, chunk, oz0, oy0, ox0, wave, lane, gn_sm, tile);
+        conv_epilogue_gnb<T, G, NC, NV, (NC <= 2)>(acc, a, gr, n, oz0, oy0, ox0, wave, lane, gn_sm, tile, e_cout0, e_qstride);
     } else if constexpr (SPLIT)
         conv_epilogue<T, TO, G, NC, NV>(acc, a, n, chunk, oz0, oy0, ox0, wave, lane, gn_sm, tile, (chunk >> 1) * 64 + (chunk & 1) * 8, 16);
     else
@@ -81,7 +83,7 @@ __global__ void __launch_bounds__(256, (TZ * TY <= 16 && NC <= 2) ? 3 : 2) conv_
 // These convs are bound by writing / reading the 32-channel tensor (HBM), not by MFMA.
 // ---------------------------------------------------------------------------------------------
 template <typename TO, int NC, bool GNB = false>
-__global__ void __launch_bounds__(256, GNB ? 3 : 4) conv_kpack_kernel(const ConvArgs a) {
+__global__ void __launch_bounds__(256, GNB ? 2 : 4) conv_kpack_kernel(const ConvArgs a) {
     using T = bf16_t;
     using G = Geo<3, 1, 4, 8>;
     constexpr int NV = G::NV, NG = (G::TAPS + 3) / 4;
@@ -101,6 +103,8 @@ __global__ void __launch_bounds__(256, GNB ? 3 : 4) conv_kpack_kernel(const Conv
     const int chunk = b / a.N;
     const int oz0 = tz * G::TZ, oy0 = ty * G::TY, ox0 = tx * 16;
 
+    GnbRegs<T, NC, GNB ? NV : 1> gr;
+    if constexpr (GNB) gnb_issue<T, G, NC, NV>(gr, a, n, oz0, oy0, ox0, wave, lane, chunk * NC * 16, NC * 4);
     // stage the halo: one lane per voxel
     const T* x = reinterpret_cast<const T*>(a.x);
     for (int c = wave; c < NCH; c += 4) {
@@ -159,8 +163,8 @@ __global__ void __launch_bounds__(256, GNB ? 3 : 4) conv_kpack_kernel(const Conv
     }
     constexpr int IMG = NCH * 1024;
     if constexpr (GNB)
-        conv_epilogue_gnb<T, G, NC, NV>(acc, a, n, chunk, oz0, oy0, ox0, wave, lane, reinterpret_cast<float*>(lds + IMG),
-                                        (tz * a.nty + ty) * a.ntx + tx);
+        conv_epilogue_gnb<T, G, NC, NV, true>(acc, a, gr, n, oz0, oy0, ox0, wave, lane, reinterpret_cast<float*>(lds + IMG),
+                                              (tz * a.nty + ty) * a.ntx + tx, chunk * NC * 16, NC * 4);
     else
         conv_epilogue<T, TO, G, NC, NV>(acc, a, n, chunk, oz0, oy0, ox0, wave, lane, reinterpret_cast<float*>(lds + IMG),
                                         (tz * a.nty + ty) * a.ntx + tx);

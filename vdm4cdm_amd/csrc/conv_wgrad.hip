@@ -228,16 +228,21 @@ __global__ void __launch_bounds__(256, 2) conv_wgrad_kernel(const WgradArgs w) {
     constexpr int CL = NT * 16;                               // channels per 64-B block
     if (TAPS > 1 && w.bslabs != nullptr && kb == 0) {          // workgroup-uniform condition
         float* shb = reinterpret_cast<float*>(lds);           // all tiles are done: the LDS image is free
+        constexpr int EPLc = DT<T>::EPL;
         __syncthreads();
-        if (tid < CL) shb[tid] = 0.f;
-        __syncthreads();
-        {
-            const int piece = (lane & 3) ^ (((lane >> 2) >> 1) & 3);
 #pragma unroll
-            for (int j = 0; j < DT<T>::EPL; ++j) atomicAdd(&shb[piece * DT<T>::EPL + j], bsum[j]);
-        }
+        for (int j = 0; j < EPLc; ++j) shb[tid * EPLc + j] = bsum[j];
         __syncthreads();
-        if (tid < CL) w.bslabs[((size_t)cb * (CLS ? 8 : 1) * w.P + cls * w.P + pidx) * CL + tid] = shb[tid];
+        if (tid < CL) {                                       // fixed-order fold (no LDS atomics: the bias gradient is bit-reproducible)
+            const int piece = tid / EPLc, j = tid % EPLc;
+            float tot = 0.f;
+            for (int wv = 0; wv < 4; ++wv)
+                for (int vx = 0; vx < 16; ++vx) {             // the lane of voxel vx that holds this channel piece
+                    const int ln = vx * 4 + (piece ^ ((vx >> 1) & 3));
+                    tot += shb[(wv * 64 + ln) * EPLc + j];
+                }
+            w.bslabs[((size_t)cb * (CLS ? 8 : 1) * w.P + cls * w.P + pidx) * CL + tid] = tot;
+        }
     }
     // ---- write this wave's partial tiles: slab[tap][co_local][ci_local] ------------------------
     constexpr int SLAB = TAPS * CL * CL;

@@ -445,7 +445,7 @@ __global__ void __launch_bounds__(256) gn_silu_bwd_apply_kernel(const GnArgs a) 
 
 // ---------------------------------------------------------------------------------------------
 // GroupNorm backward, fused form: the dgrad conv that produced dL/dy already stored dyh = dL/dy * keep * silu'(yhat) and
-// reduced per (tile, channel) partial sums of (dyh, dyh * xhat) in its epilogue (conv_common.h, conv_epilogue_gnb).
+// reduced per (tile, channel) partial sums of (dyh, dyh * x) in its epilogue (conv_common.h, conv_epilogue_gnb).
 // finalize: one block per (sample, group) sums the tiles per channel in a fixed order ->
 //   chan[n][c] = {T1, T2};  red[n][g] = {sum_c gamma_c T1_c, sum_c gamma_c T2_c};
 //   colsum[n][c] = sum_v dx = rstd * (gamma_c T1_c - V m1 - m2 * rstd * (chsum[n][c] - V mean))   (analytic, optional)
@@ -480,9 +480,14 @@ __global__ void __launch_bounds__(256) gn_bwd_finalize_kernel(const float* __res
     __shared__ float gr[2];
     sm[0][t] = s0; sm[1][t] = s1;
     __syncthreads();
+    const float cnt = (float)V * gs;
+    const float gsum = stats[((size_t)n * G + g) * 2], gsq = stats[((size_t)n * G + g) * 2 + 1];
+    const float mean = gsum / cnt;
+    const float rstd = rsqrtf(fmaxf(gsq / cnt - mean * mean, 0.f) + eps);
     float T1 = 0.f, T2 = 0.f, gam = 0.f;
     if (t < gs) {
         for (int j = 0; j < per; ++j) { T1 += sm[0][t + j * gs]; T2 += sm[1][t + j * gs]; }
+        T2 = rstd * (T2 - mean * T1);                       // the epilogues sum dyh * x (raw): -> sum dyh * xhat
         gam = gamma[g * gs + t];
         chan[((size_t)n * C + g * gs + t) * 2] = T1;
         chan[((size_t)n * C + g * gs + t) * 2 + 1] = T2;
@@ -498,10 +503,6 @@ __global__ void __launch_bounds__(256) gn_bwd_finalize_kernel(const float* __res
     if (colsum == nullptr) return;                          // (uniform)
     __syncthreads();
     if (t < gs) {
-        const float cnt = (float)V * gs;
-        const float sum = stats[((size_t)n * G + g) * 2], sq = stats[((size_t)n * G + g) * 2 + 1];
-        const float mean = sum / cnt;
-        const float rstd = rsqrtf(fmaxf(sq / cnt - mean * mean, 0.f) + eps);
         const float m1 = gr[0] / cnt, m2 = gr[1] / cnt;
         const float xhsum = rstd * (chsum[(size_t)n * C + g * gs + t] - (float)V * mean);
         colsum[(size_t)n * colsum_stride + g * gs + t] = rstd * (gam * T1 - (float)V * m1 - m2 * xhsum);

@@ -242,7 +242,7 @@ class Conv:
     def dgrad_gn(self, dout, x1, x2, groups, stats, gamma, beta, keep_mask=None, dropout_p=0.0, out=None):
         """Input gradient of a conv whose input was drop(silu(gn(concat(x1, x2)))), with the GroupNorm backward reduction folded
         into the epilogue.  Returns dyh = dL/dy * keep/(1-p) * silu'(yhat) with `.gnb_partials` ([N, tiles, cin, 2]: per-tile
-        sums of dyh and dyh * xhat) for gn_bwd_finalize."""
+        sums of dyh and dyh * x) for gn_bwd_finalize."""
         L = _lib.lib()
         _contig(dout, x1, x2, stats, gamma, beta, keep_mask)
         n, od, oh, ow, c = dout.shape

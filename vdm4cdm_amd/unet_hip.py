@@ -19,6 +19,7 @@ FUSED_GN = os.environ.get("VDM4CDM_FUSED_GN", "1") != "0"
 # GroupNorm backward reduction folded into the producing dgrad conv's epilogue (VDM4CDM_FUSED_GNB=0: separate reduce pass with
 # float atomics, for A/B timing).  Needs the forward partials (FUSED_GN) for the analytic conditioning-table gradient.
 FUSED_GNB = FUSED_GN and os.environ.get("VDM4CDM_FUSED_GNB", "1") != "0"
+GNB_MIN_K = int(os.environ.get("VDM4CDM_GNB_MIN_K", "0"))      # fold only into dgrad convs with at least this many reduction channels
 
 
 class SideStream:
@@ -103,7 +104,7 @@ class _Res:
         i, G, n = self.i, self.net.norm_groups, self.i.name
         x1, x2, st1, a1, h, st2, a2, p, seed, mask2 = self.saved
         self.saved = None
-        fused = (FUSED_GNB and getattr(st2, "chsum", None) is not None and (p == 0.0 or mask2 is not None)
+        fused = (FUSED_GNB and getattr(st2, "chsum", None) is not None and (p == 0.0 or mask2 is not None) and i.cout >= GNB_MIN_K
                  and self.conv2.gn_fold_ok(i.cout, 0, h.dtype) and self.conv1.gn_fold_ok(i.c1, i.c2, h.dtype))
 
         skip_grads = []
