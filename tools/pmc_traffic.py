@@ -18,19 +18,27 @@ import sys
 
 
 def simplify(name):
-    m = re.search(r"conv_fwd_kernel<vdm::(\w+), (?:vdm::)?(\w+), (\d), (\d), (\d), (\d), \d, \d(?:, (true|false))?>", name)
+    """rocprofv3 kernel name -> the key bench.py / hip_ops.py use for the same launch family."""
+    # conv_fwd_kernel<T, TO, KS, STRIDE, UPS, NC, TZ, TY, SPLIT, GNB>
+    m = re.search(r"conv_fwd_kernel<vdm::(\w+), (?:vdm::)?(\w+), (\d), (\d), (\d), (\d), \d+, \d+(?:, (true|false))?(?:, (true|false))?>", name)
     if m:
-        return f"conv_fwd_kernel<{m.group(1)},k{m.group(3)},s{m.group(4)},NC{m.group(6)}{',split' if m.group(7) == 'true' else ''}>"
-    if "conv_kpack_kernel" in name:
-        return "conv_kpack_kernel"
+        return (f"conv_fwd_kernel<{m.group(1)},k{m.group(3)},s{m.group(4)},NC{m.group(6)}{',split' if m.group(7) == 'true' else ''}>"
+                + ("+gnb" if m.group(8) == "true" else ""))
+    m = re.search(r"conv_kpack_kernel<vdm::(\w+), (\d)(?:, (true|false))?>", name)
+    if m:
+        return "conv_kpack_kernel" + ("+gnb" if m.group(3) == "true" else "")
     m = re.search(r"conv_cls_kernel<vdm::(\w+), (\d), (\d)>", name)
     if m:
         return f"conv_cls_kernel<{m.group(1)},NC{m.group(2)},{'B' if m.group(3) == '1' else 'F'}>"
-    m = re.search(r"conv_wgrad_kernel<vdm::(\w+), (\d), (\d), (\d), \d, \d>", name)
+    # conv_wgrad_kernel<T, KS, STRIDE, UPS, TZ, TY, NTA, NTB>
+    m = re.search(r"conv_wgrad_kernel<vdm::(\w+), (\d), (\d), (\d), \d+, \d+(?:, (\d), (\d))?>", name)
     if m:
-        return f"conv_wgrad_kernel<{m.group(1)},k{m.group(2)},s{m.group(3)},u{m.group(4)}>"
-    m = re.search(r"vdm::(\w+)", name)
-    return m.group(1) if m else name[:60]
+        tiles = f",ta{m.group(5)}tb{m.group(6)}" if m.group(5) and (m.group(5), m.group(6)) != ("2", "2") else ""
+        return f"conv_wgrad_kernel<{m.group(1)},k{m.group(2)},s{m.group(3)},u{m.group(4)}{tiles}>"
+    m = re.search(r"(?:vdm::)?(\w+_kernel)\b", name)          # gn_*_kernel<T>, pack_many_kernel<T>, wgrad_reduce_kernel, ...
+    if m:
+        return m.group(1)
+    return name[:60]
 
 
 def load(d, counter):

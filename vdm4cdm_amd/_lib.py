@@ -9,7 +9,8 @@ import os
 import subprocess
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libvdm4cdm_hip.so")
+# VDM4CDM_LIB: load another build of the same library (tools/conv_timeline.py uses the stamped diagnostic build)
+LIB_PATH = os.environ.get("VDM4CDM_LIB") or os.path.join(_HERE, "libvdm4cdm_hip.so")
 CSRC = os.path.join(_HERE, "csrc")
 
 VDM_F32, VDM_BF16 = 0, 1

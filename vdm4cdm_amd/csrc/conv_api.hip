@@ -389,3 +389,12 @@ extern "C" int vdm_conv_wgrad(const vdm_conv_desc* d, const void* x, const void*
     return launch_wgrad_any(w, dw, dbias, accumulate, d->cout, d->cin, d->ksize, d->stride, d->upsample, workspace_bytes, d->dtype, s);
 }
 
+
+#ifdef VDM_TIMELINE
+namespace vdm { unsigned long long* g_timeline_stamps = nullptr; }
+// diagnostic build only (make timeline): every later conv_fwd_kernel launch writes [workgroup][wave][8] stamps to `buf`
+extern "C" int vdm_debug_set_stamps(void* buf) {
+    vdm::g_timeline_stamps = (unsigned long long*)buf;
+    return VDM_OK;
+}
+#endif

@@ -24,31 +24,7 @@ namespace vdm {
 template <typename T, typename G>
 __device__ __forceinline__ void stage_halo_dma_sub(char* lds, const T* __restrict__ x, const ClsArgs& ca, int n, int oz0, int oy0,
                                                    int ox0, int kb, int ss, int soz, int soy, int sox, int wave, int lane) {
-    constexpr int EPL = DT<T>::EPL, KB = DT<T>::KB;
-    constexpr int NCHUNK = (G::HVOX + 15) / 16;
-    const ConvArgs& a = ca.c;
-    const int iz0 = oz0 - G::PAD, iy0 = oy0 - G::PAD, ix0 = ox0 - G::PAD;
-    const int k = lane >> 2, j = lane & 3;
-    for (int c = wave; c < NCHUNK; c += 4) {
-        const int hv = c * 16 + k;
-        const int hx = hv % G::HX;
-        const int t = hv / G::HX;
-        const int hy = t % G::HY;
-        const int hz = t / G::HY;
-        const int pc = j ^ ((hx >> 1) & 3);
-        int iz = iz0 + hz, iy = iy0 + hy, ix = ix0 + hx;
-        const int ci = kb * KB + pc * EPL;
-        bool ok = ci < a.Cin && hv < G::HVOX;
-        if (a.circular) {
-            iz = wrap(iz, a.Iz); iy = wrap(iy, a.Iy); ix = wrap(ix, a.Ix);
-        } else {
-            ok = ok && (unsigned)iz < (unsigned)a.Iz && (unsigned)iy < (unsigned)a.Iy && (unsigned)ix < (unsigned)a.Ix;
-        }
-        const size_t off = ((((size_t)n * ca.sDz + (ss * iz + soz)) * ca.sDy + (ss * iy + soy)) * ca.sDx + (ss * ix + sox)) * a.CinStride + ci;
-        const void* src = ok ? static_cast<const void*>(x + off) : static_cast<const void*>(g_zero_page);
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-                                         (__attribute__((address_space(3))) void*)(lds + c * 1024), 16, 0, 0);
-    }
+    stage_halo_dma_gen<T, G, 0>(lds, x, ca.c, n, oz0, oy0, ox0, kb, wave, lane, ss, soz, soy, sox, ca.sDz, ca.sDy, ca.sDx);
 }
 
 // tap-list MFMA loop (runtime offsets): weights one entry ahead, activations one entry ahead.

@@ -71,7 +71,22 @@ struct ConvArgs {
     const unsigned char* gmask;      // optional dropout keep bits, one byte per 16-byte piece of y: [N][V][C/EPL]
     int gc1, gc2, gG;
     float geps, gcnt, ginv_keep;     // gcnt = voxels * channels per group
+#ifdef VDM_TIMELINE
+    unsigned long long* stamps;      // diagnostic build only (tools/conv_timeline.py): [workgroup][wave][8] s_memrealtime stamps + HW ids
+#endif
 };
+
+#ifdef VDM_TIMELINE
+#define VDM_STAMP(k)                                                                       \
+    do {                                                                                   \
+        __builtin_amdgcn_sched_barrier(0);                                                 \
+        tl_t[k] = __builtin_amdgcn_s_memrealtime();                                        \
+        __builtin_amdgcn_sched_barrier(0);                                                 \
+    } while (0)
+extern unsigned long long* g_timeline_stamps;            // set by vdm_debug_set_stamps (conv_api.hip)
+#else
+#define VDM_STAMP(k) do { } while (0)
+#endif
 
 __device__ __forceinline__ int wrap(int i, int n) {
     i %= n;
@@ -88,34 +103,63 @@ static __device__ uint4 g_zero_page[16];
 // (dz, dy, row) shifts stay compile-time ds_read offsets.
 // Filled by LDS-DMA (global_load_lds_dwordx4): one wave-instruction = 16 voxels x 64 B = 1 KiB of LDS written
 // linearly; the four lanes of a voxel fetch its (permuted) pieces, i.e. whole 64-B segments of the NDHWC row.
+//
+// The address arithmetic of the ~17 chunks a wave stages is on the critical path of every tile (tools/conv_timeline.py: a
+// workgroup used to spend 5 of its 17 us between kernel entry and the last DMA issue): the halo coordinate (hz, hy, hx) of a
+// lane advances by a CONSTANT from chunk to chunk (64 halo voxels), so it is carried incrementally (adds + two conditional
+// carries, no division), and the voxel offset inside the sample is 32-bit with 24-bit multiplies (full-rate v_mul_u32_u24;
+// 32-bit integer multiplies are quarter rate).  The host checks that a sample's elements fit 32 bits.
+// ss / so*: logical voxel i maps to source voxel ss * i + so (class sub-grid of the per-parity-class kernels when ss == 2);
+// sD*: source tensor dims.
 template <typename T, typename G, int UPS>
-__device__ __forceinline__ void stage_halo_dma(char* lds, const T* __restrict__ x, const ConvArgs& a, int n,
-                                               int oz0, int oy0, int ox0, int kb, int wave, int lane, int nwaves = 4) {
+__device__ __forceinline__ void stage_halo_dma_gen(char* lds, const T* __restrict__ x, const ConvArgs& a, int n, int oz0, int oy0,
+                                                   int ox0, int kb, int wave, int lane, int ss, int soz, int soy, int sox, int sDz,
+                                                   int sDy, int sDx) {
     constexpr int EPL = DT<T>::EPL, KB = DT<T>::KB;
     constexpr int NCHUNK = (G::HVOX + 15) / 16;
+    constexpr int STEP = 64;                                // halo voxels between two chunks of one wave (4 waves x 16)
+    constexpr int DX = STEP % G::HX, DY = (STEP / G::HX) % G::HY, DZ = STEP / (G::HX * G::HY);
     const int iz0 = oz0 * G::STRIDE - G::PAD, iy0 = oy0 * G::STRIDE - G::PAD, ix0 = ox0 * G::STRIDE - G::PAD;
     const int k = lane >> 2, j = lane & 3;
-    for (int c = wave; c < NCHUNK; c += nwaves) {
-        const int hv = c * 16 + k;
-        const int hx = hv % G::HX;
-        const int t = hv / G::HX;
-        const int hy = t % G::HY;
-        const int hz = t / G::HY;
+    const int hv0 = wave * 16 + k;                          // first chunk of this wave (constant divisors: once per call)
+    int hx = hv0 % G::HX, hy = (hv0 / G::HX) % G::HY, hz = hv0 / (G::HX * G::HY);
+    const T* xn = x + (size_t)n * ((size_t)sDz * sDy * sDx * a.CinStride);
+    const bool fastwrap = a.Iz >= G::HZ && a.Iy >= G::HY && a.Ix >= G::HX;      // one conditional add / subtract wraps
+    for (int c = wave; c < NCHUNK; c += 4) {
         const int pc = j ^ ((hx >> 1) & 3);
-        int iz = iz0 + hz, iy = iy0 + hy, ix = ix0 + hx;
         const int ci = kb * KB + pc * EPL;
-        bool ok = ci < a.Cin && hv < G::HVOX;
+        int iz = iz0 + hz, iy = iy0 + hy, ix = ix0 + hx;
+        bool ok = ci < a.Cin && hz < G::HZ;                 // (hz < HZ <=> the chunk's tail is inside the halo)
         if (a.circular) {
-            iz = wrap(iz, a.Iz); iy = wrap(iy, a.Iy); ix = wrap(ix, a.Ix);
+            if (fastwrap) {
+                iz += iz < 0 ? a.Iz : 0; iz -= iz >= a.Iz ? a.Iz : 0;
+                iy += iy < 0 ? a.Iy : 0; iy -= iy >= a.Iy ? a.Iy : 0;
+                ix += ix < 0 ? a.Ix : 0; ix -= ix >= a.Ix ? a.Ix : 0;
+            } else {
+                iz = wrap(iz, a.Iz); iy = wrap(iy, a.Iy); ix = wrap(ix, a.Ix);
+            }
         } else {
             ok = ok && (unsigned)iz < (unsigned)a.Iz && (unsigned)iy < (unsigned)a.Iy && (unsigned)ix < (unsigned)a.Ix;
         }
         if (UPS) { iz >>= 1; iy >>= 1; ix >>= 1; }
-        const size_t off = ((((size_t)n * a.Sz + iz) * a.Sy + iy) * a.Sx + ix) * a.CinStride + ci;
-        const void* src = ok ? static_cast<const void*>(x + off) : static_cast<const void*>(g_zero_page);
+        const unsigned sz = (unsigned)(ss * iz + soz) & 0xffffffu, sy = (unsigned)(ss * iy + soy) & 0xffffffu,
+                       sx = (unsigned)(ss * ix + sox) & 0xffffffu;      // (masked: garbage of !ok lanes stays a legal u24 operand)
+        const unsigned row = __umul24(sz, (unsigned)sDy) + sy;
+        const unsigned vox = __umul24(row, (unsigned)sDx) + sx;
+        const unsigned eoff = vox * (unsigned)a.CinStride + (unsigned)ci;
+        const void* src = ok ? static_cast<const void*>(xn + eoff) : static_cast<const void*>(g_zero_page);
         __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
                                          (__attribute__((address_space(3))) void*)(lds + c * 1024), 16, 0, 0);
+        hx += DX; hy += DY; hz += DZ;
+        if (hx >= G::HX) { hx -= G::HX; hy += 1; }
+        if (hy >= G::HY) { hy -= G::HY; hz += 1; }
     }
+}
+
+template <typename T, typename G, int UPS>
+__device__ __forceinline__ void stage_halo_dma(char* lds, const T* __restrict__ x, const ConvArgs& a, int n,
+                                               int oz0, int oy0, int ox0, int kb, int wave, int lane) {
+    stage_halo_dma_gen<T, G, UPS>(lds, x, a, n, oz0, oy0, ox0, kb, wave, lane, 1, 0, 0, 0, a.Sz, a.Sy, a.Sx);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -288,19 +332,29 @@ __device__ __forceinline__ void gn_partials_reduce(float (&gs)[NC * 4], float (&
     }
 }
 
-// epilogue: + bias + per-sample conditioning bias + residual, cast, 16-byte NDHWC stores
-template <typename T, typename TO, typename G, int NC, int NV>
-__device__ __forceinline__ void conv_epilogue(const f32x4 (&acc)[NV][NC], const ConvArgs& a, int n, int chunk, int oz0, int oy0,
-                                              int ox0, int cwave, int lane, float* gn_sm = nullptr, int tile = 0, int cout0 = -1,
-                                              int qstride = NC * 4) {
-    constexpr int EPL = DT<T>::EPL;
-    float gs[NC * 4], gq[NC * 4];
-#pragma unroll
-    for (int j = 0; j < NC * 4; ++j) gs[j] = gq[j] = 0.f;
-    const int lx = lane & 15, q = lane >> 4;
-    if (cout0 < 0) cout0 = chunk * NC * 16;             // (half-chunk kernels pass their own origin and lane-group stride)
-    const int cbase = cout0 + q * qstride;              // first of this lane's NC*4 consecutive couts
-    float badd[NC * 4];
+// Output voxels of a lane: row v of wave `cwave` is (oz, oyw + v, ox); its linear voxel index inside the sample is
+// vox0 + v * Dx (a wave's NV rows share one z-slab: TY % NV == 0), all in 32 bits (no 64-bit multiply chains per row).
+template <typename G, int NV>
+struct RowMap {
+    unsigned vox0;
+    int oyw;
+    bool zx_ok;
+    __device__ __forceinline__ RowMap(const ConvArgs& a, int oz0, int oy0, int ox0, int cwave, int lane) {
+        static_assert(G::TY % NV == 0, "a wave's rows must stay inside one z-slab");
+        const int r0 = cwave * NV;
+        const int oz = oz0 + r0 / G::TY, ox = ox0 + (lane & 15);
+        oyw = oy0 + r0 % G::TY;
+        zx_ok = oz < a.Dz && ox < a.Dx;
+        vox0 = __umul24(__umul24((unsigned)oz, (unsigned)a.Dy) + (unsigned)oyw, (unsigned)a.Dx) + (unsigned)ox;
+    }
+    __device__ __forceinline__ bool ok(const ConvArgs& a, int v) const { return zx_ok && oyw + v < a.Dy; }
+    __device__ __forceinline__ unsigned vox(const ConvArgs& a, int v) const { return vox0 + (unsigned)(v * a.Dx); }
+};
+
+// per-lane additive terms of the epilogue (bias + per-sample conditioning bias): loaded BEFORE the tap loop by the kernels, so
+// that their latency is not exposed at the start of the epilogue
+template <int NC>
+__device__ __forceinline__ void load_badd(float (&badd)[NC * 4], const ConvArgs& a, int n, int cbase) {
 #pragma unroll
     for (int j = 0; j < NC * 4; ++j) {
         float bv = 0.f;
@@ -310,15 +364,27 @@ __device__ __forceinline__ void conv_epilogue(const f32x4 (&acc)[NV][NC], const 
         }
         badd[j] = bv;
     }
+}
+
+// epilogue: + bias + per-sample conditioning bias + residual, cast, 16-byte NDHWC stores
+template <typename T, typename TO, typename G, int NC, int NV>
+__device__ __forceinline__ void conv_epilogue(const f32x4 (&acc)[NV][NC], const ConvArgs& a, const float (&badd)[NC * 4], int n, int oz0,
+                                              int oy0, int ox0, int cwave, int lane, float* gn_sm, int tile, int cout0, int qstride) {
+    constexpr int EPL = DT<T>::EPL;
+    float gs[NC * 4], gq[NC * 4];
+#pragma unroll
+    for (int j = 0; j < NC * 4; ++j) gs[j] = gq[j] = 0.f;
+    const int q = lane >> 4;
+    const int cbase = cout0 + q * qstride;              // first of this lane's NC*4 consecutive couts
     const bool vec_ok = (a.Cout % (NC * 4) == 0) && (cbase + NC * 4 <= a.Cout);
-    TO* out = reinterpret_cast<TO*>(a.out);
-    const T* res = reinterpret_cast<const T*>(a.res);
+    const size_t sample = (size_t)n * ((size_t)a.Dz * a.Dy * a.Dx * a.Cout);
+    TO* out = reinterpret_cast<TO*>(a.out) + sample;
+    const T* res = a.res ? reinterpret_cast<const T*>(a.res) + sample : nullptr;
+    const RowMap<G, NV> rm(a, oz0, oy0, ox0, cwave, lane);
 #pragma unroll
     for (int v = 0; v < NV; ++v) {
-        const int r = cwave * NV + v;
-        const int oz = oz0 + r / G::TY, oy = oy0 + r % G::TY, ox = ox0 + lx;
-        if (oz >= a.Dz || oy >= a.Dy || ox >= a.Dx) continue;
-        const size_t vo = ((((size_t)n * a.Dz + oz) * a.Dy + oy) * a.Dx + ox) * a.Cout + cbase;
+        if (!rm.ok(a, v)) continue;
+        const unsigned vo = rm.vox(a, v) * (unsigned)a.Cout + (unsigned)cbase;
         float val[NC * 4];
 #pragma unroll
         for (int c = 0; c < NC; ++c)
@@ -432,28 +498,25 @@ struct GnbRegs {
 template <typename T, int NC, int NV>
 struct GnbLane {                                            // where this lane's channels live
     const T* xsrc; int xc, xoff, cbase; bool lane_ok;
-    __device__ __forceinline__ GnbLane(const ConvArgs& a, int lane, int cout0, int qstride) {
+    __device__ __forceinline__ GnbLane(const ConvArgs& a, int n, int lane, int cout0, int qstride) {
         const int q = lane >> 4;
         const int cbase0 = cout0 + q * qstride;
         lane_ok = cbase0 + NC * 4 <= a.Cout;
         cbase = lane_ok ? cbase0 : 0;                       // (idle lanes read valid memory, their results are discarded)
         const bool first = cbase < a.gc1;
-        xsrc = reinterpret_cast<const T*>(first ? a.gx1 : a.gx2);
         xc = first ? a.gc1 : a.gc2;
         xoff = first ? cbase : cbase - a.gc1;
+        xsrc = reinterpret_cast<const T*>(first ? a.gx1 : a.gx2) + (size_t)n * ((size_t)a.Dz * a.Dy * a.Dx * xc);     // this sample
     }
 };
 
 template <typename T, typename G, int NC, int NV>
-__device__ __forceinline__ void gnb_issue_row(GnbRegs<T, NC, NV>& r, const GnbLane<T, NC, NV>& L, const ConvArgs& a, int n, int oz0,
-                                              int oy0, int ox0, int cwave, int lane, int v) {
+__device__ __forceinline__ void gnb_issue_row(GnbRegs<T, NC, NV>& r, const GnbLane<T, NC, NV>& L, const RowMap<G, NV>& rm, const ConvArgs& a,
+                                              int n, int v) {
     using R = GnbRegs<T, NC, NV>;
     constexpr int EPL = R::EPL, SUB = R::SUB, NSUB = R::NSUB;
     const int PPV = a.Cout / EPL;
-    const int row = cwave * NV + v;
-    int oz = oz0 + row / G::TY, oy = oy0 + row % G::TY, ox = ox0 + (lane & 15);
-    if (oz >= a.Dz || oy >= a.Dy || ox >= a.Dx) { oz = oy = ox = 0; }
-    const size_t vox = (((size_t)n * a.Dz + oz) * a.Dy + oy) * a.Dx + ox;
+    const unsigned vox = rm.ok(a, v) ? rm.vox(a, v) : 0u;   // (rows outside the tensor read voxel 0: valid memory, discarded)
 #pragma unroll
     for (int sc = 0; sc < NSUB; ++sc) {
         const T* px = L.xsrc + vox * L.xc + L.xoff + sc * SUB;
@@ -467,7 +530,7 @@ __device__ __forceinline__ void gnb_issue_row(GnbRegs<T, NC, NV>& r, const GnbLa
     }
     uint32_t m = 0xffffffffu;
     if (a.gmask) {
-        const unsigned char* pm = a.gmask + vox * PPV + L.cbase / EPL;
+        const unsigned char* pm = a.gmask + (size_t)n * ((size_t)a.Dz * a.Dy * a.Dx * PPV) + vox * (unsigned)PPV + L.cbase / EPL;
         m = 0;
 #pragma unroll
         for (int k = 0; k < R::NBT; ++k) m |= (uint32_t)pm[k] << (8 * k);
@@ -496,9 +559,10 @@ __device__ __forceinline__ void gnb_issue_consts(GnbRegs<T, NC, NV>& r, const Gn
 template <typename T, typename G, int NC, int NV>
 __device__ __forceinline__ void gnb_issue(GnbRegs<T, NC, NV>& r, const ConvArgs& a, int n, int oz0, int oy0, int ox0, int cwave, int lane,
                                           int cout0, int qstride) {
-    const GnbLane<T, NC, NV> L(a, lane, cout0, qstride);
+    const GnbLane<T, NC, NV> L(a, n, lane, cout0, qstride);
+    const RowMap<G, NV> rm(a, oz0, oy0, ox0, cwave, lane);
 #pragma unroll
-    for (int v = 0; v < NV; ++v) gnb_issue_row<T, G, NC, NV>(r, L, a, n, oz0, oy0, ox0, cwave, lane, v);
+    for (int v = 0; v < NV; ++v) gnb_issue_row<T, G, NC, NV>(r, L, rm, a, n, v);
     gnb_issue_consts<T, NC, NV>(r, L, a, n);
 }
 
@@ -529,29 +593,28 @@ __device__ __forceinline__ void conv_epilogue_gnb(const f32x4 (&acc)[NV][NC], co
     using R = GnbRegs<T, NC, NV>;
     constexpr int EPL = R::EPL, CH = R::CH, SUB = R::SUB, NSUB = R::NSUB;
     constexpr int PD = NV < 3 ? NV : 3;                    // (4 rows in flight spill the NC = 4, 4x8x16 kernel)
-    const int lx = lane & 15, q = lane >> 4;
+    const int q = lane >> 4;
     const int cbase = cout0 + q * qstride;
     const int C = a.Cout;
-    const GnbLane<T, NC, NV> L(a, lane, cout0, qstride);
+    const GnbLane<T, NC, NV> L(a, n, lane, cout0, qstride);
+    const RowMap<G, NV> rm(a, oz0, oy0, ox0, cwave, lane);
     if constexpr (!PREFETCHED) {
 #pragma unroll
-        for (int v = 0; v < PD; ++v) gnb_issue_row<T, G, NC, NV>(r, L, a, n, oz0, oy0, ox0, cwave, lane, v);
+        for (int v = 0; v < PD; ++v) gnb_issue_row<T, G, NC, NV>(r, L, rm, a, n, v);
         gnb_issue_consts<T, NC, NV>(r, L, a, n);
     }
     float gsum[CH], gsq[CH];                               // S1 = sum dyh, S2raw = sum dyh * x
 #pragma unroll
     for (int j = 0; j < CH; ++j) gsum[j] = gsq[j] = 0.f;
     const bool lane_ok = cbase + CH <= C;                  // (host: C % (NC*4) == 0 and no lane straddles c1)
-    T* out = reinterpret_cast<T*>(a.out);
+    T* out = reinterpret_cast<T*>(a.out) + (size_t)n * ((size_t)a.Dz * a.Dy * a.Dx * C);
 #pragma unroll
     for (int v = 0; v < NV; ++v) {
         if constexpr (!PREFETCHED) {
-            if (v + PD < NV) gnb_issue_row<T, G, NC, NV>(r, L, a, n, oz0, oy0, ox0, cwave, lane, v + PD);
+            if (v + PD < NV) gnb_issue_row<T, G, NC, NV>(r, L, rm, a, n, v + PD);
         }
-        const int row = cwave * NV + v;
-        const int oz = oz0 + row / G::TY, oy = oy0 + row % G::TY, ox = ox0 + lx;
-        if (oz >= a.Dz || oy >= a.Dy || ox >= a.Dx || !lane_ok) continue;
-        const size_t vox = (((size_t)n * a.Dz + oz) * a.Dy + oy) * a.Dx + ox;
+        if (!rm.ok(a, v) || !lane_ok) continue;
+        const unsigned vox = rm.vox(a, v);
         const uint32_t mb = r.mb[v];
 #pragma unroll
         for (int sc = 0; sc < NSUB; ++sc) {
@@ -570,7 +633,7 @@ __device__ __forceinline__ void conv_epilogue_gnb(const f32x4 (&acc)[NV][NC], co
                 gsum[jj] += dd;
                 gsq[jj] = fmaf(dd, xv[j], gsq[jj]);
             }
-            st_sub<T, SUB>(out + vox * C + cbase + sc * SUB, d);
+            st_sub<T, SUB>(out + (vox * (unsigned)C + (unsigned)(cbase + sc * SUB)), d);
         }
     }
     gn_partials_reduce<NC>(gsum, gsq, gn_sm, a.gnp + ((size_t)n * (a.ntz * a.nty * a.ntx) + tile) * a.Cout * 2, cout0, a.Cout, cwave,
@@ -626,6 +689,12 @@ static int validate(const vdm_conv_desc* d) {
     VDM_REQUIRE(!(d->upsample && ((d->od | d->oh | d->ow) & 1)), "conv: upsample needs even output dims");
     VDM_REQUIRE(d->dtype == VDM_F32 || d->dtype == VDM_BF16, "conv: bad dtype %d", d->dtype);
     VDM_REQUIRE(d->pad_mode == VDM_PAD_ZEROS || d->pad_mode == VDM_PAD_CIRCULAR, "conv: bad pad_mode %d", d->pad_mode);
+    // the kernels index voxels and elements INSIDE one sample with 32-bit arithmetic (24-bit multiplies on the coordinates)
+    const long long fine = (long long)d->od * d->oh * d->ow * (d->stride == 2 ? 8 : 1);
+    const long long cmax = cpad(d->cin > d->cout ? d->cin : d->cout, d->dtype);
+    VDM_REQUIRE(fine * cmax < (1LL << 32), "conv: %lld voxels x %lld channels per sample exceed the 32-bit in-sample index", fine, cmax);
+    VDM_REQUIRE((long long)(d->od > d->oh ? (d->od > d->ow ? d->od : d->ow) : (d->oh > d->ow ? d->oh : d->ow)) * d->stride < (1 << 12),
+                "conv: spatial extent too large");
     return VDM_OK;
 }
 

@@ -21,6 +21,10 @@ __global__ void __launch_bounds__(256, (TZ * TY <= 16 && NC <= 2) ? 3 : 2) conv_
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+#ifdef VDM_TIMELINE
+    unsigned long long tl_t[7] = {0, 0, 0, 0, 0, 0, 0};
+    VDM_STAMP(0);
+#endif
 
     int b = xcd_remap(blockIdx.x, gridDim.x);
     const int tx = b % a.ntx; b /= a.ntx;
@@ -41,37 +45,51 @@ __global__ void __launch_bounds__(256, (TZ * TY <= 16 && NC <= 2) ? 3 : 2) conv_
     const uint4* wbase = reinterpret_cast<const uint4*>(a.w) + (size_t)(SPLIT ? chunk >> 1 : chunk) * a.nkb * TAPS * NCW * 64 +
                          (SPLIT ? (chunk & 1) * 2 * 64 : 0) + lane;
     const T* x = reinterpret_cast<const T*>(a.x);
+    VDM_STAMP(5);
     // folded GroupNorm backward: what the epilogue reads from memory is fetched up front when the registers allow it (NC <= 2):
     // the loads retire behind the first staging barrier instead of stalling the epilogue
     const int e_cout0 = SPLIT ? (chunk >> 1) * 64 + (chunk & 1) * 8 : chunk * NC * 16, e_qstride = SPLIT ? 16 : NC * 4;
     GnbRegs<T, NC, GNB ? NV : 1> gr;
     if constexpr (GNB && NC <= 2) gnb_issue<T, G, NC, NV>(gr, a, n, oz0, oy0, ox0, wave, lane, e_cout0, e_qstride);
+    float badd[NC * 4];                                      // bias + conditioning bias of the lane's channels (latency hidden behind the taps)
+    if constexpr (!GNB) load_badd<NC>(badd, a, n, e_cout0 + (lane >> 4) * e_qstride);
 
     for (int kb = 0; kb < a.nkb; ++kb) {
         if (kb) __syncthreads();
         stage_halo_dma<T, G, UPS>(lds, x, a, n, oz0, oy0, ox0, kb, wave, lane);
+        if (kb == 0) VDM_STAMP(6);
         const uint4* wk = wbase + (size_t)kb * TAPS * NCW * 64;
         if constexpr (sizeof(T) == 2) {
             constexpr int WPD = WPipe<NC>::WPD;
             uint4 wf[WPD + 1][NC];
             taps_prefetch_weights<TAPS, NC, WPD, NCW>(wf, wk);
+            if (kb == 0) VDM_STAMP(1);
             __syncthreads();
+            if (kb == 0) VDM_STAMP(2);
             taps_pipelined<T, G, NC, NV, WPD, NCW>(acc, lds, wk, wf, lanex);
         } else {
             __syncthreads();
             taps_rolled<T, G, NC, NV>(acc, lds, wk, lanex);
         }
     }
+    VDM_STAMP(3);
     constexpr int IMG = ((G::HVOX + 15) / 16) * 1024;     // the GN scratch sits behind the operand image
     float* gn_sm = reinterpret_cast<float*>(lds + IMG);
     const int tile = (tz * a.nty + ty) * a.ntx + tx;
     if constexpr (GNB) {
         static_assert(sizeof(T) == sizeof(TO), "the folded GroupNorm backward stores dyh in the activation dtype");
         conv_epilogue_gnb<T, G, NC, NV, (NC <= 2)>(acc, a, gr, n, oz0, oy0, ox0, wave, lane, gn_sm, tile, e_cout0, e_qstride);
-    } else if constexpr (SPLIT)
-        conv_epilogue<T, TO, G, NC, NV>(acc, a, n, chunk, oz0, oy0, ox0, wave, lane, gn_sm, tile, (chunk >> 1) * 64 + (chunk & 1) * 8, 16);
-    else
-        conv_epilogue<T, TO, G, NC, NV>(acc, a, n, chunk, oz0, oy0, ox0, wave, lane, gn_sm, tile);
+    } else
+        conv_epilogue<T, TO, G, NC, NV>(acc, a, badd, n, oz0, oy0, ox0, wave, lane, gn_sm, tile, e_cout0, e_qstride);
+#ifdef VDM_TIMELINE
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // (the stores of the epilogue have left the wave's queue)
+    VDM_STAMP(4);
+    if (a.stamps && lane == 0) {
+        unsigned long long* o = a.stamps + ((size_t)blockIdx.x * 4 + wave) * 8;
+        for (int k = 0; k < 7; ++k) o[k] = tl_t[k];
+        o[7] = ((unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 20) << 32) | (unsigned)__builtin_amdgcn_s_getreg((31 << 11) | 4);
+    }
+#endif
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -105,25 +123,39 @@ __global__ void __launch_bounds__(256, GNB ? 2 : 4) conv_kpack_kernel(const Conv
 
     GnbRegs<T, NC, GNB ? NV : 1> gr;
     if constexpr (GNB) gnb_issue<T, G, NC, NV>(gr, a, n, oz0, oy0, ox0, wave, lane, chunk * NC * 16, NC * 4);
+    float badd[NC * 4];
+    if constexpr (!GNB) load_badd<NC>(badd, a, n, chunk * NC * 16 + (lane >> 4) * NC * 4);
     // stage the halo: one lane per voxel
     const T* x = reinterpret_cast<const T*>(a.x);
-    for (int c = wave; c < NCH; c += 4) {
-        const int hv = c * 64 + lane;
-        const int hx = hv % G::HX;
-        const int t = hv / G::HX;
-        const int hy = t % G::HY;
-        const int hz = t / G::HY;
-        int iz = oz0 - 1 + hz, iy = oy0 - 1 + hy, ix = ox0 - 1 + hx;
-        bool ok = hv < G::HVOX;
-        if (a.circular) {
-            iz = wrap(iz, a.Iz); iy = wrap(iy, a.Iy); ix = wrap(ix, a.Ix);
-        } else {
-            ok = ok && (unsigned)iz < (unsigned)a.Iz && (unsigned)iy < (unsigned)a.Iy && (unsigned)ix < (unsigned)a.Ix;
+    {   // (same incremental / 32-bit address arithmetic as stage_halo_dma_gen; 256 halo voxels between two chunks of a wave)
+        constexpr int DXs = 256 % G::HX, DYs = (256 / G::HX) % G::HY, DZs = 256 / (G::HX * G::HY);
+        const int hv0 = wave * 64 + lane;
+        int hx = hv0 % G::HX, hy = (hv0 / G::HX) % G::HY, hz = hv0 / (G::HX * G::HY);
+        const T* xn = x + (size_t)n * ((size_t)a.Sz * a.Sy * a.Sx * a.CinStride);
+        const bool fastwrap = a.Iz >= G::HZ && a.Iy >= G::HY && a.Ix >= G::HX;
+        for (int c = wave; c < NCH; c += 4) {
+            int iz = oz0 - 1 + hz, iy = oy0 - 1 + hy, ix = ox0 - 1 + hx;
+            bool ok = hz < G::HZ;
+            if (a.circular) {
+                if (fastwrap) {
+                    iz += iz < 0 ? a.Iz : 0; iz -= iz >= a.Iz ? a.Iz : 0;
+                    iy += iy < 0 ? a.Iy : 0; iy -= iy >= a.Iy ? a.Iy : 0;
+                    ix += ix < 0 ? a.Ix : 0; ix -= ix >= a.Ix ? a.Ix : 0;
+                } else {
+                    iz = wrap(iz, a.Iz); iy = wrap(iy, a.Iy); ix = wrap(ix, a.Ix);
+                }
+            } else {
+                ok = ok && (unsigned)iz < (unsigned)a.Iz && (unsigned)iy < (unsigned)a.Iy && (unsigned)ix < (unsigned)a.Ix;
+            }
+            const unsigned row = __umul24((unsigned)iz & 0xffffffu, (unsigned)a.Sy) + ((unsigned)iy & 0xffffffu);
+            const unsigned vox = __umul24(row, (unsigned)a.Sx) + ((unsigned)ix & 0xffffffu);
+            const void* src = ok ? static_cast<const void*>(xn + vox * (unsigned)a.CinStride) : static_cast<const void*>(g_zero_page);
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                             (__attribute__((address_space(3))) void*)(lds + c * 1024), 16, 0, 0);
+            hx += DXs; hy += DYs; hz += DZs;
+            if (hx >= G::HX) { hx -= G::HX; hy += 1; }
+            if (hy >= G::HY) { hy -= G::HY; hz += 1; }
         }
-        const size_t off = ((((size_t)n * a.Sz + iz) * a.Sy + iy) * a.Sx + ix) * a.CinStride;
-        const void* src = ok ? static_cast<const void*>(x + off) : static_cast<const void*>(g_zero_page);
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-                                         (__attribute__((address_space(3))) void*)(lds + c * 1024), 16, 0, 0);
     }
     // weights of this cout chunk: NG x NC fragments
     uint4 wf[NG][NC];
@@ -166,8 +198,8 @@ __global__ void __launch_bounds__(256, GNB ? 2 : 4) conv_kpack_kernel(const Conv
         conv_epilogue_gnb<T, G, NC, NV, true>(acc, a, gr, n, oz0, oy0, ox0, wave, lane, reinterpret_cast<float*>(lds + IMG),
                                               (tz * a.nty + ty) * a.ntx + tx, chunk * NC * 16, NC * 4);
     else
-        conv_epilogue<T, TO, G, NC, NV>(acc, a, n, chunk, oz0, oy0, ox0, wave, lane, reinterpret_cast<float*>(lds + IMG),
-                                        (tz * a.nty + ty) * a.ntx + tx);
+        conv_epilogue<T, TO, G, NC, NV>(acc, a, badd, n, oz0, oy0, ox0, wave, lane, reinterpret_cast<float*>(lds + IMG),
+                                        (tz * a.nty + ty) * a.ntx + tx, chunk * NC * 16, NC * 4);
 }
 
 template <typename T, typename TO, int KS, int STRIDE, int UPS, int NC, int TZ, int TY, bool SPLIT = false, bool GNB = false>
@@ -185,6 +217,9 @@ static int launch_fwd_cfg(const ConvArgs& a0, hipStream_t s) {
     }
     const long long nwg = (long long)a.N * a.ntz * a.nty * a.ntx * a.nchunks;
     if (nwg > 0x7fffffffLL) { set_error("conv: grid too large"); return VDM_ERR_ARG; }
+#ifdef VDM_TIMELINE
+    a.stamps = g_timeline_stamps;
+#endif
     hipLaunchKernelGGL(kern, dim3((unsigned)nwg), dim3(256), lds, s, a);
     VDM_LAUNCH_CHECK("conv_fwd_kernel");
     return VDM_OK;
