@@ -63,40 +63,51 @@ def make_batch(D, B, rank, device):
             "conditioning_values": [b["conditioning_values"][0].to(device)]}
 
 
-def cpu_baseline(chs, budget_D=96):
-    """Oracle fwd+bwd on the host cores on a bounded sample (same network, one 96^3 crop, fp32)."""
+def _oracle_fwd_bwd_seconds(chs, D, B, iters):
+    """Oracle (torch CPU fp32) forward + backward of the UNet on a (B,1,D,D,D) batch: 1 warm-up + `iters` timed, list of seconds."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     from helpers import oracle_cfg, oracle_params
     from oracle import unet_oracle
     from vdm4cdm_amd.networks import CUNet
-    cores = min(os.cpu_count() or 1, 64)          # oneDNN does not scale a 48^3 conv past a few dozen threads
-    torch.set_num_threads(cores)
-    net = CUNet(shape=(1, budget_D, budget_D, budget_D), chs=chs, s_conditioning_channels=1, v_conditioning_dims=[6],
-                norm_groups=8, backend="torch")
+    net = CUNet(shape=(1, D, D, D), chs=chs, s_conditioning_channels=1, v_conditioning_dims=[6], norm_groups=8, backend="torch")
     net.reset_parameters(generator=torch.Generator().manual_seed(42), zero_init_std=0.02)
     P = {k: v.clone().requires_grad_(True) for k, v in oracle_params(net).items()}
     g = torch.Generator().manual_seed(7)
-    x = torch.randn(1, 1, budget_D, budget_D, budget_D, generator=g)
-    s = torch.randn(1, 1, budget_D, budget_D, budget_D, generator=g)
-    t = torch.rand(1, generator=g)
-    v = [torch.rand(1, 6, generator=g)]
+    x = torch.randn(B, 1, D, D, D, generator=g)
+    s = torch.randn(B, 1, D, D, D, generator=g)
+    t = torch.rand(B, generator=g)
+    v = [torch.rand(B, 6, generator=g)]
     times = []
-    for it in range(2):                                          # 1 warm-up + 1 timed (bounded: ~10-30 s total)
+    for it in range(1 + iters):
         t0 = time.time()
         y = unet_oracle.cunet_forward(P, oracle_cfg(net), x, t, s, v)
         (y * x).sum().backward()
         times.append(time.time() - t0)
-    vox = budget_D ** 3
-    return {"value": vox / times[-1], "unit": "voxels/s", "cores": cores, "kind": "port",
-            "sample": f"oracle (torch CPU fp32) fwd+bwd of the same UNet on one {budget_D}^3 cube, batch 1, {cores} threads, "
-                      f"{times[-1]:.1f} s (warm-up {times[0]:.1f} s)"}
+        for p in P.values():
+            p.grad = None
+    return times[1:], times[0]
+
+
+def cpu_baseline(chs):
+    """the oracle (this repo's fp32 torch-CPU restatement of the path; kind "port") on the host cores -
+    C2 (64^3, batch 2) and 128^3 batch 1, UNet fwd+bwd, 1 warm-up + 3 timed iterations each, median.  `value` is the 128^3 number
+    (the metric's cube size); the C2 number rides along."""
+    cores = min(os.cpu_count() or 1, 64)          # oneDNN does not scale these convs past a few dozen threads
+    torch.set_num_threads(cores)
+    t64, w64 = _oracle_fwd_bwd_seconds(chs, 64, 2, 3)
+    t128, w128 = _oracle_fwd_bwd_seconds(chs, 128, 1, 3)
+    med = lambda ts: sorted(ts)[len(ts) // 2]
+    return {"value": 128 ** 3 / med(t128), "unit": "voxels/s", "cores": cores, "kind": "port",
+            "c2_64cube_batch2_voxels_per_s": 2 * 64 ** 3 / med(t64),
+            "sample": f"oracle (torch CPU fp32, {cores} threads) UNet fwd+bwd, 1 warm-up + 3 timed, median: 128^3 batch 1 "
+                      f"{med(t128):.2f} s (warm-up {w128:.1f} s); C2 64^3 batch 2 {med(t64):.2f} s (warm-up {w64:.1f} s)"}
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=100)
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--config", default="c3", choices=sorted(CONFIGS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-events", action="store_true", help="skip per-launch HIP events (pure wall-clock run)")
@@ -104,9 +115,9 @@ def main():
                     help="HIP events around EVERY kernel launch (full per-kernel table; ~600 event pairs per step cost ~6 %% of the step)."
                          " Default: only the 3^3 conv fwd/dgrad launches, the candidates for the dominant kernel (~50 per step)")
     ap.add_argument("--per-step", action="store_true", help="diagnostic: synchronise after every timed step and print its duration to stderr")
-    ap.add_argument("--sample-steps", type=int, default=0,
+    ap.add_argument("--sample-steps", type=int, default=1000,
                     help="after the training steps, rank 0 also times an n-step reverse-diffusion sample of one cube (second half of the "
-                         "BASELINE metric; reported under \"sample\", never part of \"value\"); e.g. --sample-steps 1000")
+                         "BASELINE metric: 1000-step sample wall-clock; reported under \"sample\", never part of \"value\"); 0 = skip")
     args = ap.parse_args()
 
     import torch.distributed as dist
@@ -179,7 +190,7 @@ def main():
     if rank == 0:
         scale = 1.0 if chs == [32, 64, 128, 256] else None
         out = {
-            "metric": "3D voxels/sec UNet fwd+bwd @128^3 (VDM training step)", "value": value, "unit": "voxels/s",
+            "metric": f"3D voxels/sec UNet fwd+bwd @{D}^3 (VDM training step)", "value": value, "unit": "voxels/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": precision, "data": "synthetic",
             "config": {"workload": f"{args.config}: {D}^3 conditional VDM (trainVDM3D128_c_c thick_lowbatch), chs {chs}, "
@@ -196,14 +207,19 @@ def main():
             if dom_key:
                 d = conv[dom_key]
                 ach = d["flops"] / (d["ms"] * 1e-3)
-                traffic = None                        # HBM bytes per launch from separate rocprofv3 --pmc passes (tools/pmc_traffic.py)
-                tpath = os.path.join(ROOT, "profiles", "r01_pmc_bench_traffic.json")
+                # HBM bytes per launch: NOT measured in this run - a static profile from separate rocprofv3 --pmc passes of this same
+                # command (tools/round_profile.sh -> tools/pmc_traffic.py, FETCH_SIZE doubled per the gfx950 correction)
+                traffic, traffic_src = None, None
+                tpath = os.path.join(ROOT, "profiles", "r02_pmc_bench_traffic.json")
                 if args.config == "c3" and os.path.exists(tpath):
                     t = json.load(open(tpath))["kernels"].get(dom_key)
                     traffic = t["hbm_bytes_per_launch"] if t else None
+                    traffic_src = "static profile profiles/r02_pmc_bench_traffic.json (separate --pmc FETCH_SIZE / WRITE_SIZE passes)"
                 roof = {"bound": "mfma", "kernel": dom_key, "achieved": ach / 1e12, "peak": MFMA_PEAK[precision] / 1e12,
-                        "unit": "TFLOP/s", "frac": ach / MFMA_PEAK[precision], "traffic": traffic,
+                        "unit": "TFLOP/s", "frac": ach / MFMA_PEAK[precision], "traffic": traffic, "traffic_source": traffic_src,
                         "algorithmic_flop_per_launch": d["flops"] / d["launches"],
+                        "executed_flop_per_launch": d["exec_flops"] / d["launches"],
+                        "algorithmic_bytes_per_launch": d["bytes"] / d["launches"],
                         "launches": d["launches"], "avg_launch_ms": d["ms"] / d["launches"],
                         "share_of_step_time": d["ms"] / (total_ms * (1.0 if args.all_kernel_events else len(range(0, args.steps, 5)) / args.steps)),
                         "events": "all launches, every timed step" if args.all_kernel_events
@@ -211,13 +227,17 @@ def main():
             ev_steps = args.steps if args.all_kernel_events else len(range(0, args.steps, 5))
             out["kernels"] = {k: {"launches": v["launches"], "ms_per_step": v["ms"] / ev_steps,
                                   "TFLOP/s": (v["flops"] / (v["ms"] * 1e-3) / 1e12) if v["flops"] else None,
+                                  "executed_TFLOP/s": (v["exec_flops"] / (v["ms"] * 1e-3) / 1e12) if v["exec_flops"] else None,
                                   "GB/s": (v["bytes"] / (v["ms"] * 1e-3) / 1e9) if v["bytes"] else None}
                               for k, v in sorted(agg.items(), key=lambda kv: -kv[1]["ms"])}
         if scale is not None:
             alg_bytes = 3.0 * BYTES_PER_VOXEL_FWD[precision] * B * D ** 3          # per GPU per step (fwd+bwd)
             alg_flops = 3.0 * FLOP_PER_VOXEL_FWD * B * D ** 3
             roof["step_hbm_frac"] = alg_bytes / (ms_per_step * 1e-3) / HBM_PEAK
-            roof["step_mfma_frac"] = alg_flops / (ms_per_step * 1e-3) / MFMA_PEAK[precision]
+            # algorithmic = 27 taps everywhere; the per-parity-class kernels execute 8 merged taps (up-conv fwd / dgrad /
+            # wgrad) or 1/8 of the dilated formulation (stride-2 dgrad): this fraction is work rate, not MFMA utilisation
+            roof["step_algorithmic_flop_frac_of_mfma_peak"] = alg_flops / (ms_per_step * 1e-3) / MFMA_PEAK[precision]
+            roof["step_mfma_frac"] = roof["step_algorithmic_flop_frac_of_mfma_peak"]
             roof["step_algorithmic_GB"] = alg_bytes / 1e9
             roof["step_algorithmic_TFLOP"] = alg_flops / 1e12
         out["roofline"] = roof
@@ -236,7 +256,10 @@ def main():
             except Exception as e:                          # never lose the training line over the secondary measurement
                 out["sample"] = {"error": repr(e)}
         if not args.no_cpu_baseline and world == 1:
-            out["cpu_baseline"] = cpu_baseline(chs)
+            try:
+                out["cpu_baseline"] = cpu_baseline(chs)
+            except Exception as e:                          # never lose the GPU line over the host-side baseline
+                out["cpu_baseline"] = {"error": repr(e)}
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()

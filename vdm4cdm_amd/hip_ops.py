@@ -27,20 +27,21 @@ class KernelProfiler:
         e.record()
         return e
 
-    def end(self, start, key, flops=0.0, nbytes=0.0):
+    def end(self, start, key, flops=0.0, nbytes=0.0, exec_flops=None):
         e = torch.cuda.Event(enable_timing=True)
         e.record()
-        self.records.append((key, start, e, flops, nbytes))
+        self.records.append((key, start, e, flops, nbytes, flops if exec_flops is None else exec_flops))
 
     def summary(self):
         torch.cuda.synchronize()
         agg = {}
-        for key, s, e, fl, nb in self.records:
-            a = agg.setdefault(key, {"launches": 0, "ms": 0.0, "flops": 0.0, "bytes": 0.0})
+        for key, s, e, fl, nb, xf in self.records:
+            a = agg.setdefault(key, {"launches": 0, "ms": 0.0, "flops": 0.0, "bytes": 0.0, "exec_flops": 0.0})
             a["launches"] += 1
             a["ms"] += s.elapsed_time(e)
             a["flops"] += fl
             a["bytes"] += nb
+            a["exec_flops"] += xf
         return agg
 
 
@@ -53,9 +54,11 @@ def _pb(tag="other"):
     return PROFILER.begin()
 
 
-def _pe(ev, key, flops=0.0, nbytes=0.0):
+def _pe(ev, key, flops=0.0, nbytes=0.0, exec_flops=None):
+    """flops: algorithmic (27 taps on the conv's own grid); exec_flops: what the kernel issues to the matrix cores (the
+    per-parity-class kernels run 8 merged taps / 1-8 taps per class instead of 27)."""
     if ev is not None:
-        PROFILER.end(ev, key, flops, nbytes)
+        PROFILER.end(ev, key, flops, nbytes, exec_flops)
 
 
 def _nc_for(cout, dtype=None):
@@ -193,9 +196,10 @@ class Conv:
                 key = f"conv_fwd_kernel<{_tname(x.dtype)},k3,s1,NC2,split>"
             else:
                 key = f"conv_fwd_kernel<{_tname(x.dtype)},k{self.ksize},s{self.stride},NC{_nc_for(self.cout, x.dtype)}>"
-            _pe(ev, key,
-                2.0 * nvox * self.ksize ** 3 * self.cin * self.cout,
-                x.numel() * es + out.numel() * out.element_size() + (residual.numel() * es if residual is not None else 0))
+            alg = 2.0 * nvox * self.ksize ** 3 * self.cin * self.cout
+            _pe(ev, key, alg,
+                x.numel() * es + out.numel() * out.element_size() + (residual.numel() * es if residual is not None else 0),
+                alg * (8.0 / 27.0) if (self.ksize == 3 and self.upsample) else None)          # 8 merged taps per parity class
         return out
 
     def dgrad(self, dout, residual=None, out=None):
@@ -227,9 +231,13 @@ class Conv:
                 key = f"conv_fwd_kernel<{_tname(dout.dtype)},k3,s1,NC2,split>"
             else:
                 key = f"conv_fwd_kernel<{_tname(dout.dtype)},k{self.ksize},s1,NC{_nc_for(self.cin, dout.dtype)}>"
-            _pe(ev, key,
-                2.0 * nvox * self.ksize ** 3 * self.cin * self.cout,
-                dout.numel() * es + out.numel() * es + (residual.numel() * es if residual is not None else 0))
+            alg = 2.0 * nvox * self.ksize ** 3 * self.cin * self.cout
+            xf = None
+            if self.ksize == 3 and self.upsample:
+                xf = alg * (8.0 / 27.0)                       # 8 classes x 8 merged taps on the coarse grid (= 64/216 of 27 fine taps)
+            elif self.ksize == 3 and self.stride == 2:
+                xf = alg                                      # 27 taps in total over the 8 classes of the fine grid: nothing skipped
+            _pe(ev, key, alg, dout.numel() * es + out.numel() * es + (residual.numel() * es if residual is not None else 0), xf)
         return out
 
     def gn_fold_ok(self, c1, c2, dtype):
@@ -285,8 +293,9 @@ class Conv:
         check(L.vdm_conv_wgrad(d, _p(x), _p(dout), _p(dw), _p(dbias), 1 if accumulate else 0, _p(ws), ws.numel(), _s()), "vdm_conv_wgrad")
         if ev is not None:
             es = x.element_size()
+            alg = 2.0 * n * od * oh * ow * self.ksize ** 3 * self.cin * self.cout
             _pe(ev, f"conv_wgrad_kernel<{_tname(x.dtype)},k{self.ksize},s{self.stride},u{self.upsample}>+reduce",
-                2.0 * n * od * oh * ow * self.ksize ** 3 * self.cin * self.cout, x.numel() * es + dout.numel() * es)
+                alg, x.numel() * es + dout.numel() * es, alg * (8.0 / 27.0) if (self.ksize == 3 and self.upsample) else None)
         return dw
 
 
