@@ -178,6 +178,30 @@ int vdm_gn_bwd_apply(const void* x1, int c1, const void* x2, int c2, int n, int6
 /* out[n][v][cpad] <- channels {a[n][v], b[n][v] (b may be NULL)} zero-padded to cpad; a,b fp32. */
 int vdm_pack_input(const float* a, const float* b, int64_t nvox, int cpad, int dtype, void* out, void* stream);
 
+/* ---- K6: conditioning embeddings -> additive injection table of all ResNetBlocks [R5; D4/D7] -------------------
+ * Replaces the ATen chain behind score_model(zt, t=(gamma_t-gamma_min)/(gamma_max-gamma_min), v_conditionings=[...])
+ * [NB vdm_model.py:320-324, networks.py:259-265]: per conditioning  c = GELU(Linear2(GELU(Linear1(in))))  with
+ * in = sinusoidal embedding of t (sinusoid != 0: `input` is t[rows]) or the raw vector (input[rows][in_dim]), and
+ * table[row][w] = sum_k c_k[row] . wproj_k[w]   over the concatenated output channels w of all blocks.
+ * `mlps` is a HOST array of n <= 4 descriptors holding DEVICE pointers.  saved: vdm_cond_saved_floats() floats kept for the
+ * backward (may be NULL for inference).  bwd writes dw1/db1/dw2/db2/dwproj of every descriptor (plain stores) and, if dbias is
+ * given, dbias[w] = sum_rows dtable[row][w] (the conv1 bias gradients); scratch: >= 2 * rows * sum_k dim_k floats.
+ * step: table[b] = table_t[*step_ptr] + table_v[b] (either may be NULL) - the per-step row gather of the captured sampler graph. */
+typedef struct vdm_cond_mlp {
+    const float* input;
+    int32_t in_dim, dim, sinusoid, reserved;
+    const float* w1; const float* b1; /* [dim][in_dim], [dim] */
+    const float* w2; const float* b2; /* [dim][dim], [dim] */
+    const float* wproj;               /* [width][dim] */
+    float* dw1; float* db1; float* dw2; float* db2; float* dwproj; /* backward outputs (NULL in forward) */
+} vdm_cond_mlp;
+size_t vdm_cond_saved_floats(const vdm_cond_mlp* mlps, int n, int rows);
+int vdm_cond_table_fwd(const vdm_cond_mlp* mlps, int n, int rows, int width, float* table, float* saved, void* stream);
+int vdm_cond_table_bwd(const vdm_cond_mlp* mlps, int n, int rows, int width, const float* dtable, int64_t dtable_stride,
+                       const float* saved, float* scratch, float* dbias, void* stream);
+int vdm_cond_table_step(const float* table_t, const float* table_v, const int32_t* step_ptr, int rows, int width, float* out,
+                        void* stream);
+
 /* ---- K7/K8: VDM forward diffusion + ELBO pieces [R7; D9/D10] -----------------------------------
  * z_t = alpha[n] x + sigma[n] eps  (fp32, contiguous per sample of `per` elements). */
 int vdm_diffuse(const float* x, const float* eps, const float* alpha, const float* sigma, int n, int64_t per,

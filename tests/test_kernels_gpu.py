@@ -475,6 +475,67 @@ def test_gn_bwd_folded_into_dgrad(case, dtype):
     assert torch.equal(r1, dx1) and torch.equal(dgam, dgam2) and torch.equal(dbet, dbet2) and torch.equal(cs, cs2)
 
 
+# ------------------------------------------------------------------------------------------ K6: conditioning table
+@pytest.mark.parametrize("cfg", [dict(t=True, vd=(6,), chs=(32, 64, 128, 256), B=2), dict(t=True, vd=(), chs=(16, 32), B=3),
+                                 dict(t=False, vd=(6, 3), chs=(16, 32, 64), B=1), dict(t=True, vd=(6, 3), chs=(16, 32), B=4)],
+                         ids=["c3", "t_only", "v_only_two", "t_and_two_v"])
+def test_cond_table_kernel(cfg):
+    """K6 (sinusoid -> 2 x (Linear + GELU) -> projections of all blocks, one launch) against the oracle's
+    sinusoidal_embedding / _mlp2 / per-block Linear on the CPU (fp32, 1e-5 relative), and its backward (2 launches) against
+    torch.autograd through the same oracle ops, for every conditioning parameter and the conv1 biases."""
+    import sys
+    import os
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from oracle import unet_oracle
+    from helpers import oracle_params, randomize
+    from vdm4cdm_amd.networks import CUNet
+    ops = _ops()
+    B = cfg["B"]
+    net = CUNet(shape=(1, 16, 16, 16), chs=list(cfg["chs"]), s_conditioning_channels=0, v_conditioning_dims=list(cfg["vd"]),
+                t_conditioning=cfg["t"], norm_groups=8, backend="hip", precision="fp32")
+    randomize(net, 5)
+    g = torch.Generator().manual_seed(1)
+    t = torch.rand(B, generator=g)
+    vs = [torch.randn(B, d, generator=g) for d in cfg["vd"]]
+    # oracle: conds -> per-block projections, concatenated in block order
+    P = {k: v.clone().requires_grad_(True) for k, v in oracle_params(net).items()}
+    conds = []
+    if cfg["t"]:
+        conds.append(unet_oracle._mlp2(P, "t_embed", unet_oracle.sinusoidal_embedding(t)))
+    for k, v in enumerate(vs):
+        conds.append(unet_oracle._mlp2(P, f"v_embeds.{k}", v))
+    ref = torch.cat([sum(F.linear(c, P[f"{b.name}.cond.{k}.weight"]) for k, c in enumerate(conds)) for b in net.blocks], dim=1)
+    flat = net.flat.detach().to(DEV)
+    specs = net.cond_specs(t.to(DEV), [v.to(DEV) for v in vs], flat)
+    ct = ops.CondTable(specs, B, net.table_width)
+    table = ct.forward(save=True)
+    assert table.shape == ref.shape
+    assert (table.cpu() - ref.detach()).abs().max().item() <= 1e-5 * ref.abs().max().item() + 1e-6
+    # backward
+    dtab = torch.randn(ref.shape, generator=g)
+    ref.backward(dtab)
+    gflat = torch.full_like(flat, float("nan"))
+    grads = [{k: sp[k] for k in ("w1", "b1", "w2", "b2", "wproj")} for sp in net.cond_specs(None, [None] * len(vs), gflat)]
+    dpad = torch.zeros(B, net.table_width + 7, device=DEV)          # row stride != width
+    dpad[:, :net.table_width] = dtab.to(DEV)
+    ct.backward(dpad[:, :net.table_width], grads, dbias=net.conv1_bias_all(gflat))
+    got = oracle_params(net, flat=gflat)
+    names = [n for n in P if ("embed" in n or ".cond." in n)]
+    assert names
+    for n in names:
+        r = P[n].grad
+        err = (got[n] - r).abs().max().item()
+        assert err <= 2e-5 * max(r.abs().max().item(), 1e-3) + 1e-6, f"{n}: {err}"
+    assert torch.allclose(net.conv1_bias_all(gflat).cpu(), dtab.sum(0), rtol=1e-5, atol=1e-5)
+    # the step gather of the sampler
+    if cfg["t"]:
+        tt = ops.CondTable(net.cond_specs(torch.linspace(0, 1, 5).to(DEV), None, flat, which="t"), 5, net.table_width).forward(save=False)
+        step = torch.tensor([3], dtype=torch.int32, device=DEV)
+        out = torch.empty(B, net.table_width, device=DEV)
+        ops.cond_table_step(tt, table, step, B, net.table_width, out)
+        assert torch.equal(out, tt[3][None] + table)
+
+
 # ------------------------------------------------------------------------------------------ small ops
 @pytest.mark.parametrize("dtype", DTYPES, ids=["f32", "bf16"])
 def test_small_ops(dtype):

@@ -44,6 +44,13 @@ class GnFold(C.Structure):
                 ("keep_mask", C.c_void_p), ("partials", C.c_void_p)]
 
 
+class CondMlp(C.Structure):
+    """vdm_cond_mlp"""
+    _fields_ = [("input", C.c_void_p), ("in_dim", C.c_int32), ("dim", C.c_int32), ("sinusoid", C.c_int32), ("reserved", C.c_int32),
+                ("w1", C.c_void_p), ("b1", C.c_void_p), ("w2", C.c_void_p), ("b2", C.c_void_p), ("wproj", C.c_void_p),
+                ("dw1", C.c_void_p), ("db1", C.c_void_p), ("dw2", C.c_void_p), ("db2", C.c_void_p), ("dwproj", C.c_void_p)]
+
+
 PACK_CHUNK = 16384                   # VDM_PACK_CHUNK
 _p, _i, _i64, _u64, _f, _sz = C.c_void_p, C.c_int, C.c_int64, C.c_uint64, C.c_float, C.c_size_t
 _D = C.POINTER(ConvDesc)
@@ -72,6 +79,10 @@ SIGNATURES = {
     "vdm_gn_bwd_finalize": (_i, [_p, _i, _i, _i, _i, _i64, _p, _p, _f, _p, _p, _p, _p, _i64, _p]),
     "vdm_gn_bwd_apply": (_i, [_p, _i, _p, _i, _i, _i64, _i, _i, _p, _p, _f, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p]),
     "vdm_pack_input": (_i, [_p, _p, _i64, _i, _i, _p, _p]),
+    "vdm_cond_saved_floats": (_sz, [C.POINTER(CondMlp), _i, _i]),
+    "vdm_cond_table_fwd": (_i, [C.POINTER(CondMlp), _i, _i, _i, _p, _p, _p]),
+    "vdm_cond_table_bwd": (_i, [C.POINTER(CondMlp), _i, _i, _i, _p, _i64, _p, _p, _p, _p]),
+    "vdm_cond_table_step": (_i, [_p, _p, _p, _i, _i, _p, _p]),
     "vdm_diffuse": (_i, [_p, _p, _p, _p, _i, _i64, _p, _p]),
     "vdm_loss_terms": (_i, [_p, _p, _p, _p, _f, _p, _i, _i64, _p, _p, _p, _p]),
     "vdm_ancestral_step": (_i, [_p, _p, _p, _p, _p, _u64, _i64, _p]),

@@ -9,7 +9,7 @@ import ctypes as C
 import torch
 
 from . import _lib
-from ._lib import ConvDesc, GnFold, PACK_DGRAD, PACK_FWD, VDM_BF16, VDM_F32, check
+from ._lib import CondMlp, ConvDesc, GnFold, PACK_DGRAD, PACK_FWD, VDM_BF16, VDM_F32, check
 
 GN_EPS = 1e-5
 
@@ -419,6 +419,56 @@ def pack_input(a, b, dtype, out=None):
     if out is None:
         out = torch.empty(tuple(a.shape) + (cp,), dtype=dtype, device=a.device)
     check(L.vdm_pack_input(_p(a), _p(b), a.numel(), cp, dt_id(dtype), _p(out), _s()), "vdm_pack_input")
+    return out
+
+
+class CondTable:
+    """K6: the conditioning MLPs and the additive injection table of all blocks (vdm_cond_table_*).
+    specs: list of dicts {input: tensor ([rows] for the sinusoidal t embedding, [rows, d] for a vector), sinusoid: bool, in_dim,
+    w1, b1, w2, b2, wproj: fp32 device tensors (views into the flat parameter vector)}."""
+
+    def __init__(self, specs, rows, width):
+        self.specs, self.rows, self.width = specs, rows, width
+        self.saved = None
+
+    def _descs(self, grads=None):
+        arr = (CondMlp * len(self.specs))()
+        for k, sp in enumerate(self.specs):
+            _contig(sp["input"], sp["w1"], sp["b1"], sp["w2"], sp["b2"], sp["wproj"])
+            assert sp["input"].dtype == torch.float32 and sp["input"].shape[0] == self.rows
+            d = arr[k]
+            d.input, d.in_dim, d.dim, d.sinusoid = _p(sp["input"]), int(sp["in_dim"]), int(sp["w2"].shape[0]), 1 if sp["sinusoid"] else 0
+            d.w1, d.b1, d.w2, d.b2, d.wproj = _p(sp["w1"]), _p(sp["b1"]), _p(sp["w2"]), _p(sp["b2"]), _p(sp["wproj"])
+            assert tuple(sp["w1"].shape) == (d.dim, d.in_dim) and tuple(sp["wproj"].shape) == (self.width, d.dim)
+            if grads is not None:
+                g = grads[k]
+                _contig(g["w1"], g["b1"], g["w2"], g["b2"], g["wproj"])
+                d.dw1, d.db1, d.dw2, d.db2, d.dwproj = _p(g["w1"]), _p(g["b1"]), _p(g["w2"]), _p(g["b2"]), _p(g["wproj"])
+        return arr
+
+    def forward(self, save):
+        L = _lib.lib()
+        dev = self.specs[0]["w1"].device
+        arr = self._descs()
+        table = torch.empty((self.rows, self.width), dtype=torch.float32, device=dev)
+        self.saved = torch.empty(L.vdm_cond_saved_floats(arr, len(self.specs), self.rows), dtype=torch.float32, device=dev) if save else None
+        check(L.vdm_cond_table_fwd(arr, len(self.specs), self.rows, self.width, _p(table), _p(self.saved), _s()), "vdm_cond_table_fwd")
+        return table
+
+    def backward(self, dtable, grads, dbias=None):
+        """grads: list of dicts {w1, b1, w2, b2, wproj} of fp32 views that receive the parameter gradients (plain stores)."""
+        L = _lib.lib()
+        assert self.saved is not None and dtable.dtype == torch.float32 and dtable.stride(1) == 1 and dtable.shape[0] == self.rows
+        arr = self._descs(grads)
+        scratch = torch.empty(2 * self.rows * sum(int(sp["w2"].shape[0]) for sp in self.specs), dtype=torch.float32, device=dtable.device)
+        check(L.vdm_cond_table_bwd(arr, len(self.specs), self.rows, self.width, _p(dtable), dtable.stride(0), _p(self.saved), _p(scratch),
+                                   _p(dbias), _s()), "vdm_cond_table_bwd")
+        self.saved = None
+
+
+def cond_table_step(table_t, table_v, step_ptr, rows, width, out):
+    _contig(table_t, table_v, out)
+    check(_lib.lib().vdm_cond_table_step(_p(table_t), _p(table_v), _p(step_ptr), rows, width, _p(out), _s()), "vdm_cond_table_step")
     return out
 
 

@@ -267,6 +267,24 @@ class CUNet(nn.Module):
             table = torch.zeros(batch, self.table_width, device=self.flat.device)
         return table
 
+    def cond_specs(self, t, v_conditionings, flat=None, which="all"):
+        """Descriptors of the conditioning MLPs for the K6 kernel (hip_ops.CondTable): views of `flat` (or of a gradient vector of
+        the same layout).  which: "all" | "t" | "v".  t: [rows] fp32 or None; v_conditionings: list of [rows, d] fp32."""
+        specs, k = [], 0
+        if self.t_conditioning:
+            if which in ("all", "t"):
+                specs.append(dict(input=t, sinusoid=True, in_dim=T_EMB_DIM, w1=self.view("t_embed.0.weight", flat),
+                                  b1=self.view("t_embed.0.bias", flat), w2=self.view("t_embed.2.weight", flat),
+                                  b2=self.view("t_embed.2.bias", flat), wproj=self.cond_matrix(0, flat)))
+            k = 1
+        if which in ("all", "v"):
+            for j, dv in enumerate(self.v_conditioning_dims):
+                v = None if v_conditionings is None else v_conditionings[j]
+                specs.append(dict(input=v, sinusoid=False, in_dim=dv, w1=self.view(f"v_embeds.{j}.0.weight", flat),
+                                  b1=self.view(f"v_embeds.{j}.0.bias", flat), w2=self.view(f"v_embeds.{j}.2.weight", flat),
+                                  b2=self.view(f"v_embeds.{j}.2.bias", flat), wproj=self.cond_matrix(k + j, flat)))
+        return specs
+
     # ------------------------------------------------------------------ forward
     def forward(self, x, t=None, s_conditioning=None, v_conditionings=None, **ignored):
         B = x.shape[0]
@@ -274,10 +292,10 @@ class CUNet(nn.Module):
             t = torch.as_tensor(t, dtype=torch.float32, device=x.device).reshape(-1)
             if t.numel() == 1 and B > 1:
                 t = t.expand(B)
-        head = self.flat[:self.head_end]
-        conds = self.cond_vectors(t, v_conditionings, head)
-        table = self.cond_table(conds, B, head)
         if self.backend == "torch":
+            head = self.flat[:self.head_end]
+            conds = self.cond_vectors(t, v_conditionings, head)
+            table = self.cond_table(conds, B, head)
             return self._forward_torch(x, s_conditioning, table)
         if self.dim != 3 or self.in_channels != 1 or self.s_conditioning_channels > 1:
             raise NotImplementedError("the HIP backend covers the 3D, single-field configurations of the reference "
@@ -286,7 +304,11 @@ class CUNet(nn.Module):
             raise RuntimeError("CUNet(backend='hip') needs tensors on a GPU; there is no CPU fallback "
                                "(construct with backend='torch' for the CPU plumbing config)")
         from .unet_hip import hip_unet_apply
-        return hip_unet_apply(self, x, s_conditioning, table)
+        if self.t_conditioning:
+            assert t is not None, "t_conditioning=True needs t"
+        vs = list(v_conditionings or [])
+        assert len(vs) == len(self.v_conditioning_dims), "len(v_conditionings) != len(v_conditioning_dims)"
+        return hip_unet_apply(self, x, s_conditioning, t=t, v_conditionings=vs)
 
     # ------------------------------------------------------------------ explicit torch backend (C1 plumbing)
     def _conv_t(self, x, wname, bname, stride=1):

@@ -239,8 +239,9 @@ class HipUNet:
             self.saved = (flat, xin, skips, coarse[::-1], h, st, a, table.shape)
         return eps.view(z.shape)
 
-    def backward(self, d_eps):
-        """d_eps: fp32 [N, D, H, W].  Returns (grad of flat, grad of conditioning table)."""
+    def backward(self, d_eps, cond=None):
+        """d_eps: fp32 [N, D, H, W].  Returns (grad of flat, grad of conditioning table).  cond: the hip_ops.CondTable whose
+        forward produced the table from this flat vector (its backward fills the conditioning parameters' gradients)."""
         net = self.net
         flat, xin, skips, coarse, h_last, st, a, tshape = self.saved
         self.saved = None
@@ -279,26 +280,45 @@ class HipUNet:
             dh, _ = self.res[f"downs.{i}.block"].bwd(P, GP, dh, dtable, ss)
         ss.run(lambda: self.conv_in.wgrad(xin, dh, GP("conv_in.weight"), GP("conv_in.bias")), xin, dh)
         ss.join()
-        # conv1 biases: column sums of the conditioning-table gradient (same additive broadcast)
-        net.conv1_bias_all(gflat).copy_(dtable.sum(0))
+        if cond is not None:      # K6 backward: conditioning MLPs + projections + the conv1 biases (column sums of dtable), 2 launches
+            grads = [{k: sp[k] for k in ("w1", "b1", "w2", "b2", "wproj")} for sp in net.cond_specs(None, [None] * len(net.v_conditioning_dims), gflat)]
+            cond.backward(dtable, grads, dbias=net.conv1_bias_all(gflat))
+        else:                     # conv1 biases: column sums of the conditioning-table gradient (same additive broadcast)
+            net.conv1_bias_all(gflat).copy_(dtable.sum(0))
         self.net.weights_epoch += 1                  # the caller is about to change the parameters: re-pack at the next forward
         return gflat, dtable
 
 
 class _HipUNetFn(torch.autograd.Function):
+    """eps_hat = CUNet(z, s_cond; t, v).  With `table` = None the conditioning table comes from the K6 kernel inside (and its
+    gradient flows back into the flat parameter vector in backward); a caller-supplied table (the sampler's per-step rows) is used
+    as is."""
+
     @staticmethod
-    def forward(ctx, flat, table, z, s_cond, ex, train, seed):
-        ctx.ex = ex
-        ctx.train = train
+    def forward(ctx, flat, table, z, s_cond, ex, train, seed, t, *vs):
+        ctx.ex, ctx.train, ctx.cond, ctx.table_grad, ctx.nvs = ex, train, None, False, len(vs)
+        net = ex.net
         with torch.no_grad():
-            return ex.forward(flat.detach(), table.detach().contiguous(), z, s_cond, train, seed)
+            fl = flat.detach()
+            if table is None:
+                specs = net.cond_specs(t, list(vs), fl)
+                if specs:
+                    cond = ops.CondTable(specs, z.shape[0], net.table_width)
+                    tab = cond.forward(save=train)
+                    ctx.cond = cond if train else None
+                else:
+                    tab = torch.zeros(z.shape[0], net.table_width, device=z.device)
+            else:
+                tab = table.detach().contiguous()
+                ctx.table_grad = table.requires_grad
+            return ex.forward(fl, tab, z, s_cond, train, seed)
 
     @staticmethod
     def backward(ctx, d_eps):
         if not ctx.train:
             raise RuntimeError("HIP CUNet: backward requested but the forward ran without saving activations")
-        gflat, dtable = ctx.ex.backward(d_eps)
-        return gflat, dtable, None, None, None, None, None
+        gflat, dtable = ctx.ex.backward(d_eps, ctx.cond)
+        return (gflat, dtable if ctx.table_grad else None, None, None, None, None, None, None) + (None,) * ctx.nvs
 
 
 _seed_counter = [0]
@@ -309,8 +329,9 @@ def _dist_rank():
     return dist.get_rank() if dist.is_available() and dist.is_initialized() else 0
 
 
-def hip_unet_apply(net, x, s_conditioning, table):
-    """x: [B, 1, D, H, W] fp32 on the GPU (NCDHW API; C == 1 so NDHWC is the same memory)."""
+def hip_unet_apply(net, x, s_conditioning, table=None, t=None, v_conditionings=None):
+    """x: [B, 1, D, H, W] fp32 on the GPU (NCDHW API; C == 1 so NDHWC is the same memory).
+    table: optional precomputed conditioning table [B, table_width] (the sampler); otherwise t ([B]) / v_conditionings feed K6."""
     if net._exec is None:
         net._exec = HipUNet(net)
     B = x.shape[0]
@@ -321,11 +342,21 @@ def hip_unet_apply(net, x, s_conditioning, table):
         s = s_conditioning.to(torch.float32).reshape(B, *x.shape[2:]).contiguous()
         if s.shape[0] != B:
             s = s.expand(B, *s.shape[1:]).contiguous()
+    vs = []
+    if table is None:
+        if t is not None:
+            t = t.to(device=x.device, dtype=torch.float32).reshape(-1).contiguous()
+            assert t.numel() == B
+        for v in (v_conditionings or []):
+            v = v.to(device=x.device, dtype=torch.float32).contiguous()
+            if v.shape[0] != B:
+                v = v.expand(B, *v.shape[1:]).contiguous()
+            vs.append(v)
     # `train` here means "autograd records: keep the activations for backward"; the dropout probability follows net.training
     # (HipUNet.forward), exactly like nn.Dropout in the reference stack.
-    train = torch.is_grad_enabled() and (net.flat.requires_grad or table.requires_grad)
+    train = torch.is_grad_enabled() and (net.flat.requires_grad or (table is not None and table.requires_grad))
     _seed_counter[0] += 1000
     # per-rank dropout masks under data parallelism: every rank calls seed_everything(42), so fold the rank in
     seed = (torch.initial_seed() + _seed_counter[0] + 0x9E3779B97F4A7C15 * _dist_rank()) & 0x7fffffffffffffff
-    eps = _HipUNetFn.apply(net.flat, table, z, s, net._exec, train, seed)
+    eps = _HipUNetFn.apply(net.flat, table, z, s, net._exec, train, seed, t, *vs)
     return eps.view(x.shape)

@@ -246,29 +246,26 @@ class VDM(nn.Module):
         seed = int(torch.randint(0, 2 ** 62, (1,)).item()) if seed is None else int(seed)
         noise_buf = torch.empty_like(z) if noises is not None else None
 
-        # The conditioning of every step is known up front: run the (tiny) embedding MLPs once for all n time values and
-        # keep one table row per step; inside the step only a row gather remains (about 20 small launches less per step).
+        # The conditioning of every step is known up front: ONE K6 launch embeds all n time values (one table row per step), one more
+        # the vector conditionings; inside the step a single gather-add kernel builds the table (device-side step counter).
         net = self.score_model
+        W = net.table_width
+        table_t = table_v = None
         with torch.no_grad():
-            k0 = 0
-            table_t = None
+            fl = net.flat.detach()
             if net.t_conditioning:
-                table_t = F.linear(net._mlp2("t_embed", net.sinusoidal_embedding(coef[:, 3].contiguous())), net.cond_matrix(0))
-                k0 = 1
-            table_v = None
-            for k, v in enumerate(list(kwargs.get("v_conditionings") or [])):
-                part = F.linear(net._mlp2(f"v_embeds.{k}", v.to(device=dev, dtype=torch.float32)), net.cond_matrix(k0 + k))
-                table_v = part if table_v is None else table_v + part
+                table_t = ops.CondTable(net.cond_specs(coef[:, 3].contiguous(), None, fl, which="t"), n, W).forward(save=False)
+            vs = [v.to(device=dev, dtype=torch.float32).expand(B, -1).contiguous() for v in list(kwargs.get("v_conditionings") or [])]
+            if vs:
+                table_v = ops.CondTable(net.cond_specs(None, vs, fl, which="v"), B, W).forward(save=False)
         s_cond = kwargs.get("s_conditioning")
+        table = torch.zeros(B, W, device=dev)
         from .unet_hip import hip_unet_apply
 
         def one_step():
-            if table_t is not None:
-                table = table_t.index_select(0, step).expand(B, -1)
-                table = table + table_v if table_v is not None else table.contiguous()
-            else:
-                table = table_v if table_v is not None else torch.zeros(B, net.table_width, device=dev)
-            eps_hat = hip_unet_apply(net, z, s_cond, table)
+            if table_t is not None or table_v is not None:
+                ops.cond_table_step(table_t, table_v, step, B, W, table)
+            eps_hat = hip_unet_apply(net, z, s_cond, table=table)
             ops.ancestral_step(z, eps_hat.contiguous(), noise_buf, coef, step, seed)
             ops.step_inc(step)
 
