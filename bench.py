@@ -140,13 +140,15 @@ def main():
     opt = vdm.configure_optimizers()
     batch = make_batch(D, B, rank, device)
     vdm.train()
+    net.enable_ddp(world)            # N > 1: the backward all-reduces the flat gradient in 4 buckets, overlapped with its own tail
 
     def step():
         loss = vdm.training_step(batch, 0)
         opt.zero_grad(set_to_none=True)
         loss.backward()
+        synced, net.grad_synced = net.grad_synced, False
         for p in params:
-            if p.grad is not None:
+            if p.grad is not None and not (synced and p is net.flat):
                 allreduce_mean_(p.grad, world)
         clip_grad_norm_flat_(params, 0.5, use_hip=True)
         opt.step()

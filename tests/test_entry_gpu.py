@@ -126,3 +126,31 @@ def test_pk_on_device_matches_reference_golden(case):
     np.testing.assert_allclose(utils.get_ccs(x, y)[1].cpu().numpy(), gold[f"{name}/cc"], atol=5e-6)
     if dim == 2:
         np.testing.assert_allclose(utils.get_ccs(x, y, full=True)[1].cpu().numpy(), gold[f"{name}/cc_full"], atol=5e-6)
+
+
+def test_hip_training_step_under_rccl_world1(tmp_path):
+    """HIP kernels and a process group in ONE process: Trainer.fit on the HIP backend inside an `nccl` (RCCL) group of world size 1,
+    once with the bucketed all-reduce forced on (the N > 1 code path: 4 slices of the flat gradient averaged on the communication
+    stream while the backward continues) and once without.  Averaging over one rank is the identity and the step is deterministic,
+    so the two runs must end with bit-identical weights."""
+    import socket
+    outs = {}
+    for forced in ("1", ""):
+        s = socket.socket()
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+        s.close()
+        d = tmp_path / f"f{forced or 0}"
+        d.mkdir()
+        env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "VDM4CDM_FORCE_BUCKETS")}
+        if forced:
+            env["VDM4CDM_FORCE_BUCKETS"] = "1"
+        r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "_ddp_gpu_worker.py"), str(d), str(port)], env=env, cwd=ROOT,
+                           capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+        outs[forced] = torch.load(d / "out.pt")
+    assert outs["1"]["bucketed"] and not outs[""]["bucketed"]
+    b = outs["1"]["bounds"]
+    assert len(b) == 4 and b[-1][0] == 0 and all(b[i][0] == b[i + 1][1] for i in range(3))      # contiguous cover, back to front
+    assert torch.isfinite(outs["1"]["flat"]).all()
+    assert torch.equal(outs["1"]["flat"], outs[""]["flat"]), "bucketed all-reduce changed the result of a world-1 step"

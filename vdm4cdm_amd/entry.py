@@ -130,6 +130,11 @@ GENERATE_WHITELIST = ["VDM_Go7_Mcdm_c_c_128", "VDM_Go8_Mcdm_c_c_128", "VDM_Go9_M
                       "VDM_Mstar_Mcdm_c_uc_256", "SFM_Mstar_Mcdm_c_c_128", "SFM_Mstar_Mcdm_c_c_256"]
 
 
+def chain_seed(chain):
+    """Seed of one sampling chain: a function of the GLOBAL chain id only, so a run gives the same cubes for any number of ranks."""
+    return 1_000_003 * int(chain) + 17
+
+
 def generate_3d(argv=None, configs_path=None):
     """Sampling entry point; (cube, repetition) chains are dealt round-robin to the ranks when launched under torchrun."""
     import yaml
@@ -145,14 +150,16 @@ def generate_3d(argv=None, configs_path=None):
         raise NotImplementedError("This model is not implemented yet")
     assert args.runtype in ["CV_12_12", "CV_1_128"]
     os.makedirs(args.save_path, exist_ok=True)
-    rank, local_rank, world = dist_env()
-    device = f"cuda:{local_rank}" if torch.cuda.is_available() else "cpu"
-    if torch.cuda.is_available():
+    from .trainer import init_distributed
+    use_cuda = torch.cuda.is_available() and os.environ.get("VDM4CDM_BACKEND", "hip") == "hip"
+    rank, local_rank, world = init_distributed("cuda" if use_cuda else "cpu")      # (process group only for the final barrier)
+    device = f"cuda:{local_rank}" if use_cuda else "cpu"
+    if use_cuda:
         torch.cuda.set_device(local_rank)
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     configs = yaml.safe_load(open(configs_path or os.path.join(root, "configs.yaml")))
     config = configs[args.model_name]
-    model = utils.get_model(config)
+    model = utils.get_model(config, backend=os.environ.get("VDM4CDM_BACKEND", "hip"))
     model.to(device)
     model.eval()
     config["data_params"].update(set_name="CV", stage="test", batch_size=1)
@@ -167,18 +174,36 @@ def generate_3d(argv=None, configs_path=None):
             continue
         s_conditioning = batch["conditioning"].to(device)
         v_conditionings = [d.to(device) for d in batch["conditioning_values"]] if config.get("conditioning_values", 6) else []
-        gens = []
+        gens, ids = [], []
         for i in range(rep):
-            chain = count * rep + i
+            chain = count * rep + i                      # global chain id: the unit that is dealt to the ranks
             if chain % world != rank:
                 continue
-            gen = model.draw_samples(batch_size=1, n_sampling_steps=n_steps, seed=1_000_003 * chain + 17,
+            gen = model.draw_samples(batch_size=1, n_sampling_steps=n_steps, seed=chain_seed(chain),
                                      s_conditioning=s_conditioning, v_conditionings=v_conditionings, verbose=(rank == 0))
             gens.append(gen.detach().cpu().numpy())
-        if gens:
-            suffix = "" if world == 1 else f"_rank{rank}"
-            np.save(os.path.join(args.save_path, f"gen_{count}{suffix}.npy"), np.concatenate(gens, axis=0))
+            ids.append(i)
+        if world == 1:
+            np.save(os.path.join(args.save_path, f"gen_{count}.npy"), np.concatenate(gens, axis=0))
+        elif gens:                                       # shard of this rank: repetitions `ids` of cube `count`
+            np.savez(os.path.join(args.save_path, f"gen_{count}_rank{rank}.npz"), gens=np.concatenate(gens, axis=0), ids=np.array(ids))
         count += 1
         if count == n_cubes:
             break
+    if world > 1:                                        # rank 0 assembles gen_{count}.npy exactly as a single process writes it
+        import torch.distributed as dist
+        dist.barrier()
+        if rank == 0:
+            for c in range(count):
+                parts = {}
+                for r in range(world):
+                    f = os.path.join(args.save_path, f"gen_{c}_rank{r}.npz")
+                    if os.path.exists(f):
+                        z = np.load(f)
+                        for i, g in zip(z["ids"], z["gens"]):
+                            parts[int(i)] = g
+                        os.remove(f)
+                assert sorted(parts) == list(range(rep)), f"cube {c}: repetitions {sorted(parts)} of {rep} arrived"
+                np.save(os.path.join(args.save_path, f"gen_{c}.npy"), np.stack([parts[i] for i in range(rep)], axis=0))
+        dist.barrier()
     return count

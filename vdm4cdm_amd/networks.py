@@ -83,6 +83,7 @@ class CUNet(nn.Module):
         self.reset_parameters()
         self._exec = None
         self.weights_epoch = 0            # see mark_weights_dirty()
+        self.grad_synced = False          # set by the HIP backward when it already averaged flat.grad over the ranks (enable_ddp)
 
     # ------------------------------------------------------------------ structure
     def _block_list(self):
@@ -111,10 +112,8 @@ class CUNet(nn.Module):
         # (2) conv1 biases of all blocks, contiguous (their gradient is the column sum of the table gradient)
         for b in self.blocks:
             sp.add(f"{b.name}.conv1.bias", (b.cout,), "bias", T * (b.c1 + b.c2))
-        # (3) everything else
-        cin0 = self.in_channels + self.s_conditioning_channels
-        sp.add("conv_in.weight", (T, chs[0], cin0), "conv", T * cin0)
-        sp.add("conv_in.bias", (chs[0],), "bias", T * cin0)
+        # (3) the conditioning MLPs.  Everything the conditioning path reads lies in [0, head_end): the torch backend slices the flat
+        # vector ONCE there (one autograd gradient for these parameters instead of one full-size tensor per parameter view).
         if self.t_conditioning:
             sp.add("t_embed.0.weight", (4 * chs[0], T_EMB_DIM), "linear", T_EMB_DIM)
             sp.add("t_embed.0.bias", (4 * chs[0],), "bias", T_EMB_DIM)
@@ -125,10 +124,15 @@ class CUNet(nn.Module):
             sp.add(f"v_embeds.{k}.0.bias", (V_EMB_DIM,), "bias", dv)
             sp.add(f"v_embeds.{k}.2.weight", (V_EMB_DIM, V_EMB_DIM), "linear", V_EMB_DIM)
             sp.add(f"v_embeds.{k}.2.bias", (V_EMB_DIM,), "bias", V_EMB_DIM)
-        # everything the (torch autograd) conditioning MLPs read lies in [0, head_end): forward() slices the flat vector ONCE, so the
-        # backward pass materialises one full-size gradient for these parameters instead of one per parameter view
         self.head_end = sp.total
-        for b in self.blocks:
+        # (4) the layers in FORWARD order: the backward pass then completes the gradient vector from its end towards its start, so
+        # contiguous slices of it can be all-reduced while the rest of the backward is still running (bucket_bounds)
+        cin0 = self.in_channels + self.s_conditioning_channels
+        sp.add("conv_in.weight", (T, chs[0], cin0), "conv", T * cin0)
+        sp.add("conv_in.bias", (chs[0],), "bias", T * cin0)
+        blocks = {b.name: b for b in self.blocks}
+
+        def add_block(b):
             cin = b.c1 + b.c2
             sp.add(f"{b.name}.norm1.weight", (cin,), "ones")
             sp.add(f"{b.name}.norm1.bias", (cin,), "zeros")
@@ -142,11 +146,18 @@ class CUNet(nn.Module):
                 if b.c2:
                     sp.add(f"{b.name}.skip2.weight", (1, b.cout, b.c2), "conv", cin)
                 sp.add(f"{b.name}.skip.bias", (b.cout,), "bias", cin)
-        for i in range(L - 1):
-            sp.add(f"downs.{i}.down.weight", (T, chs[i], chs[i]), "conv", T * chs[i])
-            sp.add(f"downs.{i}.down.bias", (chs[i],), "bias", T * chs[i])
+
+        for i in range(L):
+            add_block(blocks[f"downs.{i}.block"])
+            if i != L - 1:
+                sp.add(f"downs.{i}.down.weight", (T, chs[i], chs[i]), "conv", T * chs[i])
+                sp.add(f"downs.{i}.down.bias", (chs[i],), "bias", T * chs[i])
+        for j in range(2):
+            add_block(blocks[f"mid.{j}"])
+        for i in reversed(range(L - 1)):
             sp.add(f"ups.{i}.up.weight", (T, chs[i], chs[i + 1]), "conv", T * chs[i + 1])
             sp.add(f"ups.{i}.up.bias", (chs[i],), "bias", T * chs[i + 1])
+            add_block(blocks[f"ups.{i}.block"])
         sp.add("norm_out.weight", (chs[0],), "ones")
         sp.add("norm_out.bias", (chs[0],), "zeros")
         sp.add("conv_out.weight", (T, self.in_channels, chs[0]), "zeros")            # D6: zero-init
@@ -173,6 +184,30 @@ class CUNet(nn.Module):
         off, shape, _, _ = self.spec.items[name]
         f = self.flat if flat is None else flat
         return f[off:off + math.prod(shape)].view(shape)
+
+    def bucket_bounds(self):
+        """Slices of the flat (gradient) vector in the order the backward pass completes them, with the layer after whose backward
+        each is final: [(lo, hi, ready_after)], ready_after in {"ups", "mid", "downs.top", "end"}.  Data-parallel training
+        all-reduces them one by one on a communication stream while the backward continues (unet_hip.HipUNet.backward)."""
+        L = len(self.chs)
+        off = lambda name: self.spec.items[name][0]
+        total = self.spec.total
+        if L < 2:
+            return [(0, total, "end")]
+        cuts = [(off(f"ups.{L - 2}.up.weight"), total, "ups"), (off("mid.0.norm1.weight"), off(f"ups.{L - 2}.up.weight"), "mid"),
+                (off(f"downs.{L - 1}.block.norm1.weight"), off("mid.0.norm1.weight"), "downs.top"),
+                (0, off(f"downs.{L - 1}.block.norm1.weight"), "end")]
+        return [c for c in cuts if c[1] > c[0]]
+
+    def enable_ddp(self, world, group=None):
+        """Data-parallel training on the HIP backend: the backward pass all-reduces the flat gradient in buckets, overlapped with
+        the remaining backward kernels (unet_hip.GradBuckets).  No-op on the torch backend (the trainer reduces p.grad itself)."""
+        if self.backend != "hip":
+            return
+        if self._exec is None:
+            from .unet_hip import HipUNet
+            self._exec = HipUNet(self)
+        self._exec.enable_ddp(world, group)
 
     def mark_weights_dirty(self):
         """Tell the HIP executor that the parameters changed through an op that does not bump Tensor._version (fused optimizers):

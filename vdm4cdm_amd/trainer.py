@@ -103,6 +103,9 @@ class Trainer:
         if self.world > 1:                                   # identical weights on every rank
             for p in params:
                 dist.broadcast(p.data, src=0)
+        sm = model.model.score_model
+        if hasattr(sm, "enable_ddp") and dev_type == "cuda":     # HIP backend: bucketed all-reduce inside the backward pass
+            sm.enable_ddp(self.world)
         opt = model.configure_optimizers()
         use_hip = dev_type == "cuda" and getattr(model.model.score_model, "backend", "") == "hip"
         epoch, t0 = 0, time.time()
@@ -114,8 +117,10 @@ class Trainer:
                 loss = model.training_step(batch, self.global_step)
                 opt.zero_grad(set_to_none=True)
                 loss.backward()
-                for p in params:                              # one collective per parameter tensor (flat UNet vector + <=2 scalars)
-                    if p.grad is not None:
+                synced = getattr(sm, "grad_synced", False)     # the HIP backward already averaged the flat UNet gradient (in buckets)
+                sm.grad_synced = False
+                for p in params:                              # one collective per remaining parameter tensor (<= 2 schedule scalars)
+                    if p.grad is not None and not (synced and p is getattr(sm, "flat", None)):
                         allreduce_mean_(p.grad, self.world)
                 gnorm = None
                 if self.gradient_clip_val:

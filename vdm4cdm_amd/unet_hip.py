@@ -157,9 +157,51 @@ class _Res:
                                GP(n + ".norm1.weight"), GP(n + ".norm1.bias"), add1=add1, add2=add2)
 
 
+class GradBuckets:
+    """Data-parallel gradient averaging overlapped with the backward pass: the flat gradient vector is
+    completed from its end towards its start (CUNet parameter order = forward order), so each finished slice (CUNet.bucket_bounds:
+    up path | mid blocks | deepest down block | the rest) is all-reduced over RCCL on a communication stream while the remaining
+    levels - the expensive level-0/1 dgrad and wgrad kernels - are still running.  `finish()` makes the main stream wait for all
+    of them (before the global-norm clip, which must see the averaged gradient on every rank)."""
+
+    def __init__(self, device, world, group=None):
+        import torch.distributed as dist
+        self.dist, self.world, self.group = dist, world, group
+        self.comm = torch.cuda.Stream(device=device)
+        self.works = []
+        self.avg = dist.get_backend(group) == "nccl"          # RCCL averages in the collective; gloo sums (then one scale pass)
+        self.issued = []
+
+    def ready(self, gflat, lo, hi, side_streams):
+        """The slice [lo, hi) of gflat is final once everything issued so far on the main stream and the side streams has run."""
+        main = torch.cuda.current_stream()
+        self.comm.wait_stream(main)
+        for st in side_streams:
+            if st is not None:
+                self.comm.wait_stream(st)
+        sl = gflat[lo:hi]
+        with torch.cuda.stream(self.comm):
+            op = self.dist.ReduceOp.AVG if self.avg else self.dist.ReduceOp.SUM
+            self.works.append(self.dist.all_reduce(sl, op=op, group=self.group, async_op=True))
+            if not self.avg:
+                self.works[-1].wait()
+                sl.div_(self.world)
+        sl.record_stream(self.comm)
+        self.issued.append((lo, hi))
+
+    def finish(self):
+        for w in self.works:
+            w.wait()                                            # (stream-level wait for the collective, not a host block)
+        torch.cuda.current_stream().wait_stream(self.comm)
+        self.works = []
+        done, self.issued = self.issued, []
+        return done
+
+
 class HipUNet:
     def __init__(self, net):
         self.net = net
+        self.buckets = None               # GradBuckets when data-parallel training is on (enable_ddp)
         circ = net.conv_padding_mode == "circular"
         chs, L = net.chs, len(net.chs)
         self.cin0 = net.in_channels + net.s_conditioning_channels
@@ -198,6 +240,18 @@ class HipUNet:
             self._pack_plan = (pkey, ops.PackPlan([(conv, self.net.view(name, flat)) for conv, name in self._all_convs()], dtype, need_dgrad))
         self._pack_plan[1].run()
         self._packed_key = key
+
+    def enable_ddp(self, world, group=None):
+        """Average the gradient over `world` ranks inside backward(), bucket by bucket (see GradBuckets); CUNet.grad_synced tells
+        the trainer that the flat gradient it receives is already averaged."""
+        self.buckets = GradBuckets(self.net.flat.device, world, group) if world > 1 or os.environ.get("VDM4CDM_FORCE_BUCKETS") else None
+
+    def _bucket_ready(self, gflat, after, ss):
+        if self.buckets is None:
+            return
+        for lo, hi, when in self.net.bucket_bounds():
+            if when == after:
+                self.buckets.ready(gflat, lo, hi, [ss.side if ss.enabled else None, ss.second.side if (ss.second and ss.second.enabled) else None])
 
     def _side_stream(self, device):
         if self._ss is None or (self._ss.enabled and self._ss.side.device != device):
@@ -270,9 +324,13 @@ class HipUNet:
             ss.run(lambda i=i, du=du: self.up[i].wgrad(coarse[i], du, GP(f"ups.{i}.up.weight"), GP(f"ups.{i}.up.bias")), coarse[i], du)
             dh = self.up[i].dgrad(du)              # gradient w.r.t. the coarse source (per-parity-class conv, no pooling pass)
             del du
+        self._bucket_ready(gflat, "ups", ss)       # norm_out / conv_out / every up block and up conv: final (RCCL starts on them)
         for j in reversed(range(2)):
             dh, _ = self.res[f"mid.{j}"].bwd(P, GP, dh, dtable, ss)
+        self._bucket_ready(gflat, "mid", ss)
         for i in reversed(range(L)):
+            if i == L - 2:
+                self._bucket_ready(gflat, "downs.top", ss)
             if i != L - 1:
                 ss.run(lambda i=i, dh=dh: self.down[i].wgrad(skips[i], dh, GP(f"downs.{i}.down.weight"), GP(f"downs.{i}.down.bias")),
                        skips[i], dh)
@@ -285,6 +343,11 @@ class HipUNet:
             cond.backward(dtable, grads, dbias=net.conv1_bias_all(gflat))
         else:                     # conv1 biases: column sums of the conditioning-table gradient (same additive broadcast)
             net.conv1_bias_all(gflat).copy_(dtable.sum(0))
+        self._bucket_ready(gflat, "end", ss)
+        if self.buckets is not None:
+            done = self.buckets.finish()
+            assert sum(hi - lo for lo, hi in done) == gflat.numel(), "gradient buckets do not cover the parameter vector"
+            net.grad_synced = True
         self.net.weights_epoch += 1                  # the caller is about to change the parameters: re-pack at the next forward
         return gflat, dtable
 

@@ -227,12 +227,16 @@ class VDM(nn.Module):
                 rng = trange(n_sampling_steps, desc="sampling")
             except ImportError:
                 pass
+        gen = None
+        if noises is None and seed is not None:              # a seeded chain is reproducible on this path too (per-step noise from
+            gen = torch.Generator().manual_seed(int(seed) + 1)   # the chain's own generator, not the global RNG)
         for i in rng:
-            if noises is None:
+            if noises is None and gen is None:
                 z = self.sample_zs_given_zt(zt=z, t=steps[i], s=steps[i + 1], **kwargs)
             else:
                 w_z, w_x, x0, scale = self.sample_zs_given_zt(zt=z, t=steps[i], s=steps[i + 1], return_ddnm=True, **kwargs)
-                z = w_z * z + w_x * x0 + scale * noises[i].to(z)
+                eps = noises[i].to(z) if noises is not None else torch.randn(z.shape, generator=gen).to(z)
+                z = w_z * z + w_x * x0 + scale * eps
             if return_all:
                 zs.append(z)
         return torch.stack(zs, dim=0) if return_all else z
