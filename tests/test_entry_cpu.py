@@ -63,3 +63,80 @@ def test_ddnm_sampler_api_on_torch_backend():
     out = utils.get_ddnm_result(vdm, y, A=lambda x: x * mask, AT=lambda x: x * mask, n_sampling_steps=4, l=1)
     assert out.shape == (1, 1, 8, 8, 8) and torch.isfinite(out).all()
     assert torch.allclose(out * mask, y, atol=1e-5)            # the range-space part is pinned to the observation
+
+
+# ------------------------------------------------------------------------------ calc_SS statistics vs the reference's own functions
+import numpy as np  # noqa: E402
+
+SS_GOLD = np.load(os.path.join(ROOT, "tests", "golden", "ss_golden.npz"))
+
+
+def _ss_mod():
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("mk_ss", os.path.join(ROOT, "tests", "golden", "make_ss_golden.py"))
+    m = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(m)
+    return m
+
+
+SSMK = _ss_mod()
+
+
+def check_ss_case(case, device):
+    """calc_ss.get_stats on `device` against the outputs of the reference's get_pk_3d / get_pk_2d / get_logpdf_3d / get_logpdf_2d
+    (tests/golden/make_ss_golden.py): histogram counts bit-exact, P(k) within 1e-4, moments within 1e-5."""
+    from vdm4cdm_amd import calc_ss
+    name, seed, B, D = case
+    f = SSMK.density(seed, B, D).to(device)
+    st = calc_ss.get_stats(f, resol=D)
+    assert not any("rwst" in k for k in st)
+    for key in ("3d", "2d_half", "2d_quarter"):
+        assert np.array_equal(st[f"{key}_logpdf"], SS_GOLD[f"{name}/{key}_logpdf"]), f"{name}/{key}_logpdf"
+        assert st[f"{key}_logpdf"].sum() > 0
+        np.testing.assert_allclose(st[f"{key}_pk"], SS_GOLD[f"{name}/{key}_pk"], rtol=1e-4)
+        np.testing.assert_allclose([st[f"{key}_mean"], st[f"{key}_std"]], SS_GOLD[f"{name}/{key}_mean"], rtol=1e-5)
+
+
+@pytest.mark.parametrize("case", SSMK.CASES, ids=[c[0] for c in SSMK.CASES])
+def test_calc_ss_matches_reference_golden(case):
+    check_ss_case(case, "cpu")
+
+
+def test_sampling_scripts_and_calc_ss_end_to_end(tmp_path):
+    """generate_3D.py CV_12_12 + generate_3D_1P.py 1P_24 (torch backend on CPU, shrunk registry entry) -> calc_SS.py -> summary.pth
+    with the reference's key layout (stats / images per generated cube and per ground-truth cube)."""
+    import torch
+    cfgs = yaml.safe_load(open(os.path.join(ROOT, "configs.yaml")))
+    name = "VDM_Mstar_Mcdm_c_c_128"
+    cfgs[name].update(cropsize=8, res=8, chs=[8, 16], ckpt_path=str(tmp_path / "none.ckpt"))
+    cfg_path = tmp_path / "configs.yaml"
+    yaml.safe_dump(cfgs, open(cfg_path, "w"))
+    gen_dir = tmp_path / "gen"
+    env = dict({k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}, OMP_NUM_THREADS="2",
+               VDM4CDM_BACKEND="torch", VDM4CDM_SAMPLING_STEPS="2", VDM4CDM_REP="2", VDM4CDM_GEN_DIR=str(gen_dir))
+    for fn, runtype in (("generate_3d", "CV_12_12"), ("generate_3d_1p", "1P_24")):
+        code = ("import sys; sys.path.insert(0, %r); from vdm4cdm_amd import entry; entry.%s([%r, %r, %r], configs_path=%r)"
+                % (ROOT, fn, name, str(gen_dir / name / runtype), runtype, str(cfg_path)))
+        r = subprocess.run([sys.executable, "-c", code], env=env, cwd=ROOT, capture_output=True, text=True, timeout=900)
+        assert r.returncode == 0, r.stderr[-3000:]
+    assert sorted(f.name for f in (gen_dir / name / "1P_24").glob("*.npy")) == sorted(f"{n}_2.npy" for n in ["fid", "Om_m2", "Om_p2", "ASN1_m3", "ASN1_p3"])
+    # calc_SS expects 12 repetitions per CV cube and 24 per 1P cube; the shrunk run has 2: statistics of what is there
+    code = ("import sys; sys.path.insert(0, %r); from vdm4cdm_amd import calc_ss; calc_ss.main([%r], configs_path=%r)"
+            % (ROOT, name, str(cfg_path)))
+    r = subprocess.run([sys.executable, "-c", code], env=dict(env, VDM4CDM_REP="2"), cwd=ROOT, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    summ = torch.load(gen_dir / name / "summary.pth", weights_only=False)
+    assert set(summ) == {"CV_12_12", "1P_24"}
+    st = summ["CV_12_12"]["stats"]
+    assert "Mcdm_GT_0" in st and "Mcdm_11_1" in st and st["Mcdm_0_0"]["3d_pk"].shape == (1, 4) and st["Mcdm_0_0"]["3d_logpdf"].shape == (1, 99)
+    assert "half_Mcdm_3_1" in summ["CV_12_12"]["images"] and "quarter_cond_GT_5" in summ["CV_12_12"]["images"]
+    assert "Mcdm_GT_fid" in summ["1P_24"]["stats"] and "Mcdm_ASN1_p3_1" in summ["1P_24"]["stats"]
+
+
+def test_train_uc_c_entry_runs_on_cpu(tmp_path):
+    env = dict(os.environ, VDM4CDM_MAX_STEPS="2", VDM4CDM_CROPSIZE_2D="32", VDM4CDM_BATCH_2D="4", VDM4CDM_LOG_DIR=str(tmp_path),
+               OMP_NUM_THREADS="4")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "train_uc_c_from_field_name.py"), "Mcdm"], env=env, cwd=ROOT,
+                       capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    assert os.path.exists(tmp_path / "LH_uc_c_Mcdm" / "metrics.jsonl")

@@ -154,3 +154,21 @@ def test_hip_training_step_under_rccl_world1(tmp_path):
     assert len(b) == 4 and b[-1][0] == 0 and all(b[i][0] == b[i + 1][1] for i in range(3))      # contiguous cover, back to front
     assert torch.isfinite(outs["1"]["flat"]).all()
     assert torch.equal(outs["1"]["flat"], outs[""]["flat"]), "bucketed all-reduce changed the result of a world-1 step"
+
+
+def _ss_cases():
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("test_entry_cpu_mod", os.path.join(ROOT, "tests", "test_entry_cpu.py"))
+    m = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(m)
+    return m
+
+
+ENTRY_CPU = _ss_cases()
+
+
+@pytest.mark.parametrize("case", ENTRY_CPU.SSMK.CASES, ids=[c[0] for c in ENTRY_CPU.SSMK.CASES])
+def test_calc_ss_on_device_matches_reference_golden(case):
+    """calc_ss.get_stats on CUDA tensors (rocFFT P(k), device-side histograms) against the outputs of the reference's
+    own calc_SS.py functions (tests/golden/ss_golden.npz): histogram counts bit-exact, P(k) within 1e-4."""
+    ENTRY_CPU.check_ss_case(case, DEV)

@@ -135,11 +135,76 @@ def chain_seed(chain):
     return 1_000_003 * int(chain) + 17
 
 
-def generate_3d(argv=None, configs_path=None):
-    """Sampling entry point; (cube, repetition) chains are dealt round-robin to the ranks when launched under torchrun."""
+def _sampling_setup(model_name, configs_path, set_name):
+    """Shared by generate_3d / generate_3d_1p: process group (for the final barrier), device, model, data module."""
     import yaml
     from . import utils
-    from .trainer import dist_env
+    from .trainer import init_distributed
+    backend = os.environ.get("VDM4CDM_BACKEND", "hip")
+    use_cuda = torch.cuda.is_available() and backend == "hip"
+    rank, local_rank, world = init_distributed("cuda" if use_cuda else "cpu")
+    device = f"cuda:{local_rank}" if use_cuda else "cpu"
+    if use_cuda:
+        torch.cuda.set_device(local_rank)
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    configs = yaml.safe_load(open(configs_path or os.path.join(root, "configs.yaml")))
+    config = configs[model_name]
+    model = utils.get_model(config, backend=backend)
+    model.to(device)
+    model.eval()
+    config["data_params"].update(set_name=set_name, stage="test", batch_size=1)
+    dm = utils.get_datamodule(config)
+    dm.device = device
+    return rank, world, device, config, model, dm
+
+
+def _sample_repetitions(model, config, batch, device, rep, first_chain, rank, world, n_steps):
+    """The `rep` independent chains of one conditioning cube that fall to this rank: [(repetition index, sample)]."""
+    s_conditioning = batch["conditioning"].to(device)
+    v_conditionings = [d.to(device) for d in batch["conditioning_values"]] if config.get("conditioning_values", 6) else []
+    out = []
+    for i in range(rep):
+        chain = first_chain + i                              # global chain id: the unit that is dealt to the ranks
+        if chain % world != rank:
+            continue
+        gen = model.draw_samples(batch_size=1, n_sampling_steps=n_steps, seed=chain_seed(chain), s_conditioning=s_conditioning,
+                                 v_conditionings=v_conditionings, verbose=(rank == 0))
+        out.append((i, gen.detach().cpu().numpy()))
+    return out
+
+
+def _save_or_shard(save_path, stem, parts, rank, world):
+    if world == 1:
+        np.save(os.path.join(save_path, f"{stem}.npy"), np.concatenate([g for _, g in parts], axis=0))
+    elif parts:
+        np.savez(os.path.join(save_path, f"{stem}_rank{rank}.npz"), gens=np.concatenate([g for _, g in parts], axis=0),
+                 ids=np.array([i for i, _ in parts]))
+
+
+def _merge_shards(save_path, stems, rep, rank, world):
+    """Rank 0 assembles <stem>.npy exactly as a single process writes it (repetitions in order), then removes the shards."""
+    if world == 1:
+        return
+    import torch.distributed as dist
+    dist.barrier()
+    if rank == 0:
+        for stem in stems:
+            parts = {}
+            for r in range(world):
+                f = os.path.join(save_path, f"{stem}_rank{r}.npz")
+                if os.path.exists(f):
+                    z = np.load(f)
+                    for i, g in zip(z["ids"], z["gens"]):
+                        parts[int(i)] = g
+                    os.remove(f)
+            assert sorted(parts) == list(range(rep)), f"{stem}: repetitions {sorted(parts)} of {rep} arrived"
+            np.save(os.path.join(save_path, f"{stem}.npy"), np.stack([parts[i] for i in range(rep)], axis=0))
+    dist.barrier()
+
+
+def generate_3d(argv=None, configs_path=None):
+    """Sampling entry point (/root/reference/generate_3D.py); (cube, repetition) chains are dealt round-robin to the ranks when
+    launched under torchrun, rank 0 merges the shards into the reference's gen_{count}.npy files."""
     ap = argparse.ArgumentParser(description="Generate 3D CDM")
     ap.add_argument("model_name", type=str, help="Model name")
     ap.add_argument("save_path", type=str, help="Save path")
@@ -150,21 +215,7 @@ def generate_3d(argv=None, configs_path=None):
         raise NotImplementedError("This model is not implemented yet")
     assert args.runtype in ["CV_12_12", "CV_1_128"]
     os.makedirs(args.save_path, exist_ok=True)
-    from .trainer import init_distributed
-    use_cuda = torch.cuda.is_available() and os.environ.get("VDM4CDM_BACKEND", "hip") == "hip"
-    rank, local_rank, world = init_distributed("cuda" if use_cuda else "cpu")      # (process group only for the final barrier)
-    device = f"cuda:{local_rank}" if use_cuda else "cpu"
-    if use_cuda:
-        torch.cuda.set_device(local_rank)
-    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    configs = yaml.safe_load(open(configs_path or os.path.join(root, "configs.yaml")))
-    config = configs[args.model_name]
-    model = utils.get_model(config, backend=os.environ.get("VDM4CDM_BACKEND", "hip"))
-    model.to(device)
-    model.eval()
-    config["data_params"].update(set_name="CV", stage="test", batch_size=1)
-    dm = utils.get_datamodule(config)
-    dm.device = device
+    rank, world, device, config, model, dm = _sampling_setup(args.model_name, configs_path, "CV")
     n_steps = int(os.environ.get("VDM4CDM_SAMPLING_STEPS", 250))
     n_cubes, rep, sel = (12, 12, None) if args.runtype == "CV_12_12" else (1, 128, 2)
     rep = int(os.environ.get("VDM4CDM_REP", rep))
@@ -172,38 +223,72 @@ def generate_3d(argv=None, configs_path=None):
     for i_batch, batch in enumerate(dm.test_dataloader()):
         if sel is not None and i_batch != sel:
             continue
-        s_conditioning = batch["conditioning"].to(device)
-        v_conditionings = [d.to(device) for d in batch["conditioning_values"]] if config.get("conditioning_values", 6) else []
-        gens, ids = [], []
-        for i in range(rep):
-            chain = count * rep + i                      # global chain id: the unit that is dealt to the ranks
-            if chain % world != rank:
-                continue
-            gen = model.draw_samples(batch_size=1, n_sampling_steps=n_steps, seed=chain_seed(chain),
-                                     s_conditioning=s_conditioning, v_conditionings=v_conditionings, verbose=(rank == 0))
-            gens.append(gen.detach().cpu().numpy())
-            ids.append(i)
-        if world == 1:
-            np.save(os.path.join(args.save_path, f"gen_{count}.npy"), np.concatenate(gens, axis=0))
-        elif gens:                                       # shard of this rank: repetitions `ids` of cube `count`
-            np.savez(os.path.join(args.save_path, f"gen_{count}_rank{rank}.npz"), gens=np.concatenate(gens, axis=0), ids=np.array(ids))
+        parts = _sample_repetitions(model, config, batch, device, rep, count * rep, rank, world, n_steps)
+        _save_or_shard(args.save_path, f"gen_{count}", parts, rank, world)
         count += 1
         if count == n_cubes:
             break
-    if world > 1:                                        # rank 0 assembles gen_{count}.npy exactly as a single process writes it
-        import torch.distributed as dist
-        dist.barrier()
-        if rank == 0:
-            for c in range(count):
-                parts = {}
-                for r in range(world):
-                    f = os.path.join(args.save_path, f"gen_{c}_rank{r}.npz")
-                    if os.path.exists(f):
-                        z = np.load(f)
-                        for i, g in zip(z["ids"], z["gens"]):
-                            parts[int(i)] = g
-                        os.remove(f)
-                assert sorted(parts) == list(range(rep)), f"cube {c}: repetitions {sorted(parts)} of {rep} arrived"
-                np.save(os.path.join(args.save_path, f"gen_{c}.npy"), np.stack([parts[i] for i in range(rep)], axis=0))
-        dist.barrier()
+    _merge_shards(args.save_path, [f"gen_{c}" for c in range(count)], rep, rank, world)
     return count
+
+
+ONE_P_GENS = [0, 4, 7, 23, 28]                          # indices into the 1P test set and their names (generate_3D_1P.py:44-45)
+ONE_P_NAMES = ["fid", "Om_m2", "Om_p2", "ASN1_m3", "ASN1_p3"]
+
+
+def generate_3d_1p(argv=None, configs_path=None):
+    """``python generate_3D_1P.py <model_name> <save_path> <runtype>`` (runtype 1P_24 | 1P_128): `rep` samples for the fiducial and
+    four one-parameter-varied conditioning cubes of the CAMELS 1P set -> <name>_<rep>.npy (/root/reference/generate_3D_1P.py:31-68)."""
+    ap = argparse.ArgumentParser(description="Generate 3D CDM")
+    ap.add_argument("model_name", type=str, help="Model name")
+    ap.add_argument("save_path", type=str, help="Save path")
+    ap.add_argument("runtype", type=str, help="Type of the generation")
+    args = ap.parse_args(argv)
+    assert args.model_name in GENERATE_WHITELIST + ["VDM_Mstar_Mcdm_c_c_256_comp"], f"unknown model {args.model_name}"
+    if "SFM" in args.model_name:
+        raise NotImplementedError("This model is not implemented yet")
+    if args.runtype not in ["1P_24", "1P_128"]:
+        raise NotImplementedError("This runtype is not implemented yet")
+    os.makedirs(args.save_path, exist_ok=True)
+    rank, world, device, config, model, dm = _sampling_setup(args.model_name, configs_path, "1P")
+    n_steps = int(os.environ.get("VDM4CDM_SAMPLING_STEPS", 250))
+    rep = int(os.environ.get("VDM4CDM_REP", 24 if args.runtype == "1P_24" else 128))
+    stems = []
+    for i_batch, batch in enumerate(dm.test_dataloader()):
+        if i_batch not in ONE_P_GENS:
+            continue
+        k = ONE_P_GENS.index(i_batch)
+        if rank == 0:
+            print(ONE_P_NAMES[k], "params", batch["conditioning_values"], flush=True)
+        parts = _sample_repetitions(model, config, batch, device, rep, k * rep, rank, world, n_steps)
+        stems.append(f"{ONE_P_NAMES[k]}_{rep}")
+        _save_or_shard(args.save_path, stems[-1], parts, rank, world)
+    _merge_shards(args.save_path, stems, rep, rank, world)
+    return stems
+
+
+def train_uc_c(argv=None):
+    """2D VDM conditioned on the six simulation parameters only (/root/reference/train_uc_c_from_field_name.py:50-122): same network
+    as train_uc_uc plus one vector conditioning.  CPU plumbing through the explicit backend='torch'."""
+    from . import data, networks, vdm_model
+    from .trainer import Trainer
+    argv = sys.argv[1:] if argv is None else argv
+    if len(argv) != 1:
+        raise SystemExit("usage: train_uc_c_from_field_name.py <field_name>")
+    field_name = argv[0]
+    _seed_everything(42)
+    cropsize = int(os.environ.get("VDM4CDM_CROPSIZE_2D", 256))
+    batch_size = int(os.environ.get("VDM4CDM_BATCH_2D", 12))
+    dm = data.SyntheticAstroDataModule(cropsize=cropsize, batch_size=batch_size, dim=2, channel_names=[field_name, field_name],
+                                       conditioning=False, n_params=6,
+                                       return_func=lambda fields, params: {"x": fields[1], "conditioning": None, "conditioning_values": [params]})
+    score_model = networks.CUNet(shape=(1, cropsize, cropsize), chs=[48, 96, 192, 384], s_conditioning_channels=0,
+                                 v_conditioning_dims=[6], t_conditioning=True, norm_groups=8, dropout_prob=0.1,
+                                 conv_padding_mode="circular", n_attention_heads=4, backend="torch")
+    vdm = vdm_model.LightVDM(score_model=score_model, gamma_min=-13.3, gamma_max=13.3, noise_schedule="learned_linear",
+                             draw_figure=None)
+    trainer = Trainer(max_steps=int(os.environ.get("VDM4CDM_MAX_STEPS", 1_000_000)), val_check_interval=5000, gradient_clip_val=0.5,
+                      every_n_train_steps=10_000, default_root_dir=os.environ.get("VDM4CDM_LOG_DIR", "./data/logs/vdm4cdm-2D"),
+                      experiment_name=f"LH_uc_c_{field_name}", device="cpu")
+    trainer.fit(model=vdm, datamodule=dm)
+    return trainer
