@@ -84,15 +84,23 @@ SSMK = _ss_mod()
 
 def check_ss_case(case, device):
     """calc_ss.get_stats on `device` against the outputs of the reference's get_pk_3d / get_pk_2d / get_logpdf_3d / get_logpdf_2d
-    (tests/golden/make_ss_golden.py): histogram counts bit-exact, P(k) within 1e-4, moments within 1e-5."""
+    (tests/golden/make_ss_golden.py): histogram counts bit-exact on the CPU; on a GPU the fp32 log10 may differ from the host
+    libm's by one ulp, which can move an element that sits on a bin edge into the neighbouring bin - there the cumulative counts
+    may differ by at most 1e-4 of the elements (and the totals must agree exactly).  P(k) within 1e-4, moments within 1e-5."""
     from vdm4cdm_amd import calc_ss
     name, seed, B, D = case
     f = SSMK.density(seed, B, D).to(device)
     st = calc_ss.get_stats(f, resol=D)
     assert not any("rwst" in k for k in st)
     for key in ("3d", "2d_half", "2d_quarter"):
-        assert np.array_equal(st[f"{key}_logpdf"], SS_GOLD[f"{name}/{key}_logpdf"]), f"{name}/{key}_logpdf"
-        assert st[f"{key}_logpdf"].sum() > 0
+        got, gold = st[f"{key}_logpdf"], SS_GOLD[f"{name}/{key}_logpdf"]
+        if str(device) == "cpu":
+            assert np.array_equal(got, gold), f"{name}/{key}_logpdf"
+        else:
+            assert np.array_equal(got.sum(1), gold.sum(1)), f"{name}/{key}_logpdf totals"
+            slack = max(1, int(1e-4 * gold.sum(1).max()))
+            assert np.abs(np.cumsum(got, 1) - np.cumsum(gold, 1)).max() <= slack, f"{name}/{key}_logpdf"
+        assert got.sum() > 0
         np.testing.assert_allclose(st[f"{key}_pk"], SS_GOLD[f"{name}/{key}_pk"], rtol=1e-4)
         np.testing.assert_allclose([st[f"{key}_mean"], st[f"{key}_std"]], SS_GOLD[f"{name}/{key}_mean"], rtol=1e-5)
 
