@@ -201,7 +201,17 @@ __device__ __forceinline__ void operand_lane_offsets(int (&lanex)[G::KS], int cw
     }
 }
 
-template <int NC> struct WPipe { static constexpr int WPD = (NC <= 2) ? 2 : 1; };   // weight prefetch depth (taps)
+// Weight prefetch depth (taps ahead; ring of WPD + 1 register sets).  The packed weights are L1/L2 hits, but a CU's vector L1
+// returns hits IN ORDER behind the HBM misses of every other wave of the CU (tools/tcp_order_probe.hip: a hit takes 156 cycles
+// on an idle CU and ~1000-1300 while another wave keeps 16 LDS-DMA pieces in flight - which is what the co-resident workgroup
+// does while it stages its halo).  -DVDM_WPD_NC2 / -DVDM_WPD_NC4 override for experiments (make variant).
+#ifndef VDM_WPD_NC2
+#define VDM_WPD_NC2 2
+#endif
+#ifndef VDM_WPD_NC4
+#define VDM_WPD_NC4 1
+#endif
+template <int NC> struct WPipe { static constexpr int WPD = (NC <= 2) ? VDM_WPD_NC2 : VDM_WPD_NC4; };
 
 // bf16: first WPD taps' weights (issued before the staging barrier so their latency overlaps it)
 template <int TAPS, int NC, int WPD, int NCW = NC>
@@ -250,6 +260,67 @@ __device__ __forceinline__ void taps_pipelined(f32x4 (&acc)[NV][NC], const char*
             __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
         }
         __builtin_amdgcn_sched_barrier(0);
+    }
+}
+
+// bf16, 3x3x3 stride 1: the same pipeline with the activation rows kept in registers across the three dy taps.
+// A wave's NV rows are y-consecutive inside one z-slab, so for a fixed (dz, dx) the taps dy = 0, 1, 2 of row v read halo rows
+// v, v+1, v+2: NV + 2 distinct rows instead of 3 * NV operand reads (10 instead of 24 at NV = 8).  The LDS pipe moves 128 B per
+// clock per CU, a 64-lane ds_read_b128 takes 8 of them, and at NC = 2 the plain order needs exactly as many LDS clocks (8 reads x
+// 4 waves x 8) as MFMA clocks (16 MFMAs x 16) per tap - before the LDS-DMA writes of the co-resident workgroup; this order cuts
+// the operand reads 2.4x.  Execution order: group g = (dz, dx), then dy; a row register dies after its dy = 2 use, and the same
+// row of the NEXT group is loaded right there (ring of NV + 2 fragments: 40 VGPRs instead of the 64 of two full sets).
+#ifndef VDM_ROWREUSE
+#define VDM_ROWREUSE 1
+#endif
+__host__ __device__ constexpr int rr_tap(int e) { return ((e / 3) / 3) * 9 + (e % 3) * 3 + ((e / 3) % 3); }     // execution slot -> tap (dz, dy, dx)
+
+template <int NC, int WPD, int NCW = NC>
+__device__ __forceinline__ void rr_prefetch_weights(uint4 (&wf)[WPD + 1][NC], const uint4* wk) {
+#pragma unroll
+    for (int p = 0; p < WPD; ++p)
+#pragma unroll
+        for (int c = 0; c < NC; ++c) wf[p][c] = wk[(rr_tap(p) * NCW + c) * 64];
+}
+
+template <typename T, typename G, int NC, int NV, int WPD, int NCW = NC>
+__device__ __forceinline__ void taps_rowreuse(f32x4 (&acc)[NV][NC], const char* lds, const uint4* wk, uint4 (&wf)[WPD + 1][NC],
+                                              const int (&lanex)[3]) {
+    static_assert(G::KS == 3 && G::STRIDE == 1, "3x3x3 stride-1 geometry");
+    constexpr int NR = NV + 2, HROW = G::HX * 64, HSLAB = G::HY * HROW;
+    uint4 rows[NR];
+#pragma unroll
+    for (int r = 0; r < NR; ++r) rows[r] = *reinterpret_cast<const uint4*>(lds + lanex[0] + r * HROW);
+#pragma unroll
+    for (int e = 0; e < 27; ++e) {
+        const int g = e / 3, dy = e % 3;
+        if (e + WPD < 27) {
+#pragma unroll
+            for (int c = 0; c < NC; ++c) wf[(e + WPD) % (WPD + 1)][c] = wk[(rr_tap(e + WPD) * NCW + c) * 64];
+        }
+        if (dy < 2 || g == 8) {
+#pragma unroll
+            for (int v = 0; v < NV; ++v)
+#pragma unroll
+                for (int c = 0; c < NC; ++c) mma16<T>(acc[v][c], wf[e % (WPD + 1)][c], rows[v + dy]);
+            __builtin_amdgcn_sched_group_barrier(0x20, NC, 0);
+            __builtin_amdgcn_sched_group_barrier(0x8, NV * NC, 0);
+            __builtin_amdgcn_sched_barrier(0);
+        } else {                                           // last use of the rows: refill them for group g + 1 as they die
+            const int g1 = g + 1;
+            const char* nb = lds + lanex[g1 % 3] + (g1 / 3) * HSLAB;
+            __builtin_amdgcn_sched_barrier(0);
+            rows[0] = *reinterpret_cast<const uint4*>(nb);                     // (rows 0 and 1 died with the dy = 1 tap)
+            rows[1] = *reinterpret_cast<const uint4*>(nb + HROW);
+#pragma unroll
+            for (int v = 0; v < NV; ++v) {
+#pragma unroll
+                for (int c = 0; c < NC; ++c) mma16<T>(acc[v][c], wf[e % (WPD + 1)][c], rows[v + 2]);
+                __builtin_amdgcn_sched_barrier(0);
+                rows[v + 2] = *reinterpret_cast<const uint4*>(nb + (v + 2) * HROW);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
     }
 }
 
@@ -752,6 +823,11 @@ static void small_grid_tile(const ConvArgs& a, int& tz, int& ty) {
     const long long per_sample = (long long)a.nchunks * a.N * cdiv(a.Dx, 16);
     const long long tiles48 = per_sample * cdiv(a.Dz, 4) * cdiv(a.Dy, 8), tiles28 = per_sample * cdiv(a.Dz, 2) * cdiv(a.Dy, 8);
     tz = 4; ty = 8;
+    if (const char* f = getenv("VDM4CDM_FORCE_TZ")) {      // experiments: force the z extent of the tile (4 | 2 | 1)
+        tz = atoi(f);
+        if (tz == 1 || tz == 2 || tz == 4) return;
+        tz = 4;
+    }
     if (tiles48 >= 2LL * cu_count()) return;
     tz = 2;
     if (tiles28 >= cu_count()) return;

@@ -62,11 +62,14 @@ __global__ void __launch_bounds__(256, (TZ * TY <= 16 && NC <= 2) ? 3 : 2) conv_
         if constexpr (sizeof(T) == 2) {
             constexpr int WPD = WPipe<NC>::WPD;
             uint4 wf[WPD + 1][NC];
-            taps_prefetch_weights<TAPS, NC, WPD, NCW>(wf, wk);
+            constexpr bool RR = VDM_ROWREUSE && KS == 3 && STRIDE == 1;     // activation rows reused across the dy taps
+            if constexpr (RR) rr_prefetch_weights<NC, WPD, NCW>(wf, wk);
+            else taps_prefetch_weights<TAPS, NC, WPD, NCW>(wf, wk);
             if (kb == 0) VDM_STAMP(1);
             __syncthreads();
             if (kb == 0) VDM_STAMP(2);
-            taps_pipelined<T, G, NC, NV, WPD, NCW>(acc, lds, wk, wf, lanex);
+            if constexpr (RR) taps_rowreuse<T, G, NC, NV, WPD, NCW>(acc, lds, wk, wf, lanex);
+            else taps_pipelined<T, G, NC, NV, WPD, NCW>(acc, lds, wk, wf, lanex);
         } else {
             __syncthreads();
             taps_rolled<T, G, NC, NV>(acc, lds, wk, lanex);
