@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define VDM_ABI_VERSION 4
+#define VDM_ABI_VERSION 5
 
 typedef enum { VDM_OK = 0, VDM_ERR_ARG = -1, VDM_ERR_HIP = -2, VDM_ERR_UNSUPPORTED = -3 } vdm_status;
 typedef enum { VDM_F32 = 0, VDM_BF16 = 1 } vdm_dtype;
@@ -212,12 +212,38 @@ int vdm_diffuse(const float* x, const float* eps, const float* alpha, const floa
 int vdm_loss_terms(const float* x, const float* eps, const float* eps_hat, const float* eps0, float sigma0_over_alpha0,
                    const float* coef, int n, int64_t per, float* sums, float* d_eps_hat, float* workspace, void* stream);
 
+/* ---- data path: crop + log-normalise + flip + permute on the device -----------------------------
+ * Replaces the per-sample CPU DataLoader work of [REF src/dataset/CAMELS_3D_dataset.py:53-73] (AstroDataset.__getitem__) and
+ * [REF src/dataset/augmentation.py:8-127] (Crop, LogTransform, Normalize, Flip, Permutate):
+ *   out[c][b][i0][i1][i2] = (log10(raw + alpha) - mean) / std  of  field[c][sim][(anchor_d + c_d) % fullsize],
+ *   c_d = flip[d] ? crop-1-f_d : f_d,  f[perm[k]] = i_k   (crop -> log/normalise -> flip -> permute, the reference's order).
+ * The two tables are HOST arrays (they travel in the kernel arguments); `field` / `out` inside them are device pointers
+ * (field: [n_sims][fullsize]^3 fp32 raw cubes resident in HBM; out: [n_samples][crop]^3 fp32).  n_channels <= 4. */
+typedef struct {
+    const float* field;
+    float* out;
+    float alpha, mean, std; /* [REF src/dataset/alphas_3d.json, normalizations_3d.json] */
+} vdm_augment_channel;
+typedef struct {
+    int32_t sim;       /* simulation index into `field` */
+    int32_t anchor[3]; /* crop origin incl. the random shift (may exceed fullsize: wrapped) [REF augmentation.py:113-117] */
+    int32_t flip[3];   /* != 0: flip this axis [REF augmentation.py:51-52] */
+    int32_t perm[3];   /* axis permutation [REF augmentation.py:72] */
+} vdm_augment_sample;
+int vdm_augment_batch(const vdm_augment_channel* host_channels, int n_channels, int fullsize, int crop,
+                      const vdm_augment_sample* host_samples, int n_samples, void* stream);
+
 /* ---- K9: ancestral update [NB vdm_model.py:370-378] ----------------------------------------
  * z <- ratio*(z - c_sigma_t*eps_hat) + scale*noise ; the four scalars are read from the DEVICE table
  * coef[step][4] = {ratio, c*sigma_t, scale, t_norm} at row *step_ptr (so one captured graph serves
  * every step).  noise==NULL: Philox normal from (seed, *step_ptr, element index). */
 int vdm_ancestral_step(float* z, const float* eps_hat, const float* noise, const float* coef, const int32_t* step_ptr,
                        uint64_t seed, int64_t n, void* stream);
+/* The same update under classifier-free guidance [NB vdm_model.py:318-327, the `w_cfg` branch of VDM.get_pred_noise]:
+ * eps_hat = (1 + w_cfg) * eps_cond - w_cfg * eps_uncond, blended inside the update (eps_cond / eps_uncond are the two halves of
+ * one batch-doubled UNet forward: given v_conditionings / masked v_conditionings). */
+int vdm_ancestral_step_cfg(float* z, const float* eps_cond, const float* eps_uncond, float w_cfg, const float* noise,
+                           const float* coef, const int32_t* step_ptr, uint64_t seed, int64_t n, void* stream);
 /* standard-normal fill from Philox(seed, stream_id) (z_1 of the sampler; eps in training). */
 int vdm_randn(float* out, int64_t n, uint64_t seed, uint64_t stream_id, void* stream);
 /* *step_ptr += 1 (device-side step counter for the captured sampler graph). */

@@ -88,6 +88,18 @@ def vdm_loss(score_fn, sched, x, times, eps, eps0):
     return out
 
 
+def cfg_score_fn(score_fn_v, v_conditionings, w_cfg):
+    """Classifier-free guidance (notebook traceback ``vdm_model.py:318-327``: ``if self.w_cfg is None or self.training`` -> plain
+    call; else ``assert "v_conditionings" in kwargs, "Need v_conditionings to mask out"``).  The blend itself is not in the
+    reference tree; [INFERRED] the standard form  eps = (1 + w) * eps(v) - w * eps(masked v)  with masked v = zeros.
+    score_fn_v(z, t_norm, v_list) -> eps_hat."""
+    masked = [torch.zeros_like(v) for v in v_conditionings]
+
+    def score(z, t_norm):
+        return (1.0 + w_cfg) * score_fn_v(z, t_norm, v_conditionings) - w_cfg * score_fn_v(z, t_norm, masked)
+    return score
+
+
 def step_coeffs(sched, t, s):
     """Scalars of one ancestral step t -> s (D12).  c = -expm1(gamma_s-gamma_t)."""
     g_t, g_s = sched.gamma(t), sched.gamma(s)

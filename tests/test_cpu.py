@@ -118,6 +118,41 @@ def test_torch_backend_matches_oracle(shape, chs, pm, sc, vd):
     assert (y - ref).abs().max().item() < 1e-5
 
 
+def test_cfg_pred_noise_and_sampler_on_torch_backend():
+    """R10 on the explicit torch backend (C1 plumbing): `w_cfg` blends the given-v and masked-v estimates of one batch-doubled
+    forward; off in training mode; the eager sampler follows the oracle's guided chain."""
+    from oracle import unet_oracle, vdm_oracle
+    from vdm4cdm_amd.networks import CUNet
+    from vdm4cdm_amd.vdm_model import LightVDM
+    shape = (1, 8, 8, 8)
+    net = CUNet(shape=shape, chs=[8, 16], s_conditioning_channels=1, v_conditioning_dims=[6], norm_groups=4, backend="torch")
+    vdm = LightVDM(score_model=randomize(net, 5), gamma_max=13.3, w_cfg=1.5).eval()
+    assert vdm.model.w_cfg == 1.5
+    g = torch.Generator().manual_seed(1)
+    B, n = 2, 6
+    z1, s = torch.randn(B, *shape, generator=g), torch.randn(B, *shape, generator=g)
+    v = [torch.rand(B, 6, generator=g)]
+    noises = [torch.randn(B, *shape, generator=g) for _ in range(n)]
+    P = oracle_params(net)
+    score_v = lambda z, tn, vv: unet_oracle.cunet_forward(P, oracle_cfg(net), z, tn, s, vv)
+    guided = vdm_oracle.cfg_score_fn(score_v, v, 1.5)
+    with torch.no_grad():
+        out = vdm.draw_samples(batch_size=B, n_sampling_steps=n, z=z1.clone(), noises=noises, s_conditioning=s, v_conditionings=v)
+        ref = vdm_oracle.sample(guided, vdm_oracle.Schedule(-13.3, 13.3), z1.clone(), n, noises)
+        assert (out - ref).abs().max().item() <= 2e-5 * ref.abs().max().item() + 1e-4
+        g_t = vdm.model.gamma(torch.tensor(0.4))
+        tn = torch.full((B,), 0.4)
+        e = vdm.model.get_pred_noise(z1, g_t, s_conditioning=s, v_conditionings=v)
+        assert (e - guided(z1, tn)).abs().max().item() < 1e-4
+        vdm.train()
+        e_tr = vdm.model.get_pred_noise(z1, g_t, s_conditioning=s, v_conditionings=v)
+        net.eval()                                             # (dropout off for the comparison; vdm.model stays in training mode)
+        e_tr = vdm.model.get_pred_noise(z1, g_t, s_conditioning=s, v_conditionings=v)
+        assert vdm.model.training and (e_tr - score_v(z1, tn, v)).abs().max().item() < 1e-4
+    with pytest.raises(AssertionError, match="mask out"):
+        vdm.eval().model.get_pred_noise(z1, g_t, s_conditioning=s)
+
+
 def test_param_count_and_state_dict_roundtrip(tmp_path):
     from vdm4cdm_amd.networks import CUNet
     from vdm4cdm_amd.vdm_model import LightVDM
@@ -220,7 +255,7 @@ def test_cabi_exports_every_declared_symbol(hip_lib):
     for name in sorted(declared):
         assert hasattr(hip_lib, name), f"libvdm4cdm_hip.so does not export {name}"
     assert declared == set(_lib.SIGNATURES), f"ctypes table out of sync: {declared ^ set(_lib.SIGNATURES)}"
-    assert hip_lib.vdm_abi_version() == 4
+    assert hip_lib.vdm_abi_version() == _lib.ABI_VERSION == int(re.search(r"#define VDM_ABI_VERSION (\d+)", header).group(1))
 
 
 def test_cabi_argument_errors_do_not_need_a_gpu(hip_lib):

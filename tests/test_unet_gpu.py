@@ -235,6 +235,45 @@ def test_sampler_matches_oracle(use_graph):
     assert err <= 2e-5 * ref.abs().max().item() + 1e-3, f"sampler err {err} (max|ref| {ref.abs().max().item()})"
 
 
+@pytest.mark.parametrize("use_graph", [False, True], ids=["eager", "hipgraph"])
+def test_cfg_sampler_matches_oracle(use_graph):
+    """R10: classifier-free guidance (w_cfg) - the HIP sampler runs ONE batch-doubled UNet forward per step (given / masked
+    v_conditionings) and blends the two estimates inside the K9 update; vs the oracle chain with two oracle UNet calls per step.
+    Same tolerance as test_sampler_matches_oracle; also w_cfg = 0 must reproduce the unguided chain bit for bit."""
+    from oracle import unet_oracle, vdm_oracle
+    net = make_net(precision="fp32", **CFGS[0])
+    vdm = make_vdm(net).to(DEV).eval()
+    B, n, w = 1, 12, 0.7
+    x, _, s, v = inputs(net, B)
+    z1 = grf(x.shape, 61, slope=0.0)
+    noises = [grf(x.shape, 300 + i, slope=0.0) for i in range(n)]
+    kw = dict(s_conditioning=s.to(DEV), v_conditionings=[a.to(DEV) for a in v])
+    plain = vdm.draw_samples(batch_size=B, n_sampling_steps=n, z=z1.clone(), noises=noises, use_graph=use_graph, **kw).cpu()
+    vdm.model.w_cfg = 0.0
+    out0 = vdm.draw_samples(batch_size=B, n_sampling_steps=n, z=z1.clone(), noises=noises, use_graph=use_graph, **kw).cpu()
+    assert (out0 - plain).abs().max().item() <= 1e-5 * plain.abs().max().item(), "w_cfg = 0 differs from the unguided chain"
+    vdm.model.w_cfg = w
+    out = vdm.draw_samples(batch_size=B, n_sampling_steps=n, z=z1.clone(), noises=noises, use_graph=use_graph, **kw).cpu()
+    P = oracle_params(net)
+    score_v = lambda z, tn, vv: unet_oracle.cunet_forward(P, oracle_cfg(net), z, tn, s, vv)
+    ref = vdm_oracle.sample(vdm_oracle.cfg_score_fn(score_v, v, w), vdm_oracle.Schedule(-13.3, 13.3), z1.clone(), n, noises)
+    err = (out - ref).abs().max().item()
+    assert (ref - plain).abs().max().item() > 1e-2 * ref.abs().max().item(), "guidance had no effect: the test would be vacuous"
+    assert err <= 2e-5 * ref.abs().max().item() + 1e-3, f"CFG sampler err {err} (max|ref| {ref.abs().max().item()})"
+    # eager get_pred_noise (DDNM / sample_zs_given_zt callers) takes the same branch
+    with torch.no_grad():
+        g_t = vdm.model.gamma(torch.tensor(0.6, device=DEV))
+        e = vdm.model.get_pred_noise(z1.to(DEV), g_t, **kw).cpu()
+    tn = torch.full((B,), float((g_t.item() + 13.3) / 26.6))
+    e_ref = vdm_oracle.cfg_score_fn(score_v, v, w)(z1, tn)
+    assert (e - e_ref).abs().max().item() <= 1e-4 * e_ref.abs().max().item() + 1e-5
+    vdm.train()                                              # "or self.training": guidance is off in training mode
+    with torch.no_grad():
+        e_tr = vdm.model.get_pred_noise(z1.to(DEV), g_t, **kw).cpu()
+    e_plain = score_v(z1, tn, v)
+    assert (e_tr - e_plain).abs().max().item() <= 1e-4 * e_plain.abs().max().item() + 1e-5
+
+
 def test_sampler_identity_T2_and_api():
     """T2: mean form == DDNM form; reference call signatures (src/utils.py:294-299) work on the HIP model."""
     net = make_net(precision="fp32", **CFGS[0])

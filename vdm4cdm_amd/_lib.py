@@ -51,10 +51,20 @@ class CondMlp(C.Structure):
                 ("dw1", C.c_void_p), ("db1", C.c_void_p), ("dw2", C.c_void_p), ("db2", C.c_void_p), ("dwproj", C.c_void_p)]
 
 
+class AugmentChannel(C.Structure):
+    """vdm_augment_channel"""
+    _fields_ = [("field", C.c_void_p), ("out", C.c_void_p), ("alpha", C.c_float), ("mean", C.c_float), ("std", C.c_float)]
+
+
+class AugmentSample(C.Structure):
+    """vdm_augment_sample"""
+    _fields_ = [("sim", C.c_int32), ("anchor", C.c_int32 * 3), ("flip", C.c_int32 * 3), ("perm", C.c_int32 * 3)]
+
+
 PACK_CHUNK = 16384                   # VDM_PACK_CHUNK
 _p, _i, _i64, _u64, _f, _sz = C.c_void_p, C.c_int, C.c_int64, C.c_uint64, C.c_float, C.c_size_t
 _D = C.POINTER(ConvDesc)
-ABI_VERSION = 4                      # VDM_ABI_VERSION of include/vdm4cdm_hip.h this binding was written for
+ABI_VERSION = 5                      # VDM_ABI_VERSION of include/vdm4cdm_hip.h this binding was written for
 
 # name -> (restype, argtypes); mirrors include/vdm4cdm_hip.h one to one
 SIGNATURES = {
@@ -83,9 +93,11 @@ SIGNATURES = {
     "vdm_cond_table_fwd": (_i, [C.POINTER(CondMlp), _i, _i, _i, _p, _p, _p]),
     "vdm_cond_table_bwd": (_i, [C.POINTER(CondMlp), _i, _i, _i, _p, _i64, _p, _p, _p, _p]),
     "vdm_cond_table_step": (_i, [_p, _p, _p, _i, _i, _p, _p]),
+    "vdm_augment_batch": (_i, [C.POINTER(AugmentChannel), _i, _i, _i, C.POINTER(AugmentSample), _i, _p]),
     "vdm_diffuse": (_i, [_p, _p, _p, _p, _i, _i64, _p, _p]),
     "vdm_loss_terms": (_i, [_p, _p, _p, _p, _f, _p, _i, _i64, _p, _p, _p, _p]),
     "vdm_ancestral_step": (_i, [_p, _p, _p, _p, _p, _u64, _i64, _p]),
+    "vdm_ancestral_step_cfg": (_i, [_p, _p, _p, _f, _p, _p, _p, _u64, _i64, _p]),
     "vdm_randn": (_i, [_p, _i64, _u64, _u64, _p]),
     "vdm_step_inc": (_i, [_p, _p]),
     "vdm_sumsq": (_i, [_p, _i64, _p, _p, _p]),

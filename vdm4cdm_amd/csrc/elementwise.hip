@@ -677,7 +677,10 @@ __global__ void __launch_bounds__(256) randn_kernel(float* __restrict__ out, int
     }
 }
 
+// eu != NULL: classifier-free guidance - the noise estimate is (1 + w) * eh - w * eu (conditional / v-masked UNet outputs, the two
+// halves of one batch-doubled forward), blended here so that the guided estimate never exists in memory.
 __global__ void __launch_bounds__(256) ancestral_kernel(float* __restrict__ z, const float* __restrict__ eh,
+                                                       const float* __restrict__ eu, float w,
                                                        const float* __restrict__ noise, const float* __restrict__ coef,
                                                        const int32_t* __restrict__ step_ptr, uint64_t seed, int64_t n) {
     const int step = *step_ptr;
@@ -693,7 +696,10 @@ __global__ void __launch_bounds__(256) ancestral_kernel(float* __restrict__ z, c
         }
         for (int j = 0; j < 4; ++j) {
             const int64_t k = i * 4 + j;
-            if (k < n) z[k] = ratio * (z[k] - cs * eh[k]) + scale * nz[j];
+            if (k < n) {
+                const float e = eu ? (1.f + w) * eh[k] - w * eu[k] : eh[k];
+                z[k] = ratio * (z[k] - cs * e) + scale * nz[j];
+            }
         }
     }
 }
@@ -910,8 +916,18 @@ extern "C" int vdm_loss_terms(const float* x, const float* eps, const float* eps
 extern "C" int vdm_ancestral_step(float* z, const float* eps_hat, const float* noise, const float* coef, const int32_t* step_ptr,
                                   uint64_t seed, int64_t n, void* stream) {
     VDM_REQUIRE(z && eps_hat && coef && step_ptr && n > 0, "ancestral_step: bad arguments");
-    hipLaunchKernelGGL(ancestral_kernel, dim3(grid_for(n, 256 * 8)), dim3(256), 0, (hipStream_t)stream, z, eps_hat, noise, coef, step_ptr, seed, n);
+    hipLaunchKernelGGL(ancestral_kernel, dim3(grid_for(n, 256 * 8)), dim3(256), 0, (hipStream_t)stream, z, eps_hat, (const float*)nullptr, 0.f,
+                       noise, coef, step_ptr, seed, n);
     VDM_LAUNCH_CHECK("ancestral_kernel");
+    return VDM_OK;
+}
+
+extern "C" int vdm_ancestral_step_cfg(float* z, const float* eps_cond, const float* eps_uncond, float w_cfg, const float* noise,
+                                      const float* coef, const int32_t* step_ptr, uint64_t seed, int64_t n, void* stream) {
+    VDM_REQUIRE(z && eps_cond && eps_uncond && coef && step_ptr && n > 0, "ancestral_step_cfg: bad arguments");
+    hipLaunchKernelGGL(ancestral_kernel, dim3(grid_for(n, 256 * 8)), dim3(256), 0, (hipStream_t)stream, z, eps_cond, eps_uncond, w_cfg,
+                       noise, coef, step_ptr, seed, n);
+    VDM_LAUNCH_CHECK("ancestral_kernel(cfg)");
     return VDM_OK;
 }
 

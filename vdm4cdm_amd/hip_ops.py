@@ -472,6 +472,33 @@ def cond_table_step(table_t, table_v, step_ptr, rows, width, out):
     return out
 
 
+def augment_batch(fields, consts, samples, crop, out=None):
+    """Data path on the device (vdm_augment_batch): fields = per-channel raw cube stacks [n_sims, S, S, S] fp32 on the GPU, consts =
+    per-channel (alpha, mean, std), samples = list of (sim, anchor[3], flip[3], perm[3]).  Returns the per-channel batches
+    [B, 1, crop, crop, crop] fp32: periodic crop at the anchor -> (log10(x + alpha) - mean) / std -> flips -> axis permutation."""
+    L = _lib.lib()
+    C_, B = len(fields), len(samples)
+    S = fields[0].shape[-1]
+    for f in fields:
+        assert f.is_cuda and f.dtype == torch.float32 and f.is_contiguous() and f.dim() == 4 and tuple(f.shape[1:]) == (S, S, S), \
+            "raw fields must be contiguous fp32 [n_sims, S, S, S] tensors on the GPU"
+    nsim = min(f.shape[0] for f in fields)
+    if out is None:
+        out = [torch.empty(B, 1, crop, crop, crop, device=fields[0].device) for _ in range(C_)]
+    ch = (_lib.AugmentChannel * C_)()
+    for c, (f, (alpha, mean, std)) in enumerate(zip(fields, consts)):
+        _contig(out[c])
+        ch[c].field, ch[c].out, ch[c].alpha, ch[c].mean, ch[c].std = f.data_ptr(), out[c].data_ptr(), float(alpha), float(mean), float(std)
+    tab = (_lib.AugmentSample * B)()
+    for b, (sim, anchor, flip, perm) in enumerate(samples):
+        assert 0 <= int(sim) < nsim, f"simulation index {sim} out of range (0..{nsim - 1})"
+        tab[b].sim = int(sim)
+        for d in range(3):
+            tab[b].anchor[d], tab[b].flip[d], tab[b].perm[d] = int(anchor[d]), int(bool(flip[d])), int(perm[d])
+    check(L.vdm_augment_batch(ch, C_, int(S), int(crop), tab, B, _s()), "vdm_augment_batch")
+    return out
+
+
 def diffuse(x, eps, alpha, sigma, out=None):
     L = _lib.lib()
     _contig(x, eps, alpha, sigma)
@@ -502,11 +529,17 @@ def loss_terms(x, eps, eps_hat, eps0, sigma0_over_alpha0, coef, sums, d_eps_hat)
                            _p(sums), _p(d_eps_hat), _p(_reduce_ws(x.device)), _s()), "vdm_loss_terms")
 
 
-def ancestral_step(z, eps_hat, noise, coef, step_ptr, seed):
+def ancestral_step(z, eps_hat, noise, coef, step_ptr, seed, eps_uncond=None, w_cfg=0.0):
+    """K9.  eps_uncond given: classifier-free guidance, (1 + w_cfg) * eps_hat - w_cfg * eps_uncond blended inside the update."""
     L = _lib.lib()
-    _contig(z, eps_hat, noise, coef)
-    check(L.vdm_ancestral_step(_p(z), _p(eps_hat), _p(noise), _p(coef), _p(step_ptr), int(seed), z.numel(), _s()),
-          "vdm_ancestral_step")
+    _contig(z, eps_hat, noise, coef, eps_uncond)
+    if eps_uncond is None:
+        check(L.vdm_ancestral_step(_p(z), _p(eps_hat), _p(noise), _p(coef), _p(step_ptr), int(seed), z.numel(), _s()),
+              "vdm_ancestral_step")
+    else:
+        assert eps_uncond.shape == eps_hat.shape == z.shape and eps_uncond.dtype == torch.float32
+        check(L.vdm_ancestral_step_cfg(_p(z), _p(eps_hat), _p(eps_uncond), float(w_cfg), _p(noise), _p(coef), _p(step_ptr), int(seed),
+                                       z.numel(), _s()), "vdm_ancestral_step_cfg")
 
 
 def randn(out, seed, stream_id=0):

@@ -83,10 +83,33 @@ class VDM(nn.Module):
     # ---------------------------------------------------------------- score
     def get_pred_noise(self, zt, gamma_t, **kwargs):
         """notebook frame vdm_model.py:309-327."""
+        t = (gamma_t - self.gamma_min) / (self.gamma_max - self.gamma_min)
         if self.w_cfg is None or self.training:
-            return self.score_model(zt, t=(gamma_t - self.gamma_min) / (self.gamma_max - self.gamma_min), **kwargs)
-        raise NotImplementedError("classifier-free guidance (w_cfg) is a 'next' row of SURVEY.md section 8f; every "
-                                  "script in the reference runs with w_cfg=None")
+            return self.score_model(zt, t=t, **kwargs)
+        eps_c, eps_u = self._cfg_pair(zt, t, kwargs)
+        return (1.0 + self.w_cfg) * eps_c - self.w_cfg * eps_u
+
+    @staticmethod
+    def cfg_mask(v_conditionings):
+        """The "masked out" vector conditionings of the unguided branch (frame vdm_model.py:327: "Need v_conditionings to mask out";
+        the masking value is not in the reference tree - [INFERRED] zeros, the usual null token of a vector conditioning)."""
+        return [torch.zeros_like(v) for v in v_conditionings]
+
+    def _cfg_pair(self, zt, t, kwargs):
+        """Classifier-free guidance (notebook frame vdm_model.py:318-327): conditional and v-masked noise estimates from ONE
+        batch-doubled UNet forward (rows 0..B-1 with the given v_conditionings, rows B..2B-1 with them masked)."""
+        assert "v_conditionings" in kwargs, "Need v_conditionings to mask out"
+        B = zt.shape[0]
+        vs = [v.to(zt.device).expand(B, *v.shape[1:]) if v.shape[0] != B else v.to(zt.device) for v in kwargs["v_conditionings"]]
+        kw = dict(kwargs)
+        kw["v_conditionings"] = [torch.cat([v, m], dim=0) for v, m in zip(vs, self.cfg_mask(vs))]
+        if kw.get("s_conditioning") is not None:
+            sc = kw["s_conditioning"]
+            sc = sc.expand(B, *sc.shape[1:]) if sc.shape[0] != B else sc
+            kw["s_conditioning"] = torch.cat([sc, sc], dim=0)
+        t2 = torch.cat([t.expand(B), t.expand(B)]) if torch.is_tensor(t) else t
+        eps = self.score_model(torch.cat([zt, zt], dim=0), t=t2, **kw)
+        return eps[:B], eps[B:]
 
     # ---------------------------------------------------------------- loss (D10)
     @staticmethod
@@ -260,17 +283,32 @@ class VDM(nn.Module):
             if net.t_conditioning:
                 table_t = ops.CondTable(net.cond_specs(coef[:, 3].contiguous(), None, fl, which="t"), n, W).forward(save=False)
             vs = [v.to(device=dev, dtype=torch.float32).expand(B, -1).contiguous() for v in list(kwargs.get("v_conditionings") or [])]
+            cfg = self.w_cfg is not None and not self.training
+            if cfg:                                            # guided + v-masked rows of one batch-doubled forward (see _cfg_pair)
+                assert "v_conditionings" in kwargs, "Need v_conditionings to mask out"
+                vs = [torch.cat([v, m], dim=0).contiguous() for v, m in zip(vs, self.cfg_mask(vs))]
+            R = 2 * B if cfg else B                            # rows the UNet sees
             if vs:
-                table_v = ops.CondTable(net.cond_specs(None, vs, fl, which="v"), B, W).forward(save=False)
+                table_v = ops.CondTable(net.cond_specs(None, vs, fl, which="v"), R, W).forward(save=False)
         s_cond = kwargs.get("s_conditioning")
-        table = torch.zeros(B, W, device=dev)
+        if cfg and s_cond is not None:
+            s_cond = s_cond.to(dev).expand(B, *s_cond.shape[1:])
+            s_cond = torch.cat([s_cond, s_cond], dim=0).contiguous()
+        table = torch.zeros(R, W, device=dev)
+        zz = torch.empty(R, *z.shape[1:], device=dev) if cfg else z
         from .unet_hip import hip_unet_apply
 
         def one_step():
             if table_t is not None or table_v is not None:
-                ops.cond_table_step(table_t, table_v, step, B, W, table)
-            eps_hat = hip_unet_apply(net, z, s_cond, table=table)
-            ops.ancestral_step(z, eps_hat.contiguous(), noise_buf, coef, step, seed)
+                ops.cond_table_step(table_t, table_v, step, R, W, table)
+            if cfg:
+                zz[:B].copy_(z)
+                zz[B:].copy_(z)
+            eps_hat = hip_unet_apply(net, zz, s_cond, table=table).contiguous()
+            if cfg:                                            # blend inside K9: the guided estimate is never materialised
+                ops.ancestral_step(z, eps_hat[:B], noise_buf, coef, step, seed, eps_uncond=eps_hat[B:], w_cfg=float(self.w_cfg))
+            else:
+                ops.ancestral_step(z, eps_hat, noise_buf, coef, step, seed)
             ops.step_inc(step)
 
         graph = None
