@@ -146,11 +146,12 @@ int vdm_gn_stats(const void* x1, int c1, const void* x2, int c2, int n, int64_t 
                  int dtype, float* stats, float* workspace, const float* part1, int tiles1, const float* part2, int tiles2,
                  float* chsum, void* stream);
 /* y[n][v][c1+c2] = dropout(silu(gn(concat(x1,x2)))) ; keep-mask from Philox(seed, element index).
+ * linear != 0: no activation - the plain GroupNorm in front of the attention block's qkv projection (mid_attn=True).
  * keep_mask (may be NULL): with dropout_p > 0 the keep bits are also written, one byte per 16-byte piece of y
  * ([n][voxels][(c1+c2) / (4 fp32 | 8 bf16)], bit j = channel j of the piece), for vdm_conv_dgrad_gn. */
 int vdm_gn_silu_fwd(const void* x1, int c1, const void* x2, int c2, int n, int64_t voxels, int groups,
                     int dtype, const float* stats, const float* gamma, const float* beta, float eps,
-                    float dropout_p, uint64_t seed, void* y, uint8_t* keep_mask, void* stream);
+                    float dropout_p, uint64_t seed, void* y, uint8_t* keep_mask, int linear, void* stream);
 /* Backward of the above.  dy is the gradient w.r.t. y.  Writes dx1 (and dx2), ADDS into
  * dgamma/dbeta [c] (caller zeroes); optional add1 / add2 (shaped like x1 / x2) are added to dx1 / dx2
  * (residual-path gradients); optional colsum[n*colsum_stride + c] += sum_v dx (caller zeroes; bias and
@@ -159,7 +160,7 @@ int vdm_gn_silu_bwd(const void* x1, int c1, const void* x2, int c2, int n, int64
                     int dtype, const float* stats, const float* gamma, const float* beta, float eps,
                     float dropout_p, uint64_t seed, const void* dy, const void* add1, const void* add2, void* dx1,
                     void* dx2, float* dgamma, float* dbeta, float* colsum, int64_t colsum_stride, float* red_ws,
-                    void* stream);
+                    int linear, void* stream);
 
 /* Second half of the GroupNorm backward after vdm_conv_dgrad_gn (all in fixed summation order: bit-reproducible).
  * finalize: chan[n][c][2] = sum over tiles of the partials; red[n][g][2] = sum_c gamma_c chan[n][c];
@@ -232,6 +233,15 @@ typedef struct {
 } vdm_augment_sample;
 int vdm_augment_batch(const vdm_augment_channel* host_channels, int n_channels, int fullsize, int crop,
                       const vdm_augment_sample* host_samples, int n_samples, void* stream);
+
+/* ---- attention block of the mid level (CUNet(mid_attn=True, n_attention_heads)) [REF trainSFM_c_uc_from_field_name.py:61,104-118;
+ * NB blocks.py:169-170 `x = self.attention_blocks[i](x)`] ---------------------------------------------------------------------
+ * scores[rows][cols] (fp32, in place) <- softmax over each row of scale * scores; the backward turns dprobs (in place) into the
+ * gradient w.r.t. the un-scaled scores: scale * p * (dp - sum_j dp_j p_j).  The batched GEMMs around them are library GEMMs. */
+int vdm_softmax_rows(float* scores, int64_t rows, int cols, float scale, void* stream);
+int vdm_softmax_rows_bwd(const float* probs, float* dprobs, int64_t rows, int cols, float scale, void* stream);
+/* out[c] = sum over rows of x[row][c] (x: [rows][c] in `dtype`): bias gradients of the block's two 1x1x1 projections. */
+int vdm_channel_sums(const void* x, int64_t rows, int c, int dtype, float* out, void* stream);
 
 /* ---- K9: ancestral update [NB vdm_model.py:370-378] ----------------------------------------
  * z <- ratio*(z - c_sigma_t*eps_hat) + scale*noise ; the four scalars are read from the DEVICE table

@@ -70,6 +70,23 @@ def resnet_block(p, prefix, x, conds, groups, padding_mode, drop_mask=None):
     return x + h
 
 
+def attention_block(p, prefix, x, groups, heads):
+    """D13 [INFERRED] - the mid-level self-attention of ``mid_attn=True`` (kwargs ``mid_attn`` / ``n_attention_heads``:
+    /root/reference/trainVDM3D128_c_c_from_field_name_thick_lowbatch.py:62-63,123-126; enabled by
+    /root/reference/trainSFM_c_uc_from_field_name.py:61; call order ``x = resnet_block(x, ...); x = self.attention_blocks[i](x)``
+    from the traceback frame ``blocks.py:168-170``).  The block itself is not in the reference tree; the DDPM / VDM-lineage form:
+    GroupNorm -> 1^dim conv to q, k, v (channels [C | C | C], each split into `heads` heads of C / heads) -> softmax(q k^T /
+    sqrt(C / heads)) v over all voxels -> 1^dim projection (zero-init) -> residual add."""
+    N, C = x.shape[:2]
+    sp = x.shape[2:]
+    h = F.group_norm(x, groups, p[prefix + ".norm.weight"], p[prefix + ".norm.bias"], GN_EPS)
+    qkv = _conv(h, p[prefix + ".qkv.weight"], p[prefix + ".qkv.bias"], "zeros").reshape(N, 3, heads, C // heads, -1)
+    q, k, v = qkv[:, 0], qkv[:, 1], qkv[:, 2]                                     # [N, heads, hd, V]
+    w = torch.softmax(torch.einsum("nhdi,nhdj->nhij", q, k) / math.sqrt(C // heads), dim=-1)
+    a = torch.einsum("nhij,nhdj->nhdi", w, v).reshape(N, C, *sp)
+    return x + _conv(a, p[prefix + ".proj.weight"], p[prefix + ".proj.bias"], "zeros")
+
+
 def cunet_forward(p, cfg, x, t, s_conditioning=None, v_conditionings=(), drop_masks=None,
                   taps=None):
     """eps_hat = CUNet(concat(x, s_conditioning); t, v).  D1-D8.
@@ -103,6 +120,8 @@ def cunet_forward(p, cfg, x, t, s_conditioning=None, v_conditionings=(), drop_ma
             h = _conv(h, p[f"downs.{i}.down.weight"], p[f"downs.{i}.down.bias"], pm, stride=2)  # D5
     for j in range(2):
         h = resnet_block(p, f"mid.{j}", h, conds, G, pm, dm.get(f"mid.{j}"))
+        if j == 0 and "mid_attn.qkv.weight" in p:                                 # D13: [ResNetBlock, Attention, ResNetBlock]
+            h = attention_block(p, "mid_attn", h, G, cfg.get("n_attention_heads", 4))
     if taps is not None:
         taps["mid"] = h
     for i in reversed(range(L - 1)):

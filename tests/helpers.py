@@ -16,7 +16,8 @@ def oracle_params(net, flat=None):
     for name, v in views.items():
         if name.endswith("skip2.weight"):
             continue
-        if name.endswith(".weight") and v.dim() == 3 and ("conv" in name or "skip" in name or ".down." in name or ".up." in name):
+        if name.endswith(".weight") and v.dim() == 3 and ("conv" in name or "skip" in name or ".down." in name or ".up." in name
+                                                          or ".qkv." in name or ".proj." in name):
             if name.endswith("skip.weight") and name.replace("skip.weight", "skip2.weight") in views:
                 v = torch.cat([v, views[name.replace("skip.weight", "skip2.weight")]], dim=2)
             taps, cout, cin = v.shape
@@ -27,7 +28,8 @@ def oracle_params(net, flat=None):
 
 
 def oracle_cfg(net):
-    return {"chs": net.chs, "norm_groups": net.norm_groups, "padding_mode": net.conv_padding_mode}
+    return {"chs": net.chs, "norm_groups": net.norm_groups, "padding_mode": net.conv_padding_mode,
+            "n_attention_heads": net.n_attention_heads}
 
 
 def randomize(net, seed=0, zero_init_std=0.05):

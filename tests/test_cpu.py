@@ -153,6 +153,64 @@ def test_cfg_pred_noise_and_sampler_on_torch_backend():
         vdm.eval().model.get_pred_noise(z1, g_t, s_conditioning=s)
 
 
+@pytest.mark.parametrize("shape", [(1, 16, 16), (1, 8, 8, 8)], ids=["2d", "3d"])
+def test_mid_attention_torch_backend_matches_oracle(shape):
+    """mid_attn=True (spec D13) on the explicit torch backend vs the oracle's attention block; the block is live."""
+    from oracle import unet_oracle
+    from vdm4cdm_amd.networks import CUNet
+    net = CUNet(shape=shape, chs=[8, 16], s_conditioning_channels=1, v_conditioning_dims=[6], norm_groups=4, mid_attn=True,
+                n_attention_heads=4, backend="torch")
+    randomize(net, 1).eval()
+    g = torch.Generator().manual_seed(0)
+    x, t, s, v = torch.randn(2, *shape, generator=g), torch.rand(2, generator=g), torch.randn(2, *shape, generator=g), [torch.randn(2, 6, generator=g)]
+    with torch.no_grad():
+        y = net(x, t=t, s_conditioning=s, v_conditionings=v)
+        P = oracle_params(net)
+        ref = unet_oracle.cunet_forward(P, oracle_cfg(net), x, t, s, v)
+        ref_no = unet_oracle.cunet_forward({k: a for k, a in P.items() if not k.startswith("mid_attn")}, oracle_cfg(net), x, t, s, v)
+    assert (y - ref).abs().max().item() < 1e-5
+    assert (ref - ref_no).abs().max().item() > 1e-3
+
+
+def test_sfm_torch_backend_matches_oracle_and_2d_script_runs(tmp_path):
+    """SFM (spec D14) on the torch backend: loss and Euler sampler vs oracle/sfm_oracle.py; the 2D reference script
+    trainSFM_c_uc_from_field_name.py (mid_attn=True) runs end to end on a shrunk CPU configuration."""
+    from oracle import sfm_oracle, unet_oracle
+    from vdm4cdm_amd.networks import CUNet
+    from vdm4cdm_amd.sfm_model import LightSFM
+    shape = (1, 8, 8, 8)
+    net = CUNet(shape=shape, chs=[8, 16], s_conditioning_channels=1, v_conditioning_dims=[6], norm_groups=4, backend="torch")
+    sfm = LightSFM(velocity_model=randomize(net, 2), learning_rate=1e-3).eval()
+    g = torch.Generator().manual_seed(4)
+    B = 2
+    x0, x1 = torch.randn(B, *shape, generator=g), torch.randn(B, *shape, generator=g)
+    v = [torch.rand(B, 6, generator=g)]
+    times = torch.tensor([0.2, 0.7])
+    P = oracle_params(net)
+    vel = lambda xt, t, x0_: unet_oracle.cunet_forward(P, oracle_cfg(net), xt, t, x0_, v)
+    with torch.no_grad():
+        loss, _ = sfm.model.get_loss(x0=x0, x1=x1, times=times, v_conditionings=v)
+        ref, _, _ = sfm_oracle.sfm_loss(vel, x0, x1, times)
+        assert loss.item() == pytest.approx(ref.item(), rel=1e-5)
+        out = sfm.draw_samples(x0=x0, n_sampling_steps=5, v_conditionings=v)
+        assert (out - sfm_oracle.sfm_sample(vel, x0, 5)).abs().max().item() < 1e-4
+    batch = {"x0": x0, "x1": x1, "conditioning_values": v}
+    sfm.train()
+    l0 = sfm.training_step(batch)
+    l0.backward()
+    assert net.flat.grad is not None and net.flat.grad.abs().max().item() > 0
+    sd = sfm.state_dict()
+    assert all(k.startswith("model.velocity_model.") for k in sd)
+    sfm.load_state_dict(sd)
+    import subprocess
+    import sys
+    env = dict(os.environ, VDM4CDM_MAX_STEPS="2", VDM4CDM_LOG_DIR=str(tmp_path), VDM4CDM_CROPSIZE_2D="16", VDM4CDM_BATCH_2D="2")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "trainSFM_c_uc_from_field_name.py"), "Mstar", "Mcdm"], env=env, cwd=ROOT,
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    assert "train/loss" in open(tmp_path / "LH_c_uc_Mstar_to_Mcdm" / "metrics.jsonl").read()
+
+
 def test_param_count_and_state_dict_roundtrip(tmp_path):
     from vdm4cdm_amd.networks import CUNet
     from vdm4cdm_amd.vdm_model import LightVDM

@@ -26,6 +26,20 @@ def test_train_script_runs_on_gpu(tmp_path):
     assert len(lines) >= 1 and "train/elbo" in lines[0]
 
 
+def test_sfm_train_script_runs_on_gpu_from_files(tmp_path):
+    """python trainSFM3D128_c_c_from_field_name_thick_lowbatch.py Mstar Mcdm <cropsize> on a synthetic on-disk data set in the
+    reference's file layout: file-backed AstroDataModule (device data path) -> LightSFM on the HIP backend, 3 steps."""
+    from vdm4cdm_amd import data
+    root = data.write_synthetic_camels(str(tmp_path / "camels"), dataset_name="CMD_128", n_sims=3, fullsize=32, seed=1)
+    env = dict(os.environ, VDM4CDM_MAX_STEPS="3", VDM4CDM_LOG_DIR=str(tmp_path), VDM4CDM_PRECISION="bf16", VDM4CDM_DATA_ROOT=root)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "trainSFM3D128_c_c_from_field_name_thick_lowbatch.py"), "Mstar", "Mcdm", "16"],
+                       env=env, cwd=ROOT, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    assert "SYNTHETIC" not in r.stderr
+    lines = open(tmp_path / "LH128_c_c_Mstar_to_Mcdm_thick_lowbatch_16" / "metrics.jsonl").read().strip().splitlines()
+    assert len(lines) >= 1 and "train/loss" in lines[0]
+
+
 def test_generate_3d_runs_on_gpu(tmp_path):
     """python generate_3D.py <model> <dir> CV_12_12 on a shrunk registry entry (cropsize 16, 2 cubes x 2 reps, 5 steps)."""
     cfgs = yaml.safe_load(open(os.path.join(ROOT, "configs.yaml")))

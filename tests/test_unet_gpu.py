@@ -17,11 +17,11 @@ pytestmark = pytest.mark.gpu
 DEV = "cuda:0"
 
 
-def make_net(D=16, chs=(16, 32, 64), sc=1, vd=(6,), pm="zeros", precision="fp32", dropout=0.0, groups=8, seed=1):
+def make_net(D=16, chs=(16, 32, 64), sc=1, vd=(6,), pm="zeros", precision="fp32", dropout=0.0, groups=8, seed=1, attn=False, heads=4):
     from vdm4cdm_amd.networks import CUNet
     net = CUNet(shape=(1, D, D, D), chs=list(chs), s_conditioning_channels=sc, v_conditioning_dims=list(vd),
-                t_conditioning=True, norm_groups=groups, mid_attn=False, dropout_prob=dropout,
-                conv_padding_mode=pm, n_attention_heads=4, backend="hip", precision=precision)
+                t_conditioning=True, norm_groups=groups, mid_attn=attn, dropout_prob=dropout,
+                conv_padding_mode=pm, n_attention_heads=heads, backend="hip", precision=precision)
     randomize(net, seed)
     return net
 
@@ -145,6 +145,51 @@ def test_unet_backward_bf16():
         if cos < 0.995:
             bad.append((k, cos))
     assert not bad, f"{len(bad)} tensors off: {bad[:8]}"
+
+
+ATTN_CFGS = [dict(D=16, chs=(16, 32, 64), sc=1, vd=(6,), pm="zeros", attn=True, heads=4),        # 4^3 = 64 voxels at the mid level, hd 16
+             dict(D=32, chs=(16, 32), sc=0, vd=(3,), pm="circular", attn=True, heads=2)]          # 16^3 = 4096 voxels, hd 16
+
+
+@pytest.mark.parametrize("cfg", ATTN_CFGS, ids=["attn64", "attn4096"])
+def test_mid_attention_forward_backward_fp32(cfg):
+    """mid_attn=True (spec D13): GroupNorm (no activation) + qkv / proj 1x1x1 convs + row softmax kernels + library GEMMs vs the
+    oracle's attention block, forward and every parameter gradient (incl. the attention block's own)."""
+    net = make_net(precision="fp32", **cfg).to(DEV).train()
+    assert net._exec is None and "mid_attn.qkv.weight" in net.spec.items
+    x, t, s, v = inputs(net, 2)
+    w = grf((2, 1) + net.shape[1:], 78) + 0.5
+    y, gflat = _grads(net, x, t, s, v, w)
+    yr, gref = _oracle_grads(net, x, t, s, v, w)
+    assert (y - yr).abs().max().item() <= 2e-4 * yr.abs().max().item()
+    # the block is live: without it the output differs
+    p_no = {k: a for k, a in oracle_params(net).items() if not k.startswith("mid_attn")}
+    assert (oracle_forward(net, x, t, s, v, params=p_no) - yr).abs().max().item() > 1e-3 * yr.abs().max().item()
+    got = _product_grad_views(net, gflat)
+    bad = []
+    for k, g in gref.items():
+        scale = max(g.abs().max().item(), 1e-8)
+        err = (got[k] - g).abs().max().item()
+        if err > 2e-3 * scale + 1e-6:
+            bad.append((k, err, scale))
+    assert not bad, f"{len(bad)} tensors off: {bad[:8]}"
+    assert all(gref[k].abs().max().item() > 0 for k in gref if k.startswith("mid_attn"))
+
+
+def test_mid_attention_bf16_and_sampler():
+    net = make_net(precision="bf16", **ATTN_CFGS[0]).to(DEV).train()
+    x, t, s, v = inputs(net, 2)
+    w = grf((2, 1) + net.shape[1:], 78) + 0.5
+    y, gflat = _grads(net, x, t, s, v, w)
+    yr, gref = _oracle_grads(net, x, t, s, v, w)
+    assert (y - yr).abs().max().item() <= 3e-2 * yr.abs().max().item()
+    got = _product_grad_views(net, gflat)
+    bad = [(k, c) for k, c in ((k, torch.nn.functional.cosine_similarity(got[k].flatten(), g.flatten(), dim=0).item())
+                               for k, g in gref.items() if g.numel() >= 8) if c < 0.995]
+    assert not bad, bad[:8]
+    vdm = make_vdm(net).to(DEV).eval()                       # the captured sampler graph contains the attention block
+    out = vdm.draw_samples(batch_size=1, n_sampling_steps=4, s_conditioning=s[:1].to(DEV), v_conditionings=[a[:1].to(DEV) for a in v])
+    assert out.shape == (1, 1, 16, 16, 16) and torch.isfinite(out).all()
 
 
 def test_dropout_training_runs_and_is_seeded():
@@ -272,6 +317,37 @@ def test_cfg_sampler_matches_oracle(use_graph):
         e_tr = vdm.model.get_pred_noise(z1.to(DEV), g_t, **kw).cpu()
     e_plain = score_v(z1, tn, v)
     assert (e_tr - e_plain).abs().max().item() <= 1e-4 * e_plain.abs().max().item() + 1e-5
+
+
+def test_sfm_loss_gradients_and_sampler_match_oracle():
+    """SFM (spec D14) on the HIP backend: K7 interpolation + K8 loss / gradient and the hipGraph Euler loop vs oracle/sfm_oracle.py."""
+    from oracle import sfm_oracle, unet_oracle
+    from vdm4cdm_amd.sfm_model import LightSFM
+    net = make_net(precision="fp32", **CFGS[0])
+    sfm = LightSFM(velocity_model=net, learning_rate=3e-4).to(DEV).train()
+    B = 2
+    x1, _, x0, v = inputs(net, B)
+    times = torch.tensor([0.15, 0.65])
+    P = {k: a.clone().requires_grad_(True) for k, a in oracle_params(net).items()}
+    vel = lambda xt, t, x0_: unet_oracle.cunet_forward(P, oracle_cfg(net), xt, t, x0_, v)
+    loss, _ = sfm.model.get_loss(x0=x0.to(DEV), x1=x1.to(DEV), times=times.to(DEV), v_conditionings=[a.to(DEV) for a in v])
+    ref, _, _ = sfm_oracle.sfm_loss(vel, x0, x1, times)
+    assert loss.item() == pytest.approx(ref.item(), rel=2e-4)
+    net.zero_grad()
+    loss.backward()
+    ref.backward()
+    got = _product_grad_views(net, net.flat.grad.detach().cpu())
+    bad = [(k, (got[k] - a.grad).abs().max().item()) for k, a in P.items()
+           if a.grad is not None and (got[k] - a.grad).abs().max().item() > 2e-3 * max(a.grad.abs().max().item(), 1e-8) + 1e-7]
+    assert not bad, bad[:8]
+    sfm.eval()
+    for use_graph in (False, True):
+        out = sfm.draw_samples(x0=x0[:1].to(DEV), n_sampling_steps=8, v_conditionings=[a[:1].to(DEV) for a in v], use_graph=use_graph).cpu()
+        with torch.no_grad():
+            Pd = {k: a.detach() for k, a in P.items()}
+            vel1 = lambda xt, t, x0_: unet_oracle.cunet_forward(Pd, oracle_cfg(net), xt, t, x0_, [a[:1] for a in v])
+            ref_s = sfm_oracle.sfm_sample(vel1, x0[:1], 8)
+        assert (out - ref_s).abs().max().item() <= 2e-4 * ref_s.abs().max().item() + 1e-4
 
 
 def test_sampler_identity_T2_and_api():

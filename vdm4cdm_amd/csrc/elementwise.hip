@@ -211,6 +211,7 @@ struct GnArgs {
     int blocks_per_n;
     unsigned char* mask;     // fwd (optional out): dropout keep bits, one byte per 16-byte piece of y
     const float* chan;       // bwd apply (fused path): per-sample channel sums [n][C][2] of (dyh, dyh*xhat)
+    int linear;              // 1: no activation (plain GroupNorm, the attention block's norm); 0: SiLU
 };
 
 template <typename T>
@@ -245,7 +246,8 @@ __global__ void __launch_bounds__(256) gn_silu_fwd_kernel(const GnArgs a) {
         unsigned keepbits = 0;
 #pragma unroll
         for (int j = 0; j < EPL; ++j) {
-            float o = silu_f(p.f[j] * A[j] + B[j]);
+            float o = p.f[j] * A[j] + B[j];
+            if (!a.linear) o = silu_f(o);
             if (drop) {
                 if ((j & 3) == 0) {
                     const uint64_t e4 = ((uint64_t)n * a.V * C + (uint64_t)i * EPL + j) >> 2;
@@ -305,7 +307,7 @@ __global__ void __launch_bounds__(256) gn_silu_bwd_reduce_kernel(const GnArgs a)
         uint32_t rnd[4];
 #pragma unroll
         for (int j = 0; j < EPL; ++j) {
-            float d = pd.f[j] * dsilu(px.f[j] * A[j] + B[j]);
+            float d = a.linear ? pd.f[j] : pd.f[j] * dsilu(px.f[j] * A[j] + B[j]);
             if (drop) {
                 if ((j & 3) == 0) {
                     const uint64_t e4 = ((uint64_t)n * a.V * C + (uint64_t)i * EPL + j) >> 2;
@@ -403,7 +405,7 @@ __global__ void __launch_bounds__(256) gn_silu_bwd_apply_kernel(const GnArgs a) 
         uint32_t rnd[4];
 #pragma unroll
         for (int j = 0; j < EPL; ++j) {
-            float d = pd.f[j] * dsilu(px.f[j] * A[j] + B[j]);
+            float d = a.linear ? pd.f[j] : pd.f[j] * dsilu(px.f[j] * A[j] + B[j]);
             if (drop) {
                 if ((j & 3) == 0) {
                     const uint64_t e4 = ((uint64_t)n * a.V * C + (uint64_t)i * EPL + j) >> 2;
@@ -704,6 +706,73 @@ __global__ void __launch_bounds__(256) ancestral_kernel(float* __restrict__ z, c
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// attention block (mid_attn=True): row softmax of the fp32 score matrix and its backward, in place.  The two batched GEMMs around
+// them (Q K^T, P V and their transposes in the backward) are plain library GEMMs (rocBLAS through torch.matmul).
+// One workgroup per row; a row (<= 13 824 voxels at 192^3 / 8) stays in L2 between the passes.
+// ---------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) softmax_rows_kernel(float* __restrict__ s, int cols, float scale) {
+    __shared__ float sm[8];
+    float* row = s + (size_t)blockIdx.x * cols;
+    float m[1] = {-3.0e38f};
+    for (int i = threadIdx.x; i < cols; i += 256) m[0] = fmaxf(m[0], row[i] * scale);
+    // block max through the sum helper's scratch: wave max, then fold the 4 waves
+    float w = m[0];
+    for (int off = 32; off > 0; off >>= 1) w = fmaxf(w, __shfl_xor(w, off));
+    if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = w;
+    __syncthreads();
+    const float mx = fmaxf(fmaxf(sm[0], sm[1]), fmaxf(sm[2], sm[3]));
+    float acc[1] = {0.f};
+    for (int i = threadIdx.x; i < cols; i += 256) {
+        const float e = __expf(row[i] * scale - mx);
+        row[i] = e;
+        acc[0] += e;
+    }
+    block_sum<1>(acc, sm + 4);
+    __syncthreads();
+    if (threadIdx.x == 0) sm[4] = 1.f / acc[0];
+    __syncthreads();
+    const float inv = sm[4];
+    for (int i = threadIdx.x; i < cols; i += 256) row[i] *= inv;
+}
+
+// dp <- scale * p * (dp - sum_j dp_j p_j)   (gradient w.r.t. the un-scaled scores)
+__global__ void __launch_bounds__(256) softmax_rows_bwd_kernel(const float* __restrict__ p, float* __restrict__ dp, int cols, float scale) {
+    __shared__ float sm[8];
+    const float* pr = p + (size_t)blockIdx.x * cols;
+    float* dr = dp + (size_t)blockIdx.x * cols;
+    float acc[1] = {0.f};
+    for (int i = threadIdx.x; i < cols; i += 256) acc[0] += pr[i] * dr[i];
+    block_sum<1>(acc, sm);
+    __syncthreads();
+    if (threadIdx.x == 0) sm[4] = acc[0];
+    __syncthreads();
+    const float dot = sm[4];
+    for (int i = threadIdx.x; i < cols; i += 256) dr[i] = scale * pr[i] * (dr[i] - dot);
+}
+
+// out[c] = sum over rows of x[row][c] (bias gradients of the attention block's 1x1 projections); one workgroup per 16-byte piece
+// column, fixed summation order
+template <typename T>
+__global__ void __launch_bounds__(256) channel_sums_kernel(const T* __restrict__ x, int64_t rows, int C, float* __restrict__ out) {
+    constexpr int EPL = DT<T>::EPL;
+    __shared__ float sm[4 * EPL];
+    float acc[EPL];
+#pragma unroll
+    for (int j = 0; j < EPL; ++j) acc[j] = 0.f;
+    for (int64_t r = threadIdx.x; r < rows; r += 256) {
+        Piece<T> p;
+        p.load(*reinterpret_cast<const uint4*>(x + r * C + blockIdx.x * EPL));
+#pragma unroll
+        for (int j = 0; j < EPL; ++j) acc[j] += p.f[j];
+    }
+    block_sum<EPL>(acc, sm);
+    if (threadIdx.x == 0) {
+#pragma unroll
+        for (int j = 0; j < EPL; ++j) out[blockIdx.x * EPL + j] = acc[j];
+    }
+}
+
 __global__ void step_inc_kernel(int32_t* p) { *p += 1; }
 
 __global__ void __launch_bounds__(256) sumsq_kernel(const float* __restrict__ x, int64_t n, float* __restrict__ part) {
@@ -802,7 +871,7 @@ static GnArgs gn_args(const void* x1, int c1, const void* x2, int c2, int n, int
 
 extern "C" int vdm_gn_silu_fwd(const void* x1, int c1, const void* x2, int c2, int n, int64_t voxels, int groups, int dtype,
                                const float* stats, const float* gamma, const float* beta, float eps, float dropout_p, uint64_t seed,
-                               void* y, uint8_t* keep_mask, void* stream) {
+                               void* y, uint8_t* keep_mask, int linear, void* stream) {
     int e = gn_common_check(c1, c2, n, voxels, groups, dtype, "gn_silu_fwd");
     if (e) return e;
     VDM_REQUIRE(x1 && stats && gamma && beta && y && (c2 == 0 || x2), "gn_silu_fwd: NULL pointer");
@@ -810,6 +879,7 @@ extern "C" int vdm_gn_silu_fwd(const void* x1, int c1, const void* x2, int c2, i
     GnArgs a = gn_args(x1, c1, x2, c2, n, voxels, groups, dtype, stats, gamma, beta, eps, dropout_p, seed);
     a.y = y;
     a.mask = keep_mask;
+    a.linear = linear != 0;
     hipStream_t s = (hipStream_t)stream;
     if (dtype == VDM_F32)
         hipLaunchKernelGGL(gn_silu_fwd_kernel<float>, dim3(a.blocks_per_n * n), dim3(256), 0, s, a);
@@ -822,12 +892,13 @@ extern "C" int vdm_gn_silu_fwd(const void* x1, int c1, const void* x2, int c2, i
 extern "C" int vdm_gn_silu_bwd(const void* x1, int c1, const void* x2, int c2, int n, int64_t voxels, int groups, int dtype,
                                const float* stats, const float* gamma, const float* beta, float eps, float dropout_p, uint64_t seed,
                                const void* dy, const void* add1, const void* add2, void* dx1, void* dx2, float* dgamma, float* dbeta,
-                               float* colsum, int64_t colsum_stride, float* red_ws, void* stream) {
+                               float* colsum, int64_t colsum_stride, float* red_ws, int linear, void* stream) {
     int e = gn_common_check(c1, c2, n, voxels, groups, dtype, "gn_silu_bwd");
     if (e) return e;
     VDM_REQUIRE(x1 && stats && gamma && beta && dy && dx1 && dgamma && dbeta && red_ws && (c2 == 0 || (x2 && dx2)), "gn_silu_bwd: NULL pointer");
     GnArgs a = gn_args(x1, c1, x2, c2, n, voxels, groups, dtype, stats, gamma, beta, eps, dropout_p, seed);
     a.dy = dy; a.add1 = add1; a.add2 = add2; a.colsum_stride = colsum_stride; a.dx1 = dx1; a.dx2 = dx2; a.dgamma = dgamma; a.dbeta = dbeta; a.colsum = colsum; a.red = red_ws;
+    a.linear = linear != 0;
     hipStream_t s = (hipStream_t)stream;
     e = check_hip(hipMemsetAsync(red_ws, 0, sizeof(float) * 2 * groups * n, s), "hipMemsetAsync(red_ws)");
     if (e) return e;
@@ -928,6 +999,33 @@ extern "C" int vdm_ancestral_step_cfg(float* z, const float* eps_cond, const flo
     hipLaunchKernelGGL(ancestral_kernel, dim3(grid_for(n, 256 * 8)), dim3(256), 0, (hipStream_t)stream, z, eps_cond, eps_uncond, w_cfg,
                        noise, coef, step_ptr, seed, n);
     VDM_LAUNCH_CHECK("ancestral_kernel(cfg)");
+    return VDM_OK;
+}
+
+extern "C" int vdm_softmax_rows(float* scores, int64_t rows, int cols, float scale, void* stream) {
+    VDM_REQUIRE(scores && rows > 0 && rows < (1ll << 31) && cols > 0, "softmax_rows: bad arguments");
+    hipLaunchKernelGGL(softmax_rows_kernel, dim3((unsigned)rows), dim3(256), 0, (hipStream_t)stream, scores, cols, scale);
+    VDM_LAUNCH_CHECK("softmax_rows_kernel");
+    return VDM_OK;
+}
+
+extern "C" int vdm_softmax_rows_bwd(const float* probs, float* dprobs, int64_t rows, int cols, float scale, void* stream) {
+    VDM_REQUIRE(probs && dprobs && rows > 0 && rows < (1ll << 31) && cols > 0, "softmax_rows_bwd: bad arguments");
+    hipLaunchKernelGGL(softmax_rows_bwd_kernel, dim3((unsigned)rows), dim3(256), 0, (hipStream_t)stream, probs, dprobs, cols, scale);
+    VDM_LAUNCH_CHECK("softmax_rows_bwd_kernel");
+    return VDM_OK;
+}
+
+extern "C" int vdm_channel_sums(const void* x, int64_t rows, int c, int dtype, float* out, void* stream) {
+    VDM_REQUIRE(x && out && rows > 0 && c > 0, "channel_sums: bad arguments");
+    VDM_REQUIRE(dtype == VDM_F32 || dtype == VDM_BF16, "channel_sums: dtype");
+    const int epl = dtype == VDM_F32 ? 4 : 8;
+    VDM_REQUIRE(c % epl == 0, "channel_sums: channels must be a multiple of %d", epl);
+    if (dtype == VDM_F32)
+        hipLaunchKernelGGL(channel_sums_kernel<float>, dim3(c / epl), dim3(256), 0, (hipStream_t)stream, (const float*)x, rows, c, out);
+    else
+        hipLaunchKernelGGL(channel_sums_kernel<bf16_t>, dim3(c / epl), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, rows, c, out);
+    VDM_LAUNCH_CHECK("channel_sums_kernel");
     return VDM_OK;
 }
 

@@ -5,6 +5,8 @@
   trainVDM3D_c_uc_from_field_name_thick_lowbatch.py:57-73; trainer settings :38-49).
 * ``train_uc_uc_from_field_name.py <field_name>`` (2D, learned-linear schedule, circular padding; BASELINE config C1 runs it on
   CPU PyTorch) -> ``train_uc_uc(argv)`` (/root/reference/train_uc_uc_from_field_name.py:50-120).
+* ``trainSFM3D*_from_field_name*.py <field_in> <field_out> <cropsize>`` -> ``train_sfm3d(variant, argv)`` and the 2D
+  ``trainSFM_c_uc_from_field_name.py <field_in> <field_out>`` (mid-level attention on) -> ``train_sfm_c_uc_2d(argv)``.
 * ``generate_3D.py <model_name> <save_path> <runtype>`` -> ``generate_3d(argv)`` (/root/reference/generate_3D.py).
 Environment knobs (build-side, all optional): VDM4CDM_MAX_STEPS, VDM4CDM_PRECISION (bf16|fp32), VDM4CDM_SAMPLING_STEPS,
 VDM4CDM_LOG_DIR, VDM4CDM_CROPSIZE_2D / VDM4CDM_BATCH_2D (shrink the 2D plumbing config).
@@ -96,6 +98,89 @@ def train_vdm3d(variant, argv=None):
                       experiment_name=name_pat.format(i=field_in, o=field_out, c=cropsize),
                       n_val_sampling_steps=int(os.environ.get("VDM4CDM_SAMPLING_STEPS", 250)))
     trainer.fit(model=vdm, datamodule=dm)
+    return trainer
+
+
+# variant -> (dataset_name, chs, conditioning_values, batch_size, experiment-name pattern, slab thickness of the image)
+# [/root/reference/trainSFM3D{128,160,192,}_c_c_from_field_name_thick_lowbatch.py:36,59-68,74,89;
+#  trainSFM3D_c_uc_from_field_name{,_thick,_thick_lowbatch}.py]
+SFM3D_VARIANTS = {
+    "128": ("CMD_128", [32, 64, 128, 256], 6, 4, "LH128_c_c_{i}_to_{o}_thick_lowbatch_{c}", 48),
+    "160": ("CMD_160", [32, 64, 128, 256], 6, 4, "LH160_c_c_{i}_to_{o}_thick_lowbatch_{c}", 48),
+    "192": ("CMD_192", [32, 64, 128, 256], 6, 2, "LH192_c_c_{i}_to_{o}_thick_lowbatch_{c}", 48),
+    "256": ("CMD", [16, 32, 64, 128], 6, 2, "LH_c_c_{i}_to_{o}_thick_lowbatch_{c}", 32),
+    "256_c_uc": ("CMD", [12, 36, 64, 128], 0, 2, "LH_c_uc_{i}_to_{o}", 32),
+    "256_c_uc_thick": ("CMD", [16, 32, 64, 128], 0, 3, "LH_c_uc_{i}_to_{o}_thick", 32),
+    "256_c_uc_thick_lowbatch": ("CMD", [16, 32, 64, 128], 0, 2, "LH_c_uc_{i}_to_{o}_thick_lowbatch_{c}", 32),
+}
+
+
+def _sfm_figure_closure(dm, thickness, with_values):
+    """draw_figure_sfm(batch, samples) (/root/reference/src/utils.py:204-243): the same panels as the VDM figure with the source
+    field x0 in the conditioning slot and x1 as the target."""
+    vdm_fig = _figure_closure(dm, thickness, with_values)
+
+    def draw_figure(batch, samples):
+        return vdm_fig({"x": batch["x1"], "conditioning": batch["x0"], "conditioning_values": batch.get("conditioning_values")}, samples)
+
+    return draw_figure
+
+
+def train_sfm3d(variant, argv=None):
+    """trainSFM3D*_from_field_name*.py <field_in> <field_out> <cropsize>: flow matching from field_in (x0) to field_out (x1)."""
+    from . import data, networks, sfm_model
+    from .trainer import Trainer
+    argv = sys.argv[1:] if argv is None else argv
+    if len(argv) != 3:
+        raise SystemExit("usage: <script> <field_in> <field_out> <cropsize>")
+    field_in, field_out, cropsize = argv[0], argv[1], int(argv[2])
+    dataset_name, chs, n_values, batch_size, name_pat, thick = SFM3D_VARIANTS[variant]
+    _seed_everything(42)
+
+    def return_func(fields, params):
+        return {"x0": fields[0], "x1": fields[1], "conditioning_values": [params] if n_values else None}
+
+    dm = data.get_dataset(dataset_name=dataset_name, suite_name="Astrid", return_func=return_func, set_name="LH", z_name="z_0.0",
+                          channel_names=[field_in, field_out], stage="fit", batch_size=batch_size, cropsize=cropsize,
+                          num_workers=16, mmap=False)
+    velocity_model = networks.CUNet(
+        shape=(1, cropsize, cropsize, cropsize), chs=chs, s_conditioning_channels=1,
+        v_conditioning_dims=[] if n_values == 0 else [n_values], t_conditioning=True, norm_groups=8, mid_attn=False,
+        dropout_prob=0.1, conv_padding_mode="circular" if cropsize == 256 else "zeros", n_attention_heads=4,
+        backend="hip", precision=os.environ.get("VDM4CDM_PRECISION", "bf16"))
+    sfm = sfm_model.LightSFM(velocity_model=velocity_model, draw_figure=_sfm_figure_closure(dm, thick, n_values > 0), learning_rate=3.0e-4)
+    trainer = Trainer(max_steps=int(os.environ.get("VDM4CDM_MAX_STEPS", 1_000_000)), val_check_interval=1000,
+                      gradient_clip_val=0.5, every_n_train_steps=10_000,
+                      default_root_dir=os.environ.get("VDM4CDM_LOG_DIR", "./data/logs/sfm4cdm-3D"),
+                      experiment_name=name_pat.format(i=field_in, o=field_out, c=cropsize),
+                      n_val_sampling_steps=int(os.environ.get("VDM4CDM_SAMPLING_STEPS", 100)))
+    trainer.fit(model=sfm, datamodule=dm)
+    return trainer
+
+
+def train_sfm_c_uc_2d(argv=None):
+    """trainSFM_c_uc_from_field_name.py <field_in> <field_out>: the 2D flow-matching script, the one place the reference switches
+    the mid-level attention on (mid_attn=True, /root/reference/trainSFM_c_uc_from_field_name.py:58-67,104-119).  CPU plumbing like
+    BASELINE config C1 (explicit backend='torch')."""
+    from . import data, networks, sfm_model
+    from .trainer import Trainer
+    argv = sys.argv[1:] if argv is None else argv
+    if len(argv) != 2:
+        raise SystemExit("usage: trainSFM_c_uc_from_field_name.py <field_in> <field_out>")
+    field_in, field_out = argv
+    _seed_everything(42)
+    cropsize = int(os.environ.get("VDM4CDM_CROPSIZE_2D", 256))
+    batch_size = int(os.environ.get("VDM4CDM_BATCH_2D", 12))
+    dm = data.SyntheticAstroDataModule(cropsize=cropsize, batch_size=batch_size, dim=2, channel_names=[field_in, field_out], n_params=0,
+                                       return_func=lambda fields, params: {"x0": fields[0], "x1": fields[1], "conditioning_values": None})
+    velocity_model = networks.CUNet(shape=(1, cropsize, cropsize), chs=[48, 96, 192, 384], s_conditioning_channels=1,
+                                    v_conditioning_dims=[], t_conditioning=True, norm_groups=8, mid_attn=True, dropout_prob=0.1,
+                                    conv_padding_mode="circular", n_attention_heads=4, backend="torch")
+    sfm = sfm_model.LightSFM(velocity_model=velocity_model, draw_figure=None)
+    trainer = Trainer(max_steps=int(os.environ.get("VDM4CDM_MAX_STEPS", 1_000_000)), val_check_interval=1000, gradient_clip_val=0.5,
+                      every_n_train_steps=10_000, default_root_dir=os.environ.get("VDM4CDM_LOG_DIR", "./data/logs/sfm4cdm-2D"),
+                      experiment_name=f"LH_c_uc_{field_in}_to_{field_out}", device="cpu")
+    trainer.fit(model=sfm, datamodule=dm)
     return trainer
 
 

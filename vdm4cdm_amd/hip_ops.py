@@ -333,7 +333,7 @@ def gn_stats(x1, x2, groups, out=None, chsum=False):
     return out
 
 
-def gn_silu_fwd(x1, x2, groups, stats, gamma, beta, dropout_p=0.0, seed=0, out=None, want_mask=False):
+def gn_silu_fwd(x1, x2, groups, stats, gamma, beta, dropout_p=0.0, seed=0, out=None, want_mask=False, linear=False):
     """want_mask (with dropout_p > 0): the dropout keep bits are also written, one byte per 16-byte piece, attached as
     `out.keep_mask` (consumed by Conv.dgrad_gn)."""
     L = _lib.lib()
@@ -348,14 +348,14 @@ def gn_silu_fwd(x1, x2, groups, stats, gamma, beta, dropout_p=0.0, seed=0, out=N
         mask = torch.empty((n, v, (c1 + c2) // epl(x1.dtype)), dtype=torch.uint8, device=x1.device)
     ev = _pb()
     check(L.vdm_gn_silu_fwd(_p(x1), c1, _p(x2), c2, n, v, groups, dt_id(x1.dtype), _p(stats), _p(gamma), _p(beta), GN_EPS,
-                            float(dropout_p), int(seed), _p(out), _p(mask), _s()), "vdm_gn_silu_fwd")
+                            float(dropout_p), int(seed), _p(out), _p(mask), int(bool(linear)), _s()), "vdm_gn_silu_fwd")
     out.keep_mask = mask
     _pe(ev, "gn_silu_fwd", 0.0, 2.0 * out.numel() * out.element_size())
     return out
 
 
 def gn_silu_bwd(x1, x2, groups, stats, gamma, beta, dy, dgamma, dbeta, add1=None, add2=None, colsum=None,
-                dropout_p=0.0, seed=0, dx1=None, dx2=None):
+                dropout_p=0.0, seed=0, dx1=None, dx2=None, linear=False):
     """Returns (dx1, dx2).  dgamma / dbeta / colsum are accumulated into (caller zeroes)."""
     L = _lib.lib()
     _contig(x1, x2, dy, add1, add2, gamma, beta, dgamma, dbeta)
@@ -374,7 +374,7 @@ def gn_silu_bwd(x1, x2, groups, stats, gamma, beta, dy, dgamma, dbeta, add1=None
     ev = _pb()
     check(L.vdm_gn_silu_bwd(_p(x1), c1, _p(x2), c2, n, v, groups, dt_id(x1.dtype), _p(stats), _p(gamma), _p(beta), GN_EPS,
                             float(dropout_p), int(seed), _p(dy), _p(add1), _p(add2), _p(dx1), _p(dx2), _p(dgamma), _p(dbeta),
-                            _p(colsum), cstride, _p(red), _s()), "vdm_gn_silu_bwd")
+                            _p(colsum), cstride, _p(red), int(bool(linear)), _s()), "vdm_gn_silu_bwd")
     _pe(ev, "gn_silu_bwd(reduce+apply)", 0.0, (5.0 + (1.0 if add1 is not None else 0.0)) * dy.numel() * dy.element_size())
     return dx1, dx2
 
@@ -497,6 +497,32 @@ def augment_batch(fields, consts, samples, crop, out=None):
             tab[b].anchor[d], tab[b].flip[d], tab[b].perm[d] = int(anchor[d]), int(bool(flip[d])), int(perm[d])
     check(L.vdm_augment_batch(ch, C_, int(S), int(crop), tab, B, _s()), "vdm_augment_batch")
     return out
+
+
+def channel_sums(x, out):
+    """out[c] (fp32 view) = sum over all leading dims of x[..., c]."""
+    _contig(x, out)
+    c = x.shape[-1]
+    check(_lib.lib().vdm_channel_sums(_p(x), x.numel() // c, c, dt_id(x.dtype), _p(out), _s()), "vdm_channel_sums")
+    return out
+
+
+def softmax_rows_(scores, scale):
+    """In-place row softmax of scale * scores (fp32, last dim = row)."""
+    _contig(scores)
+    assert scores.dtype == torch.float32 and scores.is_cuda
+    cols = scores.shape[-1]
+    check(_lib.lib().vdm_softmax_rows(_p(scores), scores.numel() // cols, cols, float(scale), _s()), "vdm_softmax_rows")
+    return scores
+
+
+def softmax_rows_bwd_(probs, dprobs, scale):
+    """In place on dprobs: gradient w.r.t. the un-scaled scores, scale * p * (dp - sum_j dp_j p_j)."""
+    _contig(probs, dprobs)
+    assert probs.dtype == dprobs.dtype == torch.float32 and probs.shape == dprobs.shape
+    cols = probs.shape[-1]
+    check(_lib.lib().vdm_softmax_rows_bwd(_p(probs), _p(dprobs), probs.numel() // cols, cols, float(scale), _s()), "vdm_softmax_rows_bwd")
+    return dprobs
 
 
 def diffuse(x, eps, alpha, sigma, out=None):

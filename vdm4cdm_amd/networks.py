@@ -55,9 +55,6 @@ class CUNet(nn.Module):
                  t_conditioning=True, norm_groups=8, mid_attn=False, dropout_prob=0.0,
                  conv_padding_mode="zeros", n_attention_heads=4, backend="hip", precision="bf16"):
         super().__init__()
-        if mid_attn:
-            raise NotImplementedError("mid_attn=True is outside the hot path of this build (every 3D VDM script "
-                                      "of the reference passes mid_attn=False); see DESIGN.md 'out of scope'")
         assert conv_padding_mode in ("zeros", "circular")
         assert backend in ("hip", "torch")
         self.shape = tuple(shape)
@@ -70,7 +67,9 @@ class CUNet(nn.Module):
         self.norm_groups = int(norm_groups)
         self.dropout_prob = float(dropout_prob)
         self.conv_padding_mode = conv_padding_mode
-        self.n_attention_heads = n_attention_heads
+        self.n_attention_heads = int(n_attention_heads)
+        self.mid_attn = bool(mid_attn)                # D13: self-attention between the two mid blocks
+        assert not self.mid_attn or chs[-1] % self.n_attention_heads == 0, "chs[-1] must be divisible by n_attention_heads"
         self.backend = backend
         self.precision = precision            # "bf16" | "fp32": activation storage of the HIP backend
         self.taps = 3 ** self.dim
@@ -154,6 +153,14 @@ class CUNet(nn.Module):
                 sp.add(f"downs.{i}.down.bias", (chs[i],), "bias", T * chs[i])
         for j in range(2):
             add_block(blocks[f"mid.{j}"])
+            if j == 0 and self.mid_attn:               # D13 [INFERRED]: GroupNorm -> qkv (1^dim conv) -> attention -> proj (zero-init)
+                C = chs[-1]
+                sp.add("mid_attn.norm.weight", (C,), "ones")
+                sp.add("mid_attn.norm.bias", (C,), "zeros")
+                sp.add("mid_attn.qkv.weight", (1, 3 * C, C), "conv", C)
+                sp.add("mid_attn.qkv.bias", (3 * C,), "bias", C)
+                sp.add("mid_attn.proj.weight", (1, C, C), "zeros")
+                sp.add("mid_attn.proj.bias", (C,), "zeros")
         for i in reversed(range(L - 1)):
             sp.add(f"ups.{i}.up.weight", (T, chs[i], chs[i + 1]), "conv", T * chs[i + 1])
             sp.add(f"ups.{i}.up.bias", (chs[i],), "bias", T * chs[i + 1])
@@ -374,6 +381,16 @@ class CUNet(nn.Module):
             return s + h
         return x + h
 
+    def _attn_t(self, x):
+        """D13 on the torch backend: GroupNorm -> qkv -> softmax(q k^T / sqrt(hd)) v over all voxels -> proj -> + x."""
+        N, C, H = x.shape[0], x.shape[1], self.n_attention_heads
+        h = F.group_norm(x, self.norm_groups, self.view("mid_attn.norm.weight"), self.view("mid_attn.norm.bias"), GN_EPS)
+        qkv = self._conv_t(h, "mid_attn.qkv.weight", "mid_attn.qkv.bias").reshape(N, 3, H, C // H, -1)
+        q, k, v = (qkv[:, i].transpose(-1, -2) for i in range(3))                # [N, H, V, hd]
+        a = F.scaled_dot_product_attention(q, k, v)                              # scale 1 / sqrt(hd)
+        a = a.transpose(-1, -2).reshape(x.shape)
+        return x + self._conv_t(a, "mid_attn.proj.weight", "mid_attn.proj.bias")
+
     def _forward_torch(self, x, s_conditioning, table):
         L = len(self.chs)
         blocks = {b.name: b for b in self.blocks}
@@ -387,6 +404,8 @@ class CUNet(nn.Module):
                 h = self._conv_t(h, f"downs.{i}.down.weight", f"downs.{i}.down.bias", stride=2)
         for j in range(2):
             h = self._block_t(blocks[f"mid.{j}"], h, None, table)
+            if j == 0 and self.mid_attn:
+                h = self._attn_t(h)
         for i in reversed(range(L - 1)):
             h = F.interpolate(h, scale_factor=2, mode="nearest")
             h = self._conv_t(h, f"ups.{i}.up.weight", f"ups.{i}.up.bias")

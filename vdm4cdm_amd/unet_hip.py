@@ -157,6 +157,69 @@ class _Res:
                                GP(n + ".norm1.weight"), GP(n + ".norm1.bias"), add1=add1, add2=add2)
 
 
+class _Attn:
+    """Self-attention between the two mid blocks (CUNet(mid_attn=True), spec D13): GroupNorm (no activation) -> 1x1x1 conv to q, k, v
+    -> softmax(q k^T / sqrt(hd)) v over all voxels of the level -> 1x1x1 projection + residual.  GroupNorm, the two projections
+    (MFMA convs), the row softmax and its backward are kernels of this library; the four batched GEMMs (Q K^T, P V and their
+    transposes) are plain library GEMMs (rocBLAS via torch.matmul), computed in fp32: the level has 16^3 voxels at 128^3 input, the
+    [N, heads, V, V] score tensor is 0.5 GB there."""
+
+    def __init__(self, net):
+        self.net = net
+        C = net.chs[-1]
+        self.C, self.H = C, net.n_attention_heads
+        self.qkv = Conv(C, 3 * C, 1)
+        self.proj = Conv(C, C, 1)
+        self.saved = None
+
+    def convs(self):
+        return [(self.qkv, "mid_attn.qkv.weight"), (self.proj, "mid_attn.proj.weight")]
+
+    def _heads(self, t):
+        """[N, V, C] -> [N, heads, V, hd] fp32 (contiguous)."""
+        N, V = t.shape[0], t.shape[1]
+        return t.reshape(N, V, self.H, self.C // self.H).permute(0, 2, 1, 3).float().contiguous()
+
+    def fwd(self, P, x, save):
+        G, C, H = self.net.norm_groups, self.C, self.H
+        N = x.shape[0]
+        V = x.numel() // (N * C)
+        st = ops.gn_stats(x, None, G)
+        xn = ops.gn_silu_fwd(x, None, G, st, P("mid_attn.norm.weight"), P("mid_attn.norm.bias"), linear=True)
+        qkv = self.qkv.fwd(xn, P("mid_attn.qkv.bias")).reshape(N, V, 3, C)
+        q, k, v = (self._heads(qkv[:, :, i]) for i in range(3))
+        scale = 1.0 / (C // H) ** 0.5
+        prob = ops.softmax_rows_(torch.matmul(q, k.transpose(-1, -2)), scale)            # [N, H, V, V] fp32
+        a = torch.matmul(prob, v).permute(0, 2, 1, 3).reshape(x.shape).to(x.dtype).contiguous()
+        out = self.proj.fwd(a, P("mid_attn.proj.bias"), None, x, gn=FUSED_GN)          # + residual; feeds mid.1's GroupNorm
+        if save:
+            self.saved = (x, st, xn, q, k, v, prob, a)
+        return out
+
+    def bwd(self, P, GP, dout, ss):
+        G, C, H = self.net.norm_groups, self.C, self.H
+        x, st, xn, q, k, v, prob, a = self.saved
+        self.saved = None
+        N = x.shape[0]
+        V = x.numel() // (N * C)
+        scale = 1.0 / (C // H) ** 0.5
+        ss.run(lambda: self.proj.wgrad(a, dout, GP("mid_attn.proj.weight")), a, dout)
+        ops.channel_sums(dout, GP("mid_attn.proj.bias"))
+        do = self._heads(self.proj.dgrad(dout).reshape(N, V, C))                          # [N, H, V, hd]
+        dv = torch.matmul(prob.transpose(-1, -2), do)
+        ds = ops.softmax_rows_bwd_(prob, torch.matmul(do, v.transpose(-1, -2)), scale)   # gradient w.r.t. q k^T
+        dq = torch.matmul(ds, k)
+        dk = torch.matmul(ds.transpose(-1, -2), q)
+        dqkv = torch.stack([t.permute(0, 2, 1, 3).reshape(N, V, C) for t in (dq, dk, dv)], dim=2)     # [N, V, 3, C]
+        dqkv = dqkv.to(x.dtype).reshape(*x.shape[:-1], 3 * C).contiguous()
+        ss.run(lambda: self.qkv.wgrad(xn, dqkv, GP("mid_attn.qkv.weight")), xn, dqkv)
+        ops.channel_sums(dqkv, GP("mid_attn.qkv.bias"))
+        dxn = self.qkv.dgrad(dqkv)
+        dx, _ = ops.gn_silu_bwd(x, None, G, st, P("mid_attn.norm.weight"), P("mid_attn.norm.bias"), dxn,
+                                GP("mid_attn.norm.weight"), GP("mid_attn.norm.bias"), add1=dout, linear=True)
+        return dx
+
+
 class GradBuckets:
     """Data-parallel gradient averaging overlapped with the backward pass: the flat gradient vector is
     completed from its end towards its start (CUNet parameter order = forward order), so each finished slice (CUNet.bucket_bounds:
@@ -210,6 +273,7 @@ class HipUNet:
         self.down = [Conv(chs[i], chs[i], 3, stride=2, circular=circ) for i in range(L - 1)]
         self.up = [Conv(chs[i + 1], chs[i], 3, upsample=1, circular=circ) for i in range(L - 1)]
         self.res = {b.name: _Res(net, b) for b in net.blocks}
+        self.attn = _Attn(net) if net.mid_attn else None
         self._packed_key = None
         self._pack_plan = None
         self.saved = None
@@ -223,6 +287,8 @@ class HipUNet:
             out.append((self.up[i], f"ups.{i}.up.weight"))
         for r in self.res.values():
             out.extend(r.convs())
+        if self.attn is not None:
+            out.extend(self.attn.convs())
         return out
 
     def pack_weights(self, flat, dtype, need_dgrad):
@@ -281,6 +347,8 @@ class HipUNet:
                 h = self.down[i].fwd(h, P(f"downs.{i}.down.bias"), gn=FUSED_GN)
         for j in range(2):
             h = self.res[f"mid.{j}"].fwd(P, h, None, table, train, p, seed + 100 + j, ss)
+            if j == 0 and self.attn is not None:
+                h = self.attn.fwd(P, h, train)
         coarse = []
         for i in reversed(range(L - 1)):
             coarse.append(h)
@@ -327,6 +395,8 @@ class HipUNet:
         self._bucket_ready(gflat, "ups", ss)       # norm_out / conv_out / every up block and up conv: final (RCCL starts on them)
         for j in reversed(range(2)):
             dh, _ = self.res[f"mid.{j}"].bwd(P, GP, dh, dtable, ss)
+            if j == 1 and self.attn is not None:
+                dh = self.attn.bwd(P, GP, dh, ss)
         self._bucket_ready(gflat, "mid", ss)
         for i in reversed(range(L)):
             if i == L - 2:

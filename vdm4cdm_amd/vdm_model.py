@@ -120,16 +120,7 @@ class VDM(nn.Module):
         return 0, 1
 
     def sample_times(self, B, device):
-        """D10 antithetic sampling t_i = (u0 + i/B) mod 1, stratified over the GLOBAL batch under data parallelism: every rank
-        seeds identically (seed_everything(42)), so u0 is the same on all ranks and rank r takes strata r*B .. r*B+B-1 of world*B -
-        the variance of the t-sampling shrinks with the world size instead of every rank drawing the same B times."""
-        rank, world = self._rank_world()
-        if self.antithetic_time_sampling:
-            u0 = torch.rand(1, device=device)
-            i = torch.arange(B, device=device, dtype=torch.float32) + rank * B
-            return torch.remainder(u0 + i / (world * B), 1.0)
-        t = torch.rand(world * B, device=device)
-        return t[rank * B:(rank + 1) * B]
+        return stratified_times(B, device, self.antithetic_time_sampling)
 
     def get_loss(self, x, times=None, eps=None, eps0=None, **kwargs):
         """Continuous-time ELBO in bits/dim.  Returns (loss, metrics dict)."""
@@ -265,80 +256,104 @@ class VDM(nn.Module):
         return torch.stack(zs, dim=0) if return_all else z
 
     def _sample_hip(self, z, n, noises, seed, verbose, use_graph, kwargs):
-        from . import hip_ops as ops
-        dev = z.device
-        coef = self.step_table(n).to(device=dev, dtype=torch.float32).contiguous()
-        step = torch.zeros(1, dtype=torch.int32, device=dev)
-        B = z.shape[0]
-        seed = int(torch.randint(0, 2 ** 62, (1,)).item()) if seed is None else int(seed)
-        noise_buf = torch.empty_like(z) if noises is not None else None
+        coef = self.step_table(n).to(device=z.device, dtype=torch.float32).contiguous()
+        cfg = self.w_cfg is not None and not self.training
+        if cfg:
+            assert "v_conditionings" in kwargs, "Need v_conditionings to mask out"
+        return hip_graph_sampler(self.score_model, z, coef, noises, seed, verbose, use_graph, kwargs.get("s_conditioning"),
+                                 list(kwargs.get("v_conditionings") or []), w_cfg=float(self.w_cfg) if cfg else None,
+                                 mask_fn=self.cfg_mask)
 
-        # The conditioning of every step is known up front: ONE K6 launch embeds all n time values (one table row per step), one more
-        # the vector conditionings; inside the step a single gather-add kernel builds the table (device-side step counter).
-        net = self.score_model
-        W = net.table_width
-        table_t = table_v = None
-        with torch.no_grad():
-            fl = net.flat.detach()
-            if net.t_conditioning:
-                table_t = ops.CondTable(net.cond_specs(coef[:, 3].contiguous(), None, fl, which="t"), n, W).forward(save=False)
-            vs = [v.to(device=dev, dtype=torch.float32).expand(B, -1).contiguous() for v in list(kwargs.get("v_conditionings") or [])]
-            cfg = self.w_cfg is not None and not self.training
-            if cfg:                                            # guided + v-masked rows of one batch-doubled forward (see _cfg_pair)
-                assert "v_conditionings" in kwargs, "Need v_conditionings to mask out"
-                vs = [torch.cat([v, m], dim=0).contiguous() for v, m in zip(vs, self.cfg_mask(vs))]
-            R = 2 * B if cfg else B                            # rows the UNet sees
-            if vs:
-                table_v = ops.CondTable(net.cond_specs(None, vs, fl, which="v"), R, W).forward(save=False)
-        s_cond = kwargs.get("s_conditioning")
-        if cfg and s_cond is not None:
-            s_cond = s_cond.to(dev).expand(B, *s_cond.shape[1:])
-            s_cond = torch.cat([s_cond, s_cond], dim=0).contiguous()
-        table = torch.zeros(R, W, device=dev)
-        zz = torch.empty(R, *z.shape[1:], device=dev) if cfg else z
-        from .unet_hip import hip_unet_apply
 
-        def one_step():
-            if table_t is not None or table_v is not None:
-                ops.cond_table_step(table_t, table_v, step, R, W, table)
-            if cfg:
-                zz[:B].copy_(z)
-                zz[B:].copy_(z)
-            eps_hat = hip_unet_apply(net, zz, s_cond, table=table).contiguous()
-            if cfg:                                            # blend inside K9: the guided estimate is never materialised
-                ops.ancestral_step(z, eps_hat[:B], noise_buf, coef, step, seed, eps_uncond=eps_hat[B:], w_cfg=float(self.w_cfg))
-            else:
-                ops.ancestral_step(z, eps_hat, noise_buf, coef, step, seed)
-            ops.step_inc(step)
+def hip_graph_sampler(net, z, coef, noises, seed, verbose, use_graph, s_cond, v_conditionings, w_cfg=None, mask_fn=None):
+    """The multi-step sampling loop on the HIP backend, shared by the VDM ancestral sampler and the SFM Euler integrator: per step
+    [conditioning-table row gather, UNet forward, fused update z <- ratio * (z - cs * net_out) + scale * noise, step counter + 1],
+    captured once in a hipGraph and replayed; coef[n][4] = {ratio, cs, scale, network time} is read on the device at the row of the
+    device-side step counter.  z is updated in place and returned."""
+    from . import hip_ops as ops
+    from .unet_hip import hip_unet_apply
+    dev = z.device
+    n = coef.shape[0]
+    step = torch.zeros(1, dtype=torch.int32, device=dev)
+    B = z.shape[0]
+    seed = int(torch.randint(0, 2 ** 62, (1,)).item()) if seed is None else int(seed)
+    noise_buf = torch.empty_like(z) if noises is not None else None
 
-        graph = None
-        if use_graph and n > 2:
-            # warm-up on a side stream (packs weights, sizes the allocator), then capture one step
-            side = torch.cuda.Stream(device=dev)
-            z_keep = z.clone()
-            side.wait_stream(torch.cuda.current_stream(dev))
-            with torch.cuda.stream(side):
-                if noise_buf is not None:
-                    noise_buf.copy_(noises[0].to(z))
-                one_step()
-            torch.cuda.current_stream(dev).wait_stream(side)
-            z.copy_(z_keep)
-            step.zero_()
-            graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(graph):
-                one_step()
-            z.copy_(z_keep)             # capture does not execute, but keep the state explicit
-            step.zero_()
-        for i in range(n):
+    # The conditioning of every step is known up front: ONE K6 launch embeds all n time values (one table row per step), one more
+    # the vector conditionings; inside the step a single gather-add kernel builds the table (device-side step counter).
+    W = net.table_width
+    table_t = table_v = None
+    cfg = w_cfg is not None
+    with torch.no_grad():
+        fl = net.flat.detach()
+        if net.t_conditioning:
+            table_t = ops.CondTable(net.cond_specs(coef[:, 3].contiguous(), None, fl, which="t"), n, W).forward(save=False)
+        vs = [v.to(device=dev, dtype=torch.float32).expand(B, -1).contiguous() for v in v_conditionings]
+        if cfg:                                            # guided + v-masked rows of one batch-doubled forward (VDM._cfg_pair)
+            vs = [torch.cat([v, m], dim=0).contiguous() for v, m in zip(vs, mask_fn(vs))]
+        R = 2 * B if cfg else B                            # rows the UNet sees
+        if vs:
+            table_v = ops.CondTable(net.cond_specs(None, vs, fl, which="v"), R, W).forward(save=False)
+    if cfg and s_cond is not None:
+        s_cond = s_cond.to(dev).expand(B, *s_cond.shape[1:])
+        s_cond = torch.cat([s_cond, s_cond], dim=0).contiguous()
+    table = torch.zeros(R, W, device=dev)
+    zz = torch.empty(R, *z.shape[1:], device=dev) if cfg else z
+
+    def one_step():
+        if table_t is not None or table_v is not None:
+            ops.cond_table_step(table_t, table_v, step, R, W, table)
+        if cfg:
+            zz[:B].copy_(z)
+            zz[B:].copy_(z)
+        eps_hat = hip_unet_apply(net, zz, s_cond, table=table).contiguous()
+        if cfg:                                            # blend inside K9: the guided estimate is never materialised
+            ops.ancestral_step(z, eps_hat[:B], noise_buf, coef, step, seed, eps_uncond=eps_hat[B:], w_cfg=w_cfg)
+        else:
+            ops.ancestral_step(z, eps_hat, noise_buf, coef, step, seed)
+        ops.step_inc(step)
+
+    graph = None
+    if use_graph and n > 2:
+        # warm-up on a side stream (packs weights, sizes the allocator), then capture one step
+        side = torch.cuda.Stream(device=dev)
+        z_keep = z.clone()
+        side.wait_stream(torch.cuda.current_stream(dev))
+        with torch.cuda.stream(side):
             if noise_buf is not None:
-                noise_buf.copy_(noises[i].to(z))
-            if graph is not None:
-                graph.replay()
-            else:
-                one_step()
-            if verbose and (i % 50 == 0 or i == n - 1):
-                print(f"sampling: {i + 1}/{n}", flush=True)
-        return z
+                noise_buf.copy_(noises[0].to(z))
+            one_step()
+        torch.cuda.current_stream(dev).wait_stream(side)
+        z.copy_(z_keep)
+        step.zero_()
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph):
+            one_step()
+        z.copy_(z_keep)             # capture does not execute, but keep the state explicit
+        step.zero_()
+    for i in range(n):
+        if noise_buf is not None:
+            noise_buf.copy_(noises[i].to(z))
+        if graph is not None:
+            graph.replay()
+        else:
+            one_step()
+        if verbose and (i % 50 == 0 or i == n - 1):
+            print(f"sampling: {i + 1}/{n}", flush=True)
+    return z
+
+
+def stratified_times(B, device, antithetic=True):
+    """D10 antithetic sampling t_i = (u0 + i/B) mod 1, stratified over the GLOBAL batch under data parallelism: every rank
+    seeds identically (seed_everything(42)), so u0 is the same on all ranks and rank r takes strata r*B .. r*B+B-1 of world*B -
+    the variance of the t-sampling shrinks with the world size instead of every rank drawing the same B times."""
+    rank, world = VDM._rank_world()
+    if antithetic:
+        u0 = torch.rand(1, device=device)
+        i = torch.arange(B, device=device, dtype=torch.float32) + rank * B
+        return torch.remainder(u0 + i / (world * B), 1.0)
+    t = torch.rand(world * B, device=device)
+    return t[rank * B:(rank + 1) * B]
 
 
 class LightVDM(nn.Module):
