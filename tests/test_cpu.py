@@ -237,8 +237,8 @@ def test_hip_backend_refuses_cpu_and_2d():
     net2 = CUNet(shape=(1, 8, 8), chs=[8, 16], norm_groups=4, backend="hip")
     with pytest.raises(NotImplementedError):
         net2(torch.zeros(1, 1, 8, 8), t=torch.zeros(1))
-    with pytest.raises(NotImplementedError):
-        CUNet(shape=(1, 8, 8, 8), chs=[8, 16], mid_attn=True)
+    with pytest.raises(AssertionError, match="n_attention_heads"):
+        CUNet(shape=(1, 8, 8, 8), chs=[8, 18], mid_attn=True, n_attention_heads=4)
 
 
 def test_c1_config_trains_on_cpu():
