@@ -648,3 +648,28 @@ def test_softmax_rows_and_channel_sums():
         ops.channel_sums(xd, out)
         ref = xd.float().cpu().reshape(-1, 32).sum(0)
         assert (out.cpu() - ref).abs().max().item() <= 1e-4 * ref.abs().max().item() + 1e-4
+
+
+def test_gn_stats_from_many_tile_partials():
+    """Many tiles per sample (level-0 sizes: more than one sweep of the reducing workgroup): statistics from the per-tile partials vs
+    a float64 sum of the same partials; bit-reproducible; two-source form."""
+    from vdm4cdm_amd import hip_ops as ops
+    G = 8
+    for N, shape, c in ((1, (64, 64, 128), 32), (2, (128, 64, 64), 32), (1, (64, 64, 64), 64)):
+        conv = ops.Conv(c, c, 3)
+        g = torch.Generator().manual_seed(N + c)
+        conv.pack((torch.randn(27, c, c, generator=g) * 0.05).to(DEV), torch.bfloat16, need_dgrad=False)
+        x = torch.randn(N, *shape, c, generator=g).to(DEV).to(torch.bfloat16)
+        out = conv.fwd(x, gn=True)
+        part = out.gn_partials                                 # [N, tiles, C, 2] fp32
+        assert part.shape[1] > (256 // (c // G)) * 8, "more tiles than one sweep of the reducing workgroup"
+        st = ops.gn_stats(out, None, G, chsum=True)
+        ref = part.double().sum(dim=1).reshape(N, G, c // G, 2).sum(dim=2)
+        assert ((st.double() - ref).abs() <= 2e-6 * ref.abs() + 1e-3).all()
+        assert ((st.chsum.double() - part[..., 0].double().sum(dim=1)).abs() <= 2e-6 * part[..., 0].double().sum(dim=1).abs() + 1e-3).all()
+        for _ in range(3):
+            assert torch.equal(ops.gn_stats(out, None, G), st)
+        two = ops.gn_stats(out, out, G)                        # two sources: two launches back to back;
+        gs2 = 2 * c // G                                       # concat(out, out) in G groups of 2c / G channels
+        ref2 = torch.cat([part, part], dim=2).double().sum(dim=1).reshape(N, G, gs2, 2).sum(dim=2)
+        assert ((two.double() - ref2).abs() <= 2e-6 * ref2.abs() + 1e-3).all()
