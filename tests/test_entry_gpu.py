@@ -170,6 +170,51 @@ def test_hip_training_step_under_rccl_world1(tmp_path):
     assert torch.equal(outs["1"]["flat"], outs[""]["flat"]), "bucketed all-reduce changed the result of a world-1 step"
 
 
+def _spawn_ranks(cmd, world, port, tmp_path, extra_env=None, timeout=900):
+    """world processes with the torchrun environment, all on GPU 0 over gloo (VDM4CDM_SHARE_GPU / VDM4CDM_DIST_BACKEND)."""
+    procs = []
+    for rank in range(world):
+        env = dict(os.environ, RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                   VDM4CDM_SHARE_GPU="1", VDM4CDM_DIST_BACKEND="gloo", **(extra_env or {}))
+        procs.append(subprocess.Popen(cmd, env=env, cwd=ROOT, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
+    outs = [p.communicate(timeout=timeout) for p in procs]
+    for p, (so, se) in zip(procs, outs):
+        assert p.returncode == 0, so[-2000:] + se[-4000:]
+    return outs
+
+
+def test_hip_training_two_ranks_share_one_gpu(tmp_path):
+    """SURVEY 8e with HIP kernels AND a world-2 process group in the same processes (two ranks on the one GPU of the box, gloo):
+    weights are broadcast from rank 0, each rank draws its own data shard / noise, the backward all-reduces the four gradient buckets
+    on the communication stream, and after 3 steps both ranks hold bit-identical parameters that differ from a single-rank run."""
+    import socket
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    _spawn_ranks([sys.executable, os.path.join(ROOT, "tests", "_ddp_gpu2_worker.py"), str(tmp_path)], 2, port, tmp_path)
+    o0, o1 = torch.load(tmp_path / "out0.pt"), torch.load(tmp_path / "out1.pt")
+    assert o0["world"] == o1["world"] == 2 and o0["bucketed"] and o1["bucketed"]
+    assert torch.isfinite(o0["flat"]).all() and torch.equal(o0["flat"], o1["flat"]), "ranks diverged"
+    assert o0["loss"] != o1["loss"], "both ranks saw the same batch / noise"
+
+
+def test_bench_two_ranks_share_one_gpu(tmp_path):
+    """bench.py under the torchrun contract with N = 2 (rehearsal on one GPU): one JSON line from rank 0, aggregate voxels/s over both
+    ranks, weak scaling."""
+    import json
+    import socket
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    outs = _spawn_ranks([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--config", "tiny", "--steps", "4", "--warmup", "2",
+                         "--no-cpu-baseline", "--sample-steps", "0"], 2, port, tmp_path)
+    lines = [ln for so, _ in outs for ln in so.strip().splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, "exactly rank 0 prints the line"
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["config"]["global_batch"] == 4 and d["config"]["parallelism"] == "dp2"
+    assert d["value"] == pytest.approx(2 * 2 * 32 ** 3 / (d["ms_per_step"] * 1e-3), rel=1e-6)
+
+
 def _ss_cases():
     import importlib.util
     spec = importlib.util.spec_from_file_location("test_entry_cpu_mod", os.path.join(ROOT, "tests", "test_entry_cpu.py"))

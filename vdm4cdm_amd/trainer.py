@@ -24,11 +24,18 @@ def init_distributed(device_type):
     if world > 1 and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
-        backend = "nccl" if device_type == "cuda" else "gloo"
+        backend = os.environ.get("VDM4CDM_DIST_BACKEND") or ("nccl" if device_type == "cuda" else "gloo")
         if device_type == "cuda":
-            torch.cuda.set_device(local_rank)
+            torch.cuda.set_device(local_device_index(local_rank))
         dist.init_process_group(backend=backend, rank=rank, world_size=world)
-    return rank, local_rank, world
+    return rank, local_device_index(local_rank) if device_type == "cuda" else local_rank, world
+
+
+def local_device_index(local_rank):
+    """GPU of this rank: its LOCAL_RANK - or 0 for every rank under VDM4CDM_SHARE_GPU=1, the rehearsal mode that runs the N > 1 code
+    path (shards, gradient buckets, barriers) with several ranks on ONE GPU (use VDM4CDM_DIST_BACKEND=gloo there: RCCL refuses two
+    ranks on the same device)."""
+    return 0 if os.environ.get("VDM4CDM_SHARE_GPU") == "1" else local_rank
 
 
 def allreduce_mean_(t, world):
