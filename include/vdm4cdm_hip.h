@@ -125,6 +125,7 @@ int vdm_conv_dgrad_gn(const vdm_conv_desc* d, const void* dout, const void* w_pa
 #define VDM_CONV_VARIANT_GENERIC 0
 #define VDM_CONV_VARIANT_CLASS 1
 #define VDM_CONV_VARIANT_SPLIT 3 /* generic kernel, half-chunk workgroups (64-cout chunks on a small grid) */
+#define VDM_CONV_VARIANT_KSPLIT 4 /* deepest level: the waves of a workgroup split the K-blocks, one weight fetch per workgroup */
 #define VDM_CONV_VARIANT_KPACK 2 /* <= 8 reduction channels (conv_in, conv_out's input gradient): 4 taps per MFMA K-step */
 int vdm_conv_kernel_variant(const vdm_conv_desc* d, int dgrad);
 

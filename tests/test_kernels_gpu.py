@@ -84,6 +84,10 @@ CONV_CASES = [
     ("k1_32_128", 1, (4, 8, 12), 32, 128, 1, 1, 0, False),
     ("k3_16_16", 1, (8, 8, 16), 16, 16, 3, 1, 0, False),
     ("k3_48_96", 1, (4, 8, 16), 48, 96, 3, 1, 0, False),
+    # deepest level: the K-split kernel (waves of a workgroup split the K-blocks; bf16, >= 4 K-blocks, 64-cout chunks, 1 x TY x 16 tiles)
+    ("k3_deep_256_256", 1, (16, 16, 16), 256, 256, 3, 1, 0, False),    # 8 K-blocks (2 per wave), 1x4x16 tiles, the level-3 conv at batch 1
+    ("k3_deep_160_128_circ", 2, (3, 6, 20), 160, 128, 3, 1, 0, True),  # 5 K-blocks (2,1,1,1 per wave), ragged tiles, circular
+    ("k3_deep_256_64", 2, (8, 16, 16), 256, 64, 3, 1, 0, False),       # 1x8x16 tiles (8 rows per wave in the main loop)
 ]
 
 
@@ -184,7 +188,7 @@ def test_conv_large(case):
         assert err_a <= conv_tol(dtype, xr.grad + acc_in), f"{name}: dgrad+residual err {err_a}"
 
 
-GN_FUSED_CASES = [c for c in CONV_CASES if c[0] in ("k3_32_32", "k3_32_32_ragged", "k3_64_32", "k3_128_256", "k3_cin2pad", "k3_cin8_circ", "k3_cin3_ragged", "k3_mid_64_64", "k3_mid_32_128", "k3_mid_128_64", "k3_mid_64_128", "k3_big_64_64", "k3_ups", "k3_ups_circ", "k3_ups_ragged", "k3_ups_128_64", "k3_circ_small",
+GN_FUSED_CASES = [c for c in CONV_CASES if c[0] in ("k3_deep_256_256", "k3_deep_160_128_circ", "k3_deep_256_64", "k3_32_32", "k3_32_32_ragged", "k3_64_32", "k3_128_256", "k3_cin2pad", "k3_cin8_circ", "k3_cin3_ragged", "k3_mid_64_64", "k3_mid_32_128", "k3_mid_128_64", "k3_mid_64_128", "k3_big_64_64", "k3_ups", "k3_ups_circ", "k3_ups_ragged", "k3_ups_128_64", "k3_circ_small",
                                                       "k3_s2", "k3_s2_ragged", "k1_64_32", "k3_16_16", "k3_48_96")] + LARGE_CASES[:2]
 
 
@@ -385,6 +389,8 @@ FOLD_CASES = [  # name, N, (D,H,W), producer cin, c1, c2 (GroupNorm over c1+c2 c
     ("c16", 1, (8, 8, 16), 16, 16, 0, 32, 8, 0.1, False),             # NC=1 lanes (4 channels: half a bf16 piece)
     ("out_1", 2, (8, 8, 16), 32, 32, 0, 1, 8, 0.0, False),            # conv_out: 1 output channel -> tap-packed dgrad kernel
     ("concat_16", 1, (4, 8, 16), 16, 16, 16, 16, 8, 0.0, False),      # 32-channel concat of 16 + 16 (NC=2 lanes)
+    ("deep_256", 1, (4, 8, 16), 64, 256, 0, 256, 8, 0.1, False),      # K-split kernel (8 K-blocks) with the folded epilogue
+    ("deep_concat", 2, (8, 8, 16), 64, 64, 64, 192, 8, 0.0, False),   # K-split (6 K-blocks), two-source GroupNorm, 1x8x16 tiles
 ]
 
 

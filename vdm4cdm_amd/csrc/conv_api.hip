@@ -351,9 +351,10 @@ extern "C" int vdm_conv_kernel_variant(const vdm_conv_desc* d, int dgrad) {
         if (p.nc == 4) {
             ConvArgs a{};
             a.N = d->n; a.Dz = d->od; a.Dy = d->oh; a.Dx = d->ow;         // (dgrad of a stride-1 conv runs on the output grid too)
-            a.Cout = p.O; a.nchunks = p.nchunks;
+            a.Cout = p.O; a.nchunks = p.nchunks; a.nkb = p.nkb;
             int tz, ty;
             small_grid_tile(a, tz, ty);
+            if (d->stride == 1 && ksplit_tile(a, tz, ty)) return VDM_CONV_VARIANT_KSPLIT;
             if (uses_split(a, tz, ty)) return VDM_CONV_VARIANT_SPLIT;
         }
     }

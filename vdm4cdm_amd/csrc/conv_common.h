@@ -111,13 +111,14 @@ static __device__ uint4 g_zero_page[16];
 // 32-bit integer multiplies are quarter rate).  The host checks that a sample's elements fit 32 bits.
 // ss / so*: logical voxel i maps to source voxel ss * i + so (class sub-grid of the per-parity-class kernels when ss == 2);
 // sD*: source tensor dims.
-template <typename T, typename G, int UPS>
+// NWAVES: waves that share the chunks (4: all waves of a workgroup; 1: a wave stages a private image - conv_ksplit_kernel).
+template <typename T, typename G, int UPS, int NWAVES = 4>
 __device__ __forceinline__ void stage_halo_dma_gen(char* lds, const T* __restrict__ x, const ConvArgs& a, int n, int oz0, int oy0,
                                                    int ox0, int kb, int wave, int lane, int ss, int soz, int soy, int sox, int sDz,
                                                    int sDy, int sDx) {
     constexpr int EPL = DT<T>::EPL, KB = DT<T>::KB;
     constexpr int NCHUNK = (G::HVOX + 15) / 16;
-    constexpr int STEP = 64;                                // halo voxels between two chunks of one wave (4 waves x 16)
+    constexpr int STEP = 16 * NWAVES;                       // halo voxels between two chunks of one wave
     constexpr int DX = STEP % G::HX, DY = (STEP / G::HX) % G::HY, DZ = STEP / (G::HX * G::HY);
     const int iz0 = oz0 * G::STRIDE - G::PAD, iy0 = oy0 * G::STRIDE - G::PAD, ix0 = ox0 * G::STRIDE - G::PAD;
     const int k = lane >> 2, j = lane & 3;
@@ -125,7 +126,7 @@ __device__ __forceinline__ void stage_halo_dma_gen(char* lds, const T* __restric
     int hx = hv0 % G::HX, hy = (hv0 / G::HX) % G::HY, hz = hv0 / (G::HX * G::HY);
     const T* xn = x + (size_t)n * ((size_t)sDz * sDy * sDx * a.CinStride);
     const bool fastwrap = a.Iz >= G::HZ && a.Iy >= G::HY && a.Ix >= G::HX;      // one conditional add / subtract wraps
-    for (int c = wave; c < NCHUNK; c += 4) {
+    for (int c = wave; c < NCHUNK; c += NWAVES) {
         const int pc = j ^ ((hx >> 1) & 3);
         const int ci = kb * KB + pc * EPL;
         int iz = iz0 + hz, iy = iy0 + hy, ix = ix0 + hx;
@@ -847,6 +848,18 @@ static bool uses_split(const ConvArgs& a, int tz, int ty) {
     return tz <= 2 && wgs < 2LL * cu_count() && a.Cout % 64 == 0 && getenv("VDM4CDM_NO_SPLIT") == nullptr;
 }
 
+// K-split kernel of the deepest levels (conv_fwd.hip, conv_ksplit_kernel): bf16 3x3x3 stride-1 convs with >= 4 K-blocks and 64-cout
+// chunks whose grid is small enough for small_grid_tile() to leave the 4x8x16 tile.  Takes the (tz, ty) small_grid_tile chose and
+// returns the tile the K-split kernel uses (1 x ty x 16; a 2x8x16 choice becomes 1x8x16).  VDM4CDM_KSPLIT: 0 off, 1 (default) only
+// where the generic choice was a 1 x ty x 16 tile (level 3 of the 128^3 network), 2 also the 2x8x16 grids (level 2: measured SLOWER
+// there - 0.078 vs 0.054 ms at batch 2 - one workgroup per CU loses more than the saved weight traffic gains).
+static bool ksplit_tile(const ConvArgs& a, int& tz, int& ty) {
+    static const int level = getenv("VDM4CDM_KSPLIT") ? atoi(getenv("VDM4CDM_KSPLIT")) : 1;
+    if (level <= 0 || a.nkb < 4 || a.Cout % 64 != 0 || tz > 2 || (tz == 2 && level < 2)) return false;
+    if (tz == 2) { tz = 1; ty = 8; }
+    return true;
+}
+
 static bool uses_kpack(int dtype, int ks, int stride, int ups, int K, int O, int out_f32) {
     return dtype == VDM_BF16 && ks == 3 && stride == 1 && !ups && K <= 8 && O <= 32 && !out_f32 && getenv("VDM4CDM_NO_KPACK") == nullptr;
 }
@@ -915,7 +928,10 @@ static void fwd_tile_shape(const ConvArgs& a, int dtype, int out_f32, int ks, in
     tz = 4; ty = 8;
     if (stride == 2) { tz = 2; ty = 4; return; }
     if (uses_kpack(dtype, ks, stride, ups, a.Cin, a.Cout, out_f32)) return;
-    if (ks == 3 && dtype == VDM_BF16) small_grid_tile(a, tz, ty);
+    if (ks == 3 && dtype == VDM_BF16) {
+        small_grid_tile(a, tz, ty);
+        if (stride == 1 && !ups && !out_f32) ksplit_tile(a, tz, ty);
+    }
 }
 
 // launchers (defined in conv_fwd.hip / conv_cls.hip / conv_wgrad.hip)

@@ -96,6 +96,92 @@ __global__ void __launch_bounds__(256, (TZ * TY <= 16 && NC <= 2) ? 3 : 2) conv_
 }
 
 // ---------------------------------------------------------------------------------------------
+// K-split kernel for the deepest level (bf16, 3x3x3, stride 1, >= 4 K-blocks, 64-cout chunks, 1 x TY x 16 tiles) - conv_ksplit_kernel.
+//
+// What the generic kernel does there (tools/conv_timeline.py, 16^3 voxels x 256 channels, batch 1): 512 workgroups of 64 voxels x 32
+// couts live 41 us each for 0.44 us of MFMA work per K-block - 8 K-block rounds (stage, barrier, 27 taps of 2 MFMAs), and every one
+// of the four waves fetches the SAME 55 KB of weights per round: 3.9 MB through the vector L1 of a CU per launch = 92 GB/s of its
+// 134 GB/s fill rate, for a conv with 3.5 MB of weights and 2 MB of activations.
+// Here the four waves of a workgroup split the K-blocks instead of the voxel rows: wave w stages K-blocks w, w+4, ... into its
+// PRIVATE LDS image (no workgroup barrier in the main loop: four independent pipelines hide each other's DMA latency), accumulates
+// the whole tile (all TY rows x NC cout tiles) over them - so a weight fragment is fetched ONCE per workgroup - and the partial
+// accumulators are summed across the waves through LDS in a fixed order.  The epilogue is the generic one (wave w owns rows
+// w*TY/4 ...), incl. the folded GroupNorm backward.  One workgroup per CU (4 x 21 KB images at TY = 4).
+// ---------------------------------------------------------------------------------------------
+template <typename T, typename TO, int NC, int TY, bool GNB>
+__global__ void __launch_bounds__(256, 1) conv_ksplit_kernel(const ConvArgs a) {
+    static_assert(sizeof(T) == 2 && sizeof(TO) == 2 && (TY == 4 || TY == 8), "bf16, 1 x 4 x 16 or 1 x 8 x 16 tiles");
+    using G = Geo<3, 1, 1, TY>;
+    constexpr int NVT = G::ROWS;                          // rows a wave accumulates (the whole tile)
+    constexpr int NVE = G::NV;                            // rows a wave owns in the epilogue
+    constexpr int TAPS = G::TAPS, NCW = 4, WPD = NC == 4 ? 4 : 6;
+    constexpr int IMG = ((G::HVOX + 15) / 16) * 1024;
+    static_assert(NVT * NC * 1024 <= IMG, "the reduction buffer of a wave must fit its image");
+    extern __shared__ __attribute__((aligned(16))) char lds[];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+
+    int b = xcd_remap(blockIdx.x, gridDim.x);
+    const int tx = b % a.ntx; b /= a.ntx;
+    const int ty = b % a.nty; b /= a.nty;
+    const int tz = b % a.ntz; b /= a.ntz;
+    const int n = b % a.N;
+    const int chunk = b / a.N;
+    const int oz0 = tz, oy0 = ty * TY, ox0 = tx * 16;
+    const int cout0 = chunk * NC * 16, qstride = NC * 4;
+
+    f32x4 acc[NVT][NC];
+#pragma unroll
+    for (int v = 0; v < NVT; ++v)
+#pragma unroll
+        for (int c = 0; c < NC; ++c) acc[v][c] = f32x4{0.f, 0.f, 0.f, 0.f};
+    int lanex[3];
+    operand_lane_offsets<G, NVT>(lanex, 0, lane);         // every wave walks all rows of the tile
+    const uint4* wbase = reinterpret_cast<const uint4*>(a.w) + (size_t)chunk * a.nkb * TAPS * NCW * 64 + lane;
+    const T* x = reinterpret_cast<const T*>(a.x);
+    GnbRegs<T, NC, GNB ? NVE : 1> gr;
+    if constexpr (GNB && NC <= 2) gnb_issue<T, G, NC, NVE>(gr, a, n, oz0, oy0, ox0, wave, lane, cout0, qstride);
+    float badd[NC * 4];
+    if constexpr (!GNB) load_badd<NC>(badd, a, n, cout0 + (lane >> 4) * qstride);
+
+    char* image = lds + wave * IMG;
+    for (int kb = wave; kb < a.nkb; kb += 4) {
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                      // (the previous round's operand reads have returned)
+        stage_halo_dma_gen<T, G, 0, 1>(image, x, a, n, oz0, oy0, ox0, kb, 0, lane, 1, 0, 0, 0, a.Sz, a.Sy, a.Sx);
+        const uint4* wk = wbase + (size_t)kb * TAPS * NCW * 64;
+        uint4 wf[WPD + 1][NC];
+        rr_prefetch_weights<NC, WPD, NCW>(wf, wk);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                        // this wave's own DMA has landed: no barrier needed
+        taps_rowreuse<T, G, NC, NVT, WPD, NCW>(acc, image, wk, wf, lanex);
+    }
+    // sum the partial accumulators of the four waves (fixed order: deterministic); wave w keeps rows w * NVE ... for the epilogue
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __syncthreads();                                                            // every wave is done with its image
+    f32x4* red = reinterpret_cast<f32x4*>(lds);
+#pragma unroll
+    for (int v = 0; v < NVT; ++v)
+#pragma unroll
+        for (int c = 0; c < NC; ++c) red[(size_t)wave * (IMG / 16) + (v * NC + c) * 64 + lane] = acc[v][c];
+    __syncthreads();
+    f32x4 tot[NVE][NC];
+#pragma unroll
+    for (int e = 0; e < NVE; ++e)
+#pragma unroll
+        for (int c = 0; c < NC; ++c) {
+            const int off = ((wave * NVE + e) * NC + c) * 64 + lane;
+            const f32x4 p0 = red[off], p1 = red[(IMG / 16) + off], p2 = red[2 * (IMG / 16) + off], p3 = red[3 * (IMG / 16) + off];
+            tot[e][c] = (p0 + p1) + (p2 + p3);
+        }
+    float* gn_sm = reinterpret_cast<float*>(lds + 4 * IMG);
+    const int tile = (tz * a.nty + ty) * a.ntx + tx;
+    if constexpr (GNB)
+        conv_epilogue_gnb<T, G, NC, NVE, (NC <= 2)>(tot, a, gr, n, oz0, oy0, ox0, wave, lane, gn_sm, tile, cout0, qstride);
+    else
+        conv_epilogue<T, TO, G, NC, NVE>(tot, a, badd, n, oz0, oy0, ox0, wave, lane, gn_sm, tile, cout0, qstride);
+}
+
+// ---------------------------------------------------------------------------------------------
 // Tap-packed kernel for the convs with <= 8 input channels (conv_in: 2 -> 32; input gradient of conv_out: 1 -> 32), bf16.
 // One 16-byte piece holds ALL channels of a voxel, so the 32-deep K of an MFMA is filled with 4 TAPS x 8 channels instead of
 // one tap x 32 channels of which 24..31 are padding: 7 tap groups instead of 27 taps (3.9x fewer MFMAs), an LDS image of
@@ -228,6 +314,25 @@ static int launch_fwd_cfg(const ConvArgs& a0, hipStream_t s) {
     return VDM_OK;
 }
 
+template <typename T, typename TO, int NC, int TY, bool GNB>
+static int launch_ksplit(const ConvArgs& a0, hipStream_t s) {
+    using G = Geo<3, 1, 1, TY>;
+    ConvArgs a = a0;
+    a.ntz = a.Dz; a.nty = cdiv(a.Dy, TY); a.ntx = cdiv(a.Dx, 16);
+    const size_t lds = 4 * (size_t)((G::HVOX + 15) / 16) * 1024 + GN_SCRATCH_BYTES;
+    auto kern = conv_ksplit_kernel<T, TO, NC, TY, GNB>;
+    static unsigned long long lds_done = 0;
+    {
+        int e = set_lds(kern, lds, lds_done);
+        if (e) return e;
+    }
+    const long long nwg = (long long)a.N * a.ntz * a.nty * a.ntx * a.nchunks;
+    if (nwg > 0x7fffffffLL) { set_error("conv: grid too large"); return VDM_ERR_ARG; }
+    hipLaunchKernelGGL(kern, dim3((unsigned)nwg), dim3(256), lds, s, a);
+    VDM_LAUNCH_CHECK("conv_ksplit_kernel");
+    return VDM_OK;
+}
+
 template <typename T, typename TO, int KS, int STRIDE, int UPS, int NC, bool GNB = false>
 static int launch_fwd_geo(const ConvArgs& a, hipStream_t s) {
     if constexpr (STRIDE == 2)
@@ -236,6 +341,7 @@ static int launch_fwd_geo(const ConvArgs& a, hipStream_t s) {
         int tz, ty;
         small_grid_tile(a, tz, ty);
         if constexpr (NC == 4 && UPS == 0 && sizeof(TO) == 2) {
+            if (ksplit_tile(a, tz, ty)) return ty == 4 ? launch_ksplit<T, TO, 4, 4, GNB>(a, s) : launch_ksplit<T, TO, 4, 8, GNB>(a, s);
             if (uses_split(a, tz, ty)) {
                 if (tz == 1) return ty == 4 ? launch_fwd_cfg<T, TO, KS, STRIDE, UPS, 2, 1, 4, true, GNB>(a, s) : launch_fwd_cfg<T, TO, KS, STRIDE, UPS, 2, 1, 8, true, GNB>(a, s);
                 return launch_fwd_cfg<T, TO, KS, STRIDE, UPS, 2, 2, 8, true, GNB>(a, s);

@@ -194,6 +194,8 @@ class Conv:
                 key = "conv_kpack_kernel"
             elif L.vdm_conv_kernel_variant(d, 0) == 3:
                 key = f"conv_fwd_kernel<{_tname(x.dtype)},k3,s1,NC2,split>"
+            elif L.vdm_conv_kernel_variant(d, 0) == 4:
+                key = f"conv_ksplit_kernel<{_tname(x.dtype)},NC4>"
             else:
                 key = f"conv_fwd_kernel<{_tname(x.dtype)},k{self.ksize},s{self.stride},NC{_nc_for(self.cout, x.dtype)}>"
             alg = 2.0 * nvox * self.ksize ** 3 * self.cin * self.cout
@@ -229,6 +231,8 @@ class Conv:
                 key = "conv_kpack_kernel"
             elif L.vdm_conv_kernel_variant(d, 1) == 3:
                 key = f"conv_fwd_kernel<{_tname(dout.dtype)},k3,s1,NC2,split>"
+            elif L.vdm_conv_kernel_variant(d, 1) == 4:
+                key = f"conv_ksplit_kernel<{_tname(dout.dtype)},NC4>"
             else:
                 key = f"conv_fwd_kernel<{_tname(dout.dtype)},k{self.ksize},s1,NC{_nc_for(self.cin, dout.dtype)}>"
             alg = 2.0 * nvox * self.ksize ** 3 * self.cin * self.cout
@@ -272,7 +276,8 @@ class Conv:
             es = dout.element_size()
             var = L.vdm_conv_kernel_variant(d, 1)
             key = "conv_kpack_kernel" if var == 2 else (f"conv_fwd_kernel<{_tname(dout.dtype)},k3,s1,NC2,split>" if var == 3 else
-                                                        f"conv_fwd_kernel<{_tname(dout.dtype)},k3,s1,NC{_nc_for(self.cin, dout.dtype)}>")
+                                                        (f"conv_ksplit_kernel<{_tname(dout.dtype)},NC4>" if var == 4 else
+                                                         f"conv_fwd_kernel<{_tname(dout.dtype)},k3,s1,NC{_nc_for(self.cin, dout.dtype)}>"))
             _pe(ev, key + "+gnb", 2.0 * n * od * oh * ow * 27 * self.cin * self.cout, dout.numel() * es + 2 * out.numel() * es)
         return out
 
