@@ -107,10 +107,17 @@ def test_astro_datamodule_rank_shards_are_disjoint_and_complete(tmp_path):
     for rank in range(2):
         dm = data.get_dataset(dataset_name="CMD_128", stage="fit", batch_size=2, cropsize=8, data_root=root, seed=5)
         picked = []
-        dm.draw_sample = lambda idx, train, picked=picked: picked.append(idx) or idx
+        real_draw = dm.draw_sample
+        dm.draw_sample = lambda idx, train, picked=picked, real_draw=real_draw: picked.append(idx) or real_draw(idx, train)
         dm.make_batch = lambda samples: {}                    # (record instead of launching)
-        for _ in dm.train_dataloader(rank, 2):
-            pass
-        seen.append(picked)
-    assert not set(seen[0]) & set(seen[1])
-    assert sorted(seen[0] + seen[1]) == sorted(dm.train_idx)
+        epochs = []
+        for _ in range(3):                                    # the shards must stay disjoint epoch after epoch
+            del picked[:]
+            for _ in dm.train_dataloader(rank, 2):
+                pass
+            epochs.append(list(picked))
+        seen.append(epochs)
+    for e in range(3):
+        assert not set(seen[0][e]) & set(seen[1][e]), f"epoch {e}: ranks overlap"
+        assert sorted(seen[0][e] + seen[1][e]) == sorted(dm.train_idx)
+    assert seen[0][0] != seen[0][1], "epochs are reshuffled"

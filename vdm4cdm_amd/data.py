@@ -191,7 +191,12 @@ class AstroDataModule:
         self.anchors = np.stack(np.meshgrid(ax, ax, ax, indexing="ij"), axis=-1).reshape(-1, 3)      # augmentation.py:97-103
         self.ncrops = len(self.anchors)
         self.nsamples = len(self.fields[0]) * self.ncrops
-        self._gen = torch.Generator().manual_seed(int(seed))
+        # two generators: the epoch shuffles must stay IDENTICAL on every rank (disjoint shards epoch after epoch), the augmentation
+        # draws are per rank
+        self._seed = int(seed)
+        self._gen = torch.Generator().manual_seed(self._seed)                      # split + epoch shuffles (same on all ranks)
+        self._aug_gen = torch.Generator().manual_seed(self._seed + 1)              # shifts / flips / permutations (re-seeded per rank)
+        self._aug_rank = 0
         if stage == "fit":                                       # random_split(data, [95 %, 5 %])  (CAMELS_3D_dataset.py:134-137)
             order = torch.randperm(self.nsamples, generator=self._gen).tolist()
             n_train = int(self.nsamples * 0.95)
@@ -239,9 +244,9 @@ class AstroDataModule:
         anchor = self.anchors[icrop].copy()
         flips, perm = [0, 0, 0], [0, 1, 2]
         if train:
-            anchor = anchor + torch.randint(self.crop, (3,), generator=self._gen).numpy()
-            flips = torch.randint(2, (3,), generator=self._gen).tolist()
-            perm = torch.randperm(3, generator=self._gen).tolist()
+            anchor = anchor + torch.randint(self.crop, (3,), generator=self._aug_gen).numpy()
+            flips = torch.randint(2, (3,), generator=self._aug_gen).tolist()
+            perm = torch.randperm(3, generator=self._aug_gen).tolist()
         return sim, anchor.tolist(), flips, perm
 
     def make_batch(self, samples):
@@ -254,6 +259,9 @@ class AstroDataModule:
         return self.collate_fn(items)
 
     def _loader(self, indices, train, shuffle, rank=0, world=1):
+        if rank != self._aug_rank:                                # (first use on this rank: its own augmentation stream)
+            self._aug_rank = rank
+            self._aug_gen.manual_seed(self._seed + 1 + 7919 * rank)
         idx = list(indices)
         if shuffle:
             idx = [idx[i] for i in torch.randperm(len(idx), generator=self._gen).tolist()]
