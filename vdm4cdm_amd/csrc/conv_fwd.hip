@@ -140,8 +140,10 @@ __global__ void __launch_bounds__(256, 1) conv_ksplit_kernel(const ConvArgs a) {
     operand_lane_offsets<G, NVT>(lanex, 0, lane);         // every wave walks all rows of the tile
     const uint4* wbase = reinterpret_cast<const uint4*>(a.w) + (size_t)chunk * a.nkb * TAPS * NCW * 64 + lane;
     const T* x = reinterpret_cast<const T*>(a.x);
+    // folded GroupNorm backward: everything the epilogue reads is fetched up front also at NC = 4 (one wave per SIMD: 512 registers),
+    // with a single workgroup per CU nothing else would hide those loads
     GnbRegs<T, NC, GNB ? NVE : 1> gr;
-    if constexpr (GNB && NC <= 2) gnb_issue<T, G, NC, NVE>(gr, a, n, oz0, oy0, ox0, wave, lane, cout0, qstride);
+    if constexpr (GNB) gnb_issue<T, G, NC, NVE>(gr, a, n, oz0, oy0, ox0, wave, lane, cout0, qstride);
     float badd[NC * 4];
     if constexpr (!GNB) load_badd<NC>(badd, a, n, cout0 + (lane >> 4) * qstride);
 
@@ -176,7 +178,7 @@ __global__ void __launch_bounds__(256, 1) conv_ksplit_kernel(const ConvArgs a) {
     float* gn_sm = reinterpret_cast<float*>(lds + 4 * IMG);
     const int tile = (tz * a.nty + ty) * a.ntx + tx;
     if constexpr (GNB)
-        conv_epilogue_gnb<T, G, NC, NVE, (NC <= 2)>(tot, a, gr, n, oz0, oy0, ox0, wave, lane, gn_sm, tile, cout0, qstride);
+        conv_epilogue_gnb<T, G, NC, NVE, true>(tot, a, gr, n, oz0, oy0, ox0, wave, lane, gn_sm, tile, cout0, qstride);
     else
         conv_epilogue<T, TO, G, NC, NVE>(tot, a, badd, n, oz0, oy0, ox0, wave, lane, gn_sm, tile, cout0, qstride);
 }
