@@ -232,7 +232,13 @@ class AstroDataModule:
             dev = torch.device(self.device if self.device is not None else "cuda")
             if dev.type != "cuda":
                 raise RuntimeError("AstroDataModule builds its batches with a HIP kernel: set .device to a GPU (there is no CPU path)")
-            self._dev_fields = [torch.from_numpy(np.ascontiguousarray(f, dtype=np.float32)).to(dev) for f in self.fields]
+            self._dev_fields = []
+            for f in self.fields:                             # upload in slabs of simulations: the (memory-mapped) 256^3 sets are
+                d = torch.empty(f.shape, dtype=torch.float32, device=dev)      # 67 GB per field - never a second full copy on the host
+                step = max(1, (1 << 30) // max(1, f[0].nbytes))
+                for i in range(0, len(f), step):
+                    d[i:i + step].copy_(torch.from_numpy(np.ascontiguousarray(f[i:i + step], dtype=np.float32)))
+                self._dev_fields.append(d)
             self._dev_params = torch.from_numpy(self.params).to(dev)
         return self._dev_fields
 
