@@ -545,6 +545,71 @@ def test_c4_192_training_step_properties():
     assert not diff, f"gradient not bit-reproducible in {len(diff)} tensors: {diff[:12]}"
 
 
+def test_full_size_128_cfg_sfm_attention_properties():
+    """The round-2 additions at the BASELINE cube size (128^3, chs 32..256, bf16), through size-independent properties:
+    * classifier-free guidance: w_cfg = 0 runs the batch-doubled graph and must reproduce the unguided chain (to bf16 rounding: the
+      doubled batch may pick other tile shapes at the deep levels), w_cfg > 0 moves it;
+    * SFM: one training step (K7 interpolation, UNet fwd + bwd, K8 loss) is finite, reaches every parameter and is bit-reproducible;
+      the Euler sampling graph returns x0 for a zero velocity field (zero-init conv_out);
+    * mid-level attention at 16^3 = 4096 voxels x 256 channels (4 heads): fwd + bwd finite, forward bit-reproducible, every attention
+      parameter receives a gradient."""
+    from vdm4cdm_amd.data import SyntheticAstroDataModule
+    from vdm4cdm_amd.sfm_model import LightSFM
+    import vdm4cdm_amd.unet_hip as uh
+    D = 128
+    b = SyntheticAstroDataModule(cropsize=D, batch_size=1, seed=1000)._make_batch(1000, 1)
+    x, s, v = b["x"].to(DEV), b["conditioning"].to(DEV), [b["conditioning_values"][0].to(DEV)]
+    # --- CFG
+    net = make_net(D=D, chs=(32, 64, 128, 256), precision="bf16", seed=4)
+    randomize(net, 4, zero_init_std=0.01)
+    vdm = make_vdm(net).to(DEV).eval()
+    z1 = grf((1, 1, D, D, D), 70, slope=0.0)
+    noises = [grf((1, 1, D, D, D), 400 + i, slope=0.0) for i in range(4)]
+    kw = dict(s_conditioning=s, v_conditionings=v)
+    plain = vdm.draw_samples(batch_size=1, n_sampling_steps=4, z=z1.clone(), noises=noises, **kw)
+    vdm.model.w_cfg = 0.0
+    w0 = vdm.draw_samples(batch_size=1, n_sampling_steps=4, z=z1.clone(), noises=noises, **kw)
+    vdm.model.w_cfg = 2.0
+    w2 = vdm.draw_samples(batch_size=1, n_sampling_steps=4, z=z1.clone(), noises=noises, **kw)
+    scale = plain.abs().max().item()
+    assert torch.isfinite(w2).all() and (w0 - plain).abs().max().item() <= 2e-2 * scale
+    assert (w2 - plain).abs().max().item() > (w0 - plain).abs().max().item()
+    del vdm, plain, w0, w2
+    # --- SFM
+    net = make_net(D=D, chs=(32, 64, 128, 256), precision="bf16", dropout=0.1, seed=5)
+    sfm = LightSFM(velocity_model=net).to(DEV).train()
+    outs = []
+    for rep in range(2):
+        torch.manual_seed(3)
+        uh._seed_counter[0] = 0
+        sfm.zero_grad()
+        loss = sfm.training_step({"x0": s, "x1": x, "conditioning_values": v}, 0)
+        loss.backward()
+        outs.append((loss.detach().clone(), net.flat.grad.detach().clone()))
+    assert torch.isfinite(outs[0][0]) and torch.isfinite(outs[0][1]).all()
+    assert all(net.view(name, outs[0][1]).abs().max().item() > 0 for name in net.spec.items)
+    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
+    net0 = make_net(D=D, chs=(32, 64, 128, 256), precision="bf16", seed=5)
+    net0.reset_parameters(generator=torch.Generator().manual_seed(1))          # zero-init conv_out: velocity == 0
+    out = LightSFM(velocity_model=net0).to(DEV).eval().draw_samples(x0=s, n_sampling_steps=3, v_conditionings=v)
+    assert torch.equal(out, s.float())
+    del sfm, net0, outs
+    # --- attention
+    net = make_net(D=D, chs=(32, 64, 128, 256), precision="bf16", seed=6, attn=True, heads=4).to(DEV).train()
+    outs = []
+    for rep in range(2):
+        net.zero_grad()
+        y = net(x, t=torch.tensor([0.4], device=DEV), s_conditioning=s, v_conditionings=v)
+        (y * x).sum().backward()
+        outs.append((y.detach().clone(), net.flat.grad.detach().clone()))
+    assert torch.isfinite(outs[0][0]).all() and torch.isfinite(outs[0][1]).all()
+    assert all(net.view(name, outs[0][1]).abs().max().item() > 0 for name in net.spec.items if name.startswith("mid_attn"))
+    # forward: bit-reproducible.  backward: the attention block's GroupNorm uses the un-folded gn_silu_bwd, whose reductions are float
+    # atomics (the ResNetBlocks use the folded, fixed-order form) - equal to rounding, not to the bit
+    assert torch.equal(outs[0][0], outs[1][0])
+    assert (outs[0][1] - outs[1][1]).abs().max().item() <= 1e-3 * outs[0][1].abs().max().item()
+
+
 def test_c5_sampler_128_power_spectrum():
     """BASELINE config C5 (generate_3D: reverse diffusion at 128^3, hipGraph-captured denoise step, batch 1) against the oracle
     sampler on the same weights, z_1 and per-step noise, 20 steps.  Acceptance metric of BASELINE.json / SURVEY T8: the P(k) of the
