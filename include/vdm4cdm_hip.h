@@ -243,6 +243,10 @@ int vdm_softmax_rows(float* scores, int64_t rows, int cols, float scale, void* s
 int vdm_softmax_rows_bwd(const float* probs, float* dprobs, int64_t rows, int cols, float scale, void* stream);
 /* out[c] = sum over rows of x[row][c] (x: [rows][c] in `dtype`): bias gradients of the block's two 1x1x1 projections. */
 int vdm_channel_sums(const void* x, int64_t rows, int c, int dtype, float* out, void* stream);
+/* out[n][c][2] = (sum_rows a, sum_rows a * b) per sample (a, b: [n][rows_per_sample][c]): with a = dL/dy and b = x of the block's
+ * plain GroupNorm these are the "one tile per sample" partials vdm_gn_bwd_finalize / vdm_gn_bwd_apply take - the fixed-order
+ * (bit-reproducible) backward of a GroupNorm that is not followed by a 3x3x3 conv. */
+int vdm_channel_dot_sums(const void* a, const void* b, int n, int64_t rows_per_sample, int c, int dtype, float* out, void* stream);
 
 /* ---- K9: ancestral update [NB vdm_model.py:370-378] ----------------------------------------
  * z <- ratio*(z - c_sigma_t*eps_hat) + scale*noise ; the four scalars are read from the DEVICE table

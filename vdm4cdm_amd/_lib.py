@@ -97,6 +97,7 @@ SIGNATURES = {
     "vdm_softmax_rows": (_i, [_p, _i64, _i, _f, _p]),
     "vdm_softmax_rows_bwd": (_i, [_p, _p, _i64, _i, _f, _p]),
     "vdm_channel_sums": (_i, [_p, _i64, _i, _i, _p, _p]),
+    "vdm_channel_dot_sums": (_i, [_p, _p, _i, _i64, _i, _i, _p, _p]),
     "vdm_diffuse": (_i, [_p, _p, _p, _p, _i, _i64, _p, _p]),
     "vdm_loss_terms": (_i, [_p, _p, _p, _p, _f, _p, _i, _i64, _p, _p, _p, _p]),
     "vdm_ancestral_step": (_i, [_p, _p, _p, _p, _p, _u64, _i64, _p]),

@@ -773,6 +773,34 @@ __global__ void __launch_bounds__(256) channel_sums_kernel(const T* __restrict__
     }
 }
 
+// out[n][c][2] = (sum_rows a, sum_rows a * b) per sample: the (sum dyh, sum dyh * x) channel totals that vdm_gn_bwd_finalize takes as
+// "one tile per sample" partials - the deterministic GroupNorm backward of a norm that is not followed by a 3x3x3 conv (the attention
+// block's).  One workgroup per (16-byte piece column, sample), fixed summation order.
+template <typename T>
+__global__ void __launch_bounds__(256) channel_dot_sums_kernel(const T* __restrict__ a, const T* __restrict__ b, int64_t rows, int C,
+                                                               float* __restrict__ out) {
+    constexpr int EPL = DT<T>::EPL;
+    __shared__ float sm[4 * 2 * EPL];
+    const int n = blockIdx.y;
+    const T* an = a + (size_t)n * rows * C;
+    const T* bn = b + (size_t)n * rows * C;
+    float acc[2 * EPL];
+#pragma unroll
+    for (int j = 0; j < 2 * EPL; ++j) acc[j] = 0.f;
+    for (int64_t r = threadIdx.x; r < rows; r += 256) {
+        Piece<T> pa, pb;
+        pa.load(*reinterpret_cast<const uint4*>(an + r * C + blockIdx.x * EPL));
+        pb.load(*reinterpret_cast<const uint4*>(bn + r * C + blockIdx.x * EPL));
+#pragma unroll
+        for (int j = 0; j < EPL; ++j) { acc[2 * j] += pa.f[j]; acc[2 * j + 1] = fmaf(pa.f[j], pb.f[j], acc[2 * j + 1]); }
+    }
+    block_sum<2 * EPL>(acc, sm);
+    if (threadIdx.x == 0) {
+#pragma unroll
+        for (int j = 0; j < 2 * EPL; ++j) out[((size_t)n * C + blockIdx.x * EPL) * 2 + j] = acc[j];
+    }
+}
+
 __global__ void step_inc_kernel(int32_t* p) { *p += 1; }
 
 __global__ void __launch_bounds__(256) sumsq_kernel(const float* __restrict__ x, int64_t n, float* __restrict__ part) {
@@ -1026,6 +1054,21 @@ extern "C" int vdm_channel_sums(const void* x, int64_t rows, int c, int dtype, f
     else
         hipLaunchKernelGGL(channel_sums_kernel<bf16_t>, dim3(c / epl), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, rows, c, out);
     VDM_LAUNCH_CHECK("channel_sums_kernel");
+    return VDM_OK;
+}
+
+extern "C" int vdm_channel_dot_sums(const void* a, const void* b, int n, int64_t rows_per_sample, int c, int dtype, float* out, void* stream) {
+    VDM_REQUIRE(a && b && out && n > 0 && rows_per_sample > 0 && c > 0, "channel_dot_sums: bad arguments");
+    VDM_REQUIRE(dtype == VDM_F32 || dtype == VDM_BF16, "channel_dot_sums: dtype");
+    const int epl = dtype == VDM_F32 ? 4 : 8;
+    VDM_REQUIRE(c % epl == 0, "channel_dot_sums: channels must be a multiple of %d", epl);
+    if (dtype == VDM_F32)
+        hipLaunchKernelGGL(channel_dot_sums_kernel<float>, dim3(c / epl, n), dim3(256), 0, (hipStream_t)stream, (const float*)a, (const float*)b,
+                           rows_per_sample, c, out);
+    else
+        hipLaunchKernelGGL(channel_dot_sums_kernel<bf16_t>, dim3(c / epl, n), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)a,
+                           (const bf16_t*)b, rows_per_sample, c, out);
+    VDM_LAUNCH_CHECK("channel_dot_sums_kernel");
     return VDM_OK;
 }
 

@@ -512,6 +512,17 @@ def channel_sums(x, out):
     return out
 
 
+def channel_dot_sums(a, b):
+    """[N, 1, C, 2] fp32 = per sample and channel (sum a, sum a * b) over the voxels: gnb_partials (one "tile" per sample) for
+    gn_bwd_fused when the gradient a = dL/dy of a plain GroupNorm did not come out of Conv.dgrad_gn."""
+    _contig(a, b)
+    assert a.shape == b.shape and a.dtype == b.dtype
+    n, c = a.shape[0], a.shape[-1]
+    out = torch.empty((n, 1, c, 2), dtype=torch.float32, device=a.device)
+    check(_lib.lib().vdm_channel_dot_sums(_p(a), _p(b), n, a.numel() // (n * c), c, dt_id(a.dtype), _p(out), _s()), "vdm_channel_dot_sums")
+    return out
+
+
 def softmax_rows_(scores, scale):
     """In-place row softmax of scale * scores (fp32, last dim = row)."""
     _contig(scores)

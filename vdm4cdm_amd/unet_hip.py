@@ -215,8 +215,11 @@ class _Attn:
         ss.run(lambda: self.qkv.wgrad(xn, dqkv, GP("mid_attn.qkv.weight")), xn, dqkv)
         ops.channel_sums(dqkv, GP("mid_attn.qkv.bias"))
         dxn = self.qkv.dgrad(dqkv)
-        dx, _ = ops.gn_silu_bwd(x, None, G, st, P("mid_attn.norm.weight"), P("mid_attn.norm.bias"), dxn,
-                                GP("mid_attn.norm.weight"), GP("mid_attn.norm.bias"), add1=dout, linear=True)
+        # plain GroupNorm backward in the fixed-order (bit-reproducible) form of the ResNetBlocks: dyh = dL/dy (no activation), its
+        # per-channel (sum dyh, sum dyh * x) as one "tile" per sample, then the shared finalize + apply kernels (no float atomics)
+        dxn.gnb_partials = ops.channel_dot_sums(dxn, x)
+        dx, _ = ops.gn_bwd_fused(x, None, G, st, P("mid_attn.norm.weight"), dxn, GP("mid_attn.norm.weight"), GP("mid_attn.norm.bias"),
+                                 add1=dout)
         return dx
 
 
