@@ -153,15 +153,13 @@ int vdm_gn_stats(const void* x1, int c1, const void* x2, int c2, int n, int64_t 
 int vdm_gn_silu_fwd(const void* x1, int c1, const void* x2, int c2, int n, int64_t voxels, int groups,
                     int dtype, const float* stats, const float* gamma, const float* beta, float eps,
                     float dropout_p, uint64_t seed, void* y, uint8_t* keep_mask, int linear, void* stream);
-/* Backward of the above.  dy is the gradient w.r.t. y.  Writes dx1 (and dx2), ADDS into
- * dgamma/dbeta [c] (caller zeroes); optional add1 / add2 (shaped like x1 / x2) are added to dx1 / dx2
- * (residual-path gradients); optional colsum[n*colsum_stride + c] += sum_v dx (caller zeroes; bias and
- * conditioning-bias gradients).  red_ws: >= n*groups*2 floats of scratch. */
-int vdm_gn_silu_bwd(const void* x1, int c1, const void* x2, int c2, int n, int64_t voxels, int groups,
-                    int dtype, const float* stats, const float* gamma, const float* beta, float eps,
-                    float dropout_p, uint64_t seed, const void* dy, const void* add1, const void* add2, void* dx1,
-                    void* dx2, float* dgamma, float* dbeta, float* colsum, int64_t colsum_stride, float* red_ws,
-                    int linear, void* stream);
+/* Backward of the above for a GroupNorm whose gradient did not come out of vdm_conv_dgrad_gn, first of three steps:
+ * dyh = dy * keep/(1-p) * silu'(yhat) (linear != 0: dyh = dy); dyh may alias dy.  Then vdm_channel_dot_sums(dyh, x) gives the
+ * per-sample (sum dyh, sum dyh * x) = the one-tile-per-sample `partials` of vdm_gn_bwd_finalize, and vdm_gn_bwd_apply writes dx:
+ * the same fixed-order (bit-reproducible) arithmetic as the folded path; no float atomics. */
+int vdm_gn_dyh(const void* x1, int c1, const void* x2, int c2, int n, int64_t voxels, int groups, int dtype, const float* stats,
+               const float* gamma, const float* beta, float eps, float dropout_p, uint64_t seed, const void* dy, void* dyh, int linear,
+               void* stream);
 
 /* Second half of the GroupNorm backward after vdm_conv_dgrad_gn (all in fixed summation order: bit-reproducible).
  * finalize: chan[n][c][2] = sum over tiles of the partials; red[n][g][2] = sum_c gamma_c chan[n][c];
@@ -243,10 +241,10 @@ int vdm_softmax_rows(float* scores, int64_t rows, int cols, float scale, void* s
 int vdm_softmax_rows_bwd(const float* probs, float* dprobs, int64_t rows, int cols, float scale, void* stream);
 /* out[c] = sum over rows of x[row][c] (x: [rows][c] in `dtype`): bias gradients of the block's two 1x1x1 projections. */
 int vdm_channel_sums(const void* x, int64_t rows, int c, int dtype, float* out, void* stream);
-/* out[n][c][2] = (sum_rows a, sum_rows a * b) per sample (a, b: [n][rows_per_sample][c]): with a = dL/dy and b = x of the block's
- * plain GroupNorm these are the "one tile per sample" partials vdm_gn_bwd_finalize / vdm_gn_bwd_apply take - the fixed-order
- * (bit-reproducible) backward of a GroupNorm that is not followed by a 3x3x3 conv. */
-int vdm_channel_dot_sums(const void* a, const void* b, int n, int64_t rows_per_sample, int c, int dtype, float* out, void* stream);
+/* out[n][c1+c2][2] = (sum_rows a, sum_rows a * b) per sample, a: [n][rows][c1+c2], b = concat(b1 [n][rows][c1], b2 [n][rows][c2] or
+ * NULL): with a = dyh and b = x of a GroupNorm these are the "one tile per sample" partials vdm_gn_bwd_finalize / vdm_gn_bwd_apply take. */
+int vdm_channel_dot_sums(const void* a, const void* b1, int c1, const void* b2, int c2, int n, int64_t rows_per_sample, int dtype,
+                         float* out, void* stream);
 
 /* ---- K9: ancestral update [NB vdm_model.py:370-378] ----------------------------------------
  * z <- ratio*(z - c_sigma_t*eps_hat) + scale*noise ; the four scalars are read from the DEVICE table

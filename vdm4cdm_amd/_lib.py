@@ -85,7 +85,7 @@ SIGNATURES = {
     "vdm_conv_wgrad": (_i, [_D, _p, _p, _p, _p, _i, _p, _sz, _p]),
     "vdm_gn_stats": (_i, [_p, _i, _p, _i, _i, _i64, _i, _i, _p, _p, _p, _i, _p, _i, _p, _p]),
     "vdm_gn_silu_fwd": (_i, [_p, _i, _p, _i, _i, _i64, _i, _i, _p, _p, _p, _f, _f, _u64, _p, _p, _i, _p]),
-    "vdm_gn_silu_bwd": (_i, [_p, _i, _p, _i, _i, _i64, _i, _i, _p, _p, _p, _f, _f, _u64, _p, _p, _p, _p, _p, _p, _p, _p, _i64, _p, _i, _p]),
+    "vdm_gn_dyh": (_i, [_p, _i, _p, _i, _i, _i64, _i, _i, _p, _p, _p, _f, _f, _u64, _p, _p, _i, _p]),
     "vdm_gn_bwd_finalize": (_i, [_p, _i, _i, _i, _i, _i64, _p, _p, _f, _p, _p, _p, _p, _i64, _p]),
     "vdm_gn_bwd_apply": (_i, [_p, _i, _p, _i, _i, _i64, _i, _i, _p, _p, _f, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p]),
     "vdm_pack_input": (_i, [_p, _p, _i64, _i, _i, _p, _p]),
@@ -97,7 +97,7 @@ SIGNATURES = {
     "vdm_softmax_rows": (_i, [_p, _i64, _i, _f, _p]),
     "vdm_softmax_rows_bwd": (_i, [_p, _p, _i64, _i, _f, _p]),
     "vdm_channel_sums": (_i, [_p, _i64, _i, _i, _p, _p]),
-    "vdm_channel_dot_sums": (_i, [_p, _p, _i, _i64, _i, _i, _p, _p]),
+    "vdm_channel_dot_sums": (_i, [_p, _p, _i, _p, _i, _i, _i64, _i, _p, _p]),
     "vdm_diffuse": (_i, [_p, _p, _p, _p, _i, _i64, _p, _p]),
     "vdm_loss_terms": (_i, [_p, _p, _p, _p, _f, _p, _i, _i64, _p, _p, _p, _p]),
     "vdm_ancestral_step": (_i, [_p, _p, _p, _p, _p, _u64, _i64, _p]),

@@ -270,10 +270,12 @@ __device__ __forceinline__ float dsilu(float y) {
     return s * (1.f + y * (1.f - s));
 }
 
-// pass 1: red[n][g] = {sum gamma*dyh, sum gamma*dyh*xhat};  dgamma[c] += sum dyh*xhat; dbeta[c] += sum dyh
-// where dyh = dy * keep * silu'(yhat).  Thread owns a fixed piece column (stride % PPV == 0 by construction).
+// Un-folded GroupNorm backward (a GroupNorm whose gradient did not come out of Conv.dgrad_gn): dyh = dy * keep * silu'(yhat) as its
+// own pass; vdm_channel_dot_sums then gives the per-sample (sum dyh, sum dyh * x) and the fixed-order finalize + apply kernels below
+// finish - the same bit-reproducible arithmetic as the folded path (the float-atomic reduce / apply kernels of round 1 are gone).
+// Thread owns a fixed piece column (stride % PPV == 0 by construction).  Output: a.dx1 = dyh [n][V][C] (may alias dy).
 template <typename T>
-__global__ void __launch_bounds__(256) gn_silu_bwd_reduce_kernel(const GnArgs a) {
+__global__ void __launch_bounds__(256) gn_dyh_kernel(const GnArgs a) {
     constexpr int EPL = DT<T>::EPL;
     const int C = a.c1 + a.c2, gs = C / a.G, PPV = C / EPL, P1 = a.c1 / EPL;
     const int n = blockIdx.x / a.blocks_per_n, bn = blockIdx.x % a.blocks_per_n;
@@ -283,20 +285,18 @@ __global__ void __launch_bounds__(256) gn_silu_bwd_reduce_kernel(const GnArgs a)
     const T* x1 = reinterpret_cast<const T*>(a.x1) + (size_t)n * a.V * a.c1;
     const T* x2 = a.x2 ? reinterpret_cast<const T*>(a.x2) + (size_t)n * a.V * a.c2 : nullptr;
     const T* dy = reinterpret_cast<const T*>(a.dy) + (size_t)n * a.V * C;
+    T* dyh = reinterpret_cast<T*>(a.dx1) + (size_t)n * a.V * C;
     const bool drop = a.p > 0.f;
     const float inv_keep = drop ? 1.f / (1.f - a.p) : 1.f;
     const int64_t start = (int64_t)bn * 256 + threadIdx.x;
     const int pc = (int)(start % PPV);
-    float A[EPL], B[EPL], mean[EPL], rstd[EPL], gam[EPL];
+    float A[EPL], B[EPL];
 #pragma unroll
     for (int j = 0; j < EPL; ++j) {
         const int c = pc * EPL + j;
-        gam[j] = a.gamma[c];
-        gn_affine(a.stats, n, a.G, c / gs, cnt, a.eps, gam[j], a.beta[c], A[j], B[j], mean[j], rstd[j]);
+        float mean, rstd;
+        gn_affine(a.stats, n, a.G, c / gs, cnt, a.eps, a.gamma[c], a.beta[c], A[j], B[j], mean, rstd);
     }
-    float sdy[EPL], sdyx[EPL];
-#pragma unroll
-    for (int j = 0; j < EPL; ++j) sdy[j] = sdyx[j] = 0.f;
     for (int64_t i = start; i < npieces; i += stride) {
         const int64_t v = i / PPV;
         const uint4 raw = pc < P1 ? *reinterpret_cast<const uint4*>(x1 + v * a.c1 + pc * EPL)
@@ -315,134 +315,16 @@ __global__ void __launch_bounds__(256) gn_silu_bwd_reduce_kernel(const GnArgs a)
                 }
                 d *= u32_to_unit(rnd[j & 3]) > a.p ? inv_keep : 0.f;
             }
-            sdy[j] += d;
-            sdyx[j] += d * (px.f[j] - mean[j]) * rstd[j];
+            pd.f[j] = d;
         }
+        *reinterpret_cast<uint4*>(dyh + i * EPL) = pd.store();
     }
-    // block-level accumulation in LDS: per channel (C <= 512) and per group.  When the piece column is a function of
-    // (lane % PPV) the 64/PPV lanes of a wave that share it are first folded with xor-butterflies, so only PPV lanes per
-    // wave touch the LDS accumulators (the contended LDS atomics used to cost more than the streaming loop).
-    __shared__ float shc[2 * 512];
-    __shared__ float shg[2 * 64];
-    for (int i = threadIdx.x; i < 2 * C; i += 256) shc[i] = 0.f;
-    for (int i = threadIdx.x; i < 2 * a.G; i += 256) shg[i] = 0.f;
-    __syncthreads();
-    bool writer = true;
-    if ((64 % PPV) == 0) {
-        for (int off = 32; off >= PPV; off >>= 1) {
-#pragma unroll
-            for (int j = 0; j < EPL; ++j) {
-                sdy[j] += __shfl_xor(sdy[j], off, 64);
-                sdyx[j] += __shfl_xor(sdyx[j], off, 64);
-            }
-        }
-        writer = (int)(threadIdx.x & 63) < PPV;
-    }
-    if (writer) {
-#pragma unroll
-        for (int j = 0; j < EPL; ++j) {
-            const int c = pc * EPL + j;
-            atomicAdd(&shc[2 * c], sdy[j]);
-            atomicAdd(&shc[2 * c + 1], sdyx[j]);
-            atomicAdd(&shg[2 * (c / gs)], gam[j] * sdy[j]);
-            atomicAdd(&shg[2 * (c / gs) + 1], gam[j] * sdyx[j]);
-        }
-    }
-    __syncthreads();
-    for (int i = threadIdx.x; i < C; i += 256) {
-        atomicAdd(&a.dbeta[i], shc[2 * i]);
-        atomicAdd(&a.dgamma[i], shc[2 * i + 1]);
-    }
-    for (int i = threadIdx.x; i < 2 * a.G; i += 256) atomicAdd(&a.red[(size_t)n * 2 * a.G + i], shg[i]);
 }
 
 __device__ __forceinline__ bool pc_is_first(const GnArgs& a, int epl, int bid, int tid) {
     const int ppv = (a.c1 + a.c2) / epl;
     const long long start = (long long)(bid % a.blocks_per_n) * 256 + tid;
     return (int)(start % ppv) < a.c1 / epl;
-}
-
-// pass 2: dx = rstd * (gamma*dyh - m1 - xhat*m2) (+ add), m1 = red0/cnt, m2 = red1/cnt ; colsum[n][c] += sum_v dx
-template <typename T>
-__global__ void __launch_bounds__(256) gn_silu_bwd_apply_kernel(const GnArgs a) {
-    constexpr int EPL = DT<T>::EPL;
-    const int C = a.c1 + a.c2, gs = C / a.G, PPV = C / EPL, P1 = a.c1 / EPL;
-    const int n = blockIdx.x / a.blocks_per_n, bn = blockIdx.x % a.blocks_per_n;
-    const int64_t npieces = a.V * PPV;
-    const int64_t stride = (int64_t)a.blocks_per_n * 256;
-    const float cnt = (float)a.V * gs;
-    const T* x1 = reinterpret_cast<const T*>(a.x1) + (size_t)n * a.V * a.c1;
-    const T* x2 = a.x2 ? reinterpret_cast<const T*>(a.x2) + (size_t)n * a.V * a.c2 : nullptr;
-    const T* dy = reinterpret_cast<const T*>(a.dy) + (size_t)n * a.V * C;
-    const T* add1 = a.add1 ? reinterpret_cast<const T*>(a.add1) + (size_t)n * a.V * a.c1 : nullptr;
-    const T* add2 = a.add2 ? reinterpret_cast<const T*>(a.add2) + (size_t)n * a.V * a.c2 : nullptr;
-    const T* addp = pc_is_first(a, DT<T>::EPL, blockIdx.x, threadIdx.x) ? add1 : add2;
-    T* dx1 = reinterpret_cast<T*>(a.dx1) + (size_t)n * a.V * a.c1;
-    T* dx2 = a.dx2 ? reinterpret_cast<T*>(a.dx2) + (size_t)n * a.V * a.c2 : nullptr;
-    const bool drop = a.p > 0.f;
-    const float inv_keep = drop ? 1.f / (1.f - a.p) : 1.f;
-    const int64_t start = (int64_t)bn * 256 + threadIdx.x;
-    const int pc = (int)(start % PPV);
-    float A[EPL], B[EPL], mean[EPL], rstd[EPL], gam[EPL], m1[EPL], m2[EPL], cs[EPL];
-#pragma unroll
-    for (int j = 0; j < EPL; ++j) {
-        const int c = pc * EPL + j, g = c / gs;
-        gam[j] = a.gamma[c];
-        gn_affine(a.stats, n, a.G, g, cnt, a.eps, gam[j], a.beta[c], A[j], B[j], mean[j], rstd[j]);
-        m1[j] = a.red[((size_t)n * a.G + g) * 2] / cnt;
-        m2[j] = a.red[((size_t)n * a.G + g) * 2 + 1] / cnt;
-        cs[j] = 0.f;
-    }
-    for (int64_t i = start; i < npieces; i += stride) {
-        const int64_t v = i / PPV;
-        const uint4 raw = pc < P1 ? *reinterpret_cast<const uint4*>(x1 + v * a.c1 + pc * EPL)
-                                  : *reinterpret_cast<const uint4*>(x2 + v * a.c2 + (pc - P1) * EPL);
-        Piece<T> px, pd, pa;
-        px.load(raw);
-        pd.load(*reinterpret_cast<const uint4*>(dy + i * EPL));
-        if (addp) pa.load(pc < P1 ? *reinterpret_cast<const uint4*>(addp + v * a.c1 + pc * EPL)
-                                  : *reinterpret_cast<const uint4*>(addp + v * a.c2 + (pc - P1) * EPL));
-        uint32_t rnd[4];
-#pragma unroll
-        for (int j = 0; j < EPL; ++j) {
-            float d = a.linear ? pd.f[j] : pd.f[j] * dsilu(px.f[j] * A[j] + B[j]);
-            if (drop) {
-                if ((j & 3) == 0) {
-                    const uint64_t e4 = ((uint64_t)n * a.V * C + (uint64_t)i * EPL + j) >> 2;
-                    Philox::gen((uint32_t)e4, (uint32_t)(e4 >> 32), 0x5eedu, 0u, (uint32_t)a.seed, (uint32_t)(a.seed >> 32), rnd);
-                }
-                d *= u32_to_unit(rnd[j & 3]) > a.p ? inv_keep : 0.f;
-            }
-            const float xh = (px.f[j] - mean[j]) * rstd[j];
-            float o = rstd[j] * (gam[j] * d - m1[j] - xh * m2[j]);
-            if (addp) o += pa.f[j];
-            px.f[j] = o;
-            cs[j] += o;
-        }
-        if (pc < P1)
-            *reinterpret_cast<uint4*>(dx1 + v * a.c1 + pc * EPL) = px.store();
-        else
-            *reinterpret_cast<uint4*>(dx2 + v * a.c2 + (pc - P1) * EPL) = px.store();
-    }
-    if (a.colsum) {
-        __shared__ float shc[512];
-        for (int i = threadIdx.x; i < C; i += 256) shc[i] = 0.f;
-        __syncthreads();
-        bool writer = true;
-        if ((64 % PPV) == 0) {
-            for (int off = 32; off >= PPV; off >>= 1) {
-#pragma unroll
-                for (int j = 0; j < EPL; ++j) cs[j] += __shfl_xor(cs[j], off, 64);
-            }
-            writer = (int)(threadIdx.x & 63) < PPV;
-        }
-        if (writer) {
-#pragma unroll
-            for (int j = 0; j < EPL; ++j) atomicAdd(&shc[pc * EPL + j], cs[j]);
-        }
-        __syncthreads();
-        for (int i = threadIdx.x; i < C; i += 256) atomicAdd(&a.colsum[(size_t)n * a.colsum_stride + i], shc[i]);
-    }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -773,31 +655,33 @@ __global__ void __launch_bounds__(256) channel_sums_kernel(const T* __restrict__
     }
 }
 
-// out[n][c][2] = (sum_rows a, sum_rows a * b) per sample: the (sum dyh, sum dyh * x) channel totals that vdm_gn_bwd_finalize takes as
-// "one tile per sample" partials - the deterministic GroupNorm backward of a norm that is not followed by a 3x3x3 conv (the attention
-// block's).  One workgroup per (16-byte piece column, sample), fixed summation order.
+// out[n][c][2] = (sum_rows a, sum_rows a * b) per sample, b = concat(b1 [c1 ch], b2 [c2 ch]): the (sum dyh, sum dyh * x) channel totals
+// that vdm_gn_bwd_finalize takes as "one tile per sample" partials - the deterministic GroupNorm backward of a norm whose gradient did
+// not come out of a dgrad epilogue.  One workgroup per (16-byte piece column, sample), fixed summation order.
 template <typename T>
-__global__ void __launch_bounds__(256) channel_dot_sums_kernel(const T* __restrict__ a, const T* __restrict__ b, int64_t rows, int C,
-                                                               float* __restrict__ out) {
+__global__ void __launch_bounds__(256) channel_dot_sums_kernel(const T* __restrict__ a, const T* __restrict__ b1, int c1,
+                                                               const T* __restrict__ b2, int c2, int64_t rows, float* __restrict__ out) {
     constexpr int EPL = DT<T>::EPL;
     __shared__ float sm[4 * 2 * EPL];
-    const int n = blockIdx.y;
-    const T* an = a + (size_t)n * rows * C;
-    const T* bn = b + (size_t)n * rows * C;
+    const int n = blockIdx.y, C = c1 + c2, col = blockIdx.x * EPL;
+    const T* an = a + (size_t)n * rows * C + col;
+    const bool first = col < c1;
+    const T* bn = first ? b1 + (size_t)n * rows * c1 + col : b2 + (size_t)n * rows * c2 + (col - c1);
+    const int cb = first ? c1 : c2;
     float acc[2 * EPL];
 #pragma unroll
     for (int j = 0; j < 2 * EPL; ++j) acc[j] = 0.f;
     for (int64_t r = threadIdx.x; r < rows; r += 256) {
         Piece<T> pa, pb;
-        pa.load(*reinterpret_cast<const uint4*>(an + r * C + blockIdx.x * EPL));
-        pb.load(*reinterpret_cast<const uint4*>(bn + r * C + blockIdx.x * EPL));
+        pa.load(*reinterpret_cast<const uint4*>(an + r * C));
+        pb.load(*reinterpret_cast<const uint4*>(bn + r * cb));
 #pragma unroll
         for (int j = 0; j < EPL; ++j) { acc[2 * j] += pa.f[j]; acc[2 * j + 1] = fmaf(pa.f[j], pb.f[j], acc[2 * j + 1]); }
     }
     block_sum<2 * EPL>(acc, sm);
     if (threadIdx.x == 0) {
 #pragma unroll
-        for (int j = 0; j < 2 * EPL; ++j) out[((size_t)n * C + blockIdx.x * EPL) * 2 + j] = acc[j];
+        for (int j = 0; j < 2 * EPL; ++j) out[((size_t)n * C + col) * 2 + j] = acc[j];
     }
 }
 
@@ -917,27 +801,22 @@ extern "C" int vdm_gn_silu_fwd(const void* x1, int c1, const void* x2, int c2, i
     return VDM_OK;
 }
 
-extern "C" int vdm_gn_silu_bwd(const void* x1, int c1, const void* x2, int c2, int n, int64_t voxels, int groups, int dtype,
-                               const float* stats, const float* gamma, const float* beta, float eps, float dropout_p, uint64_t seed,
-                               const void* dy, const void* add1, const void* add2, void* dx1, void* dx2, float* dgamma, float* dbeta,
-                               float* colsum, int64_t colsum_stride, float* red_ws, int linear, void* stream) {
-    int e = gn_common_check(c1, c2, n, voxels, groups, dtype, "gn_silu_bwd");
+extern "C" int vdm_gn_dyh(const void* x1, int c1, const void* x2, int c2, int n, int64_t voxels, int groups, int dtype,
+                          const float* stats, const float* gamma, const float* beta, float eps, float dropout_p, uint64_t seed,
+                          const void* dy, void* dyh, int linear, void* stream) {
+    int e = gn_common_check(c1, c2, n, voxels, groups, dtype, "gn_dyh");
     if (e) return e;
-    VDM_REQUIRE(x1 && stats && gamma && beta && dy && dx1 && dgamma && dbeta && red_ws && (c2 == 0 || (x2 && dx2)), "gn_silu_bwd: NULL pointer");
+    VDM_REQUIRE(x1 && stats && gamma && beta && dy && dyh && (c2 == 0 || x2), "gn_dyh: NULL pointer");
+    VDM_REQUIRE(dropout_p >= 0.f && dropout_p < 1.f, "gn_dyh: dropout_p out of range");
     GnArgs a = gn_args(x1, c1, x2, c2, n, voxels, groups, dtype, stats, gamma, beta, eps, dropout_p, seed);
-    a.dy = dy; a.add1 = add1; a.add2 = add2; a.colsum_stride = colsum_stride; a.dx1 = dx1; a.dx2 = dx2; a.dgamma = dgamma; a.dbeta = dbeta; a.colsum = colsum; a.red = red_ws;
+    a.dy = dy; a.dx1 = dyh;
     a.linear = linear != 0;
     hipStream_t s = (hipStream_t)stream;
-    e = check_hip(hipMemsetAsync(red_ws, 0, sizeof(float) * 2 * groups * n, s), "hipMemsetAsync(red_ws)");
-    if (e) return e;
-    if (dtype == VDM_F32) {
-        hipLaunchKernelGGL(gn_silu_bwd_reduce_kernel<float>, dim3(a.blocks_per_n * n), dim3(256), 0, s, a);
-        hipLaunchKernelGGL(gn_silu_bwd_apply_kernel<float>, dim3(a.blocks_per_n * n), dim3(256), 0, s, a);
-    } else {
-        hipLaunchKernelGGL(gn_silu_bwd_reduce_kernel<bf16_t>, dim3(a.blocks_per_n * n), dim3(256), 0, s, a);
-        hipLaunchKernelGGL(gn_silu_bwd_apply_kernel<bf16_t>, dim3(a.blocks_per_n * n), dim3(256), 0, s, a);
-    }
-    VDM_LAUNCH_CHECK("gn_silu_bwd kernels");
+    if (dtype == VDM_F32)
+        hipLaunchKernelGGL(gn_dyh_kernel<float>, dim3(a.blocks_per_n * n), dim3(256), 0, s, a);
+    else
+        hipLaunchKernelGGL(gn_dyh_kernel<bf16_t>, dim3(a.blocks_per_n * n), dim3(256), 0, s, a);
+    VDM_LAUNCH_CHECK("gn_dyh_kernel");
     return VDM_OK;
 }
 
@@ -1057,17 +936,18 @@ extern "C" int vdm_channel_sums(const void* x, int64_t rows, int c, int dtype, f
     return VDM_OK;
 }
 
-extern "C" int vdm_channel_dot_sums(const void* a, const void* b, int n, int64_t rows_per_sample, int c, int dtype, float* out, void* stream) {
-    VDM_REQUIRE(a && b && out && n > 0 && rows_per_sample > 0 && c > 0, "channel_dot_sums: bad arguments");
+extern "C" int vdm_channel_dot_sums(const void* a, const void* b1, int c1, const void* b2, int c2, int n, int64_t rows_per_sample, int dtype,
+                                    float* out, void* stream) {
+    VDM_REQUIRE(a && b1 && out && n > 0 && rows_per_sample > 0 && c1 > 0 && c2 >= 0 && (c2 == 0 || b2), "channel_dot_sums: bad arguments");
     VDM_REQUIRE(dtype == VDM_F32 || dtype == VDM_BF16, "channel_dot_sums: dtype");
     const int epl = dtype == VDM_F32 ? 4 : 8;
-    VDM_REQUIRE(c % epl == 0, "channel_dot_sums: channels must be a multiple of %d", epl);
+    VDM_REQUIRE(c1 % epl == 0 && c2 % epl == 0, "channel_dot_sums: channel counts must be multiples of %d", epl);
     if (dtype == VDM_F32)
-        hipLaunchKernelGGL(channel_dot_sums_kernel<float>, dim3(c / epl, n), dim3(256), 0, (hipStream_t)stream, (const float*)a, (const float*)b,
-                           rows_per_sample, c, out);
+        hipLaunchKernelGGL(channel_dot_sums_kernel<float>, dim3((c1 + c2) / epl, n), dim3(256), 0, (hipStream_t)stream, (const float*)a,
+                           (const float*)b1, c1, (const float*)b2, c2, rows_per_sample, out);
     else
-        hipLaunchKernelGGL(channel_dot_sums_kernel<bf16_t>, dim3(c / epl, n), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)a,
-                           (const bf16_t*)b, rows_per_sample, c, out);
+        hipLaunchKernelGGL(channel_dot_sums_kernel<bf16_t>, dim3((c1 + c2) / epl, n), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)a,
+                           (const bf16_t*)b1, c1, (const bf16_t*)b2, c2, rows_per_sample, out);
     VDM_LAUNCH_CHECK("channel_dot_sums_kernel");
     return VDM_OK;
 }

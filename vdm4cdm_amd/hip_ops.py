@@ -361,27 +361,31 @@ def gn_silu_fwd(x1, x2, groups, stats, gamma, beta, dropout_p=0.0, seed=0, out=N
 
 def gn_silu_bwd(x1, x2, groups, stats, gamma, beta, dy, dgamma, dbeta, add1=None, add2=None, colsum=None,
                 dropout_p=0.0, seed=0, dx1=None, dx2=None, linear=False):
-    """Returns (dx1, dx2).  dgamma / dbeta / colsum are accumulated into (caller zeroes)."""
+    """GroupNorm(+SiLU+dropout) backward for a gradient `dy` that did NOT come out of Conv.dgrad_gn: dyh = dy * keep * silu'(yhat) as
+    its own pass (vdm_gn_dyh), its per-sample channel totals (vdm_channel_dot_sums), then the fixed-order finalize + apply kernels of
+    the folded path (gn_bwd_fused) - bit-reproducible, no float atomics.  Returns (dx1, dx2); writes dgamma / dbeta and, if given,
+    colsum[n, c] = sum_v dx (bias / conditioning-table gradients)."""
     L = _lib.lib()
-    _contig(x1, x2, dy, add1, add2, gamma, beta, dgamma, dbeta)
+    _contig(x1, x2, dy, add1, add2, gamma, beta, dgamma, dbeta, stats)
     n, v = _nv(x1)
     c1 = x1.shape[-1]
     c2 = 0 if x2 is None else x2.shape[-1]
-    if dx1 is None:
-        dx1 = torch.empty_like(x1)
-    if x2 is not None and dx2 is None:
-        dx2 = torch.empty_like(x2)
-    red = torch.empty((n, groups, 2), dtype=torch.float32, device=x1.device)
-    cstride = 0
-    if colsum is not None:
-        assert colsum.dtype == torch.float32 and colsum.stride(1) == 1 and colsum.shape[0] == n
-        cstride = colsum.stride(0)
     ev = _pb()
-    check(L.vdm_gn_silu_bwd(_p(x1), c1, _p(x2), c2, n, v, groups, dt_id(x1.dtype), _p(stats), _p(gamma), _p(beta), GN_EPS,
-                            float(dropout_p), int(seed), _p(dy), _p(add1), _p(add2), _p(dx1), _p(dx2), _p(dgamma), _p(dbeta),
-                            _p(colsum), cstride, _p(red), int(bool(linear)), _s()), "vdm_gn_silu_bwd")
-    _pe(ev, "gn_silu_bwd(reduce+apply)", 0.0, (5.0 + (1.0 if add1 is not None else 0.0)) * dy.numel() * dy.element_size())
-    return dx1, dx2
+    dyh = dy if (dx1 is not None and dx1.data_ptr() == dy.data_ptr()) else torch.empty_like(dy)      # in place when the caller gave dy away
+    check(L.vdm_gn_dyh(_p(x1), c1, _p(x2), c2, n, v, groups, dt_id(x1.dtype), _p(stats), _p(gamma), _p(beta), GN_EPS, float(dropout_p),
+                       int(seed), _p(dy), _p(dyh), int(bool(linear)), _s()), "vdm_gn_dyh")
+    dyh.gnb_partials = channel_dot_sums(dyh, x1, x2)
+    if colsum is not None and getattr(stats, "chsum", None) is None:      # the analytic column sums need sum_v x per channel
+        cs = [channel_dot_sums(t, t)[:, 0, :, 0] for t in (x1, x2) if t is not None]
+        stats.chsum = torch.cat(cs, dim=1).contiguous()
+    _pe(ev, "gn_dyh+dot_sums", 0.0, 5.0 * dy.numel() * dy.element_size())
+    out = gn_bwd_fused(x1, x2, groups, stats, gamma, dyh, dgamma, dbeta, add1=add1, add2=add2, colsum=colsum, dx1=dx1, dx2=dx2)
+    if colsum is not None:                # colsum = sum_v dx INCLUDING the residual-path terms (the analytic form covers the GroupNorm part)
+        if add1 is not None:
+            colsum[:, :c1] += channel_dot_sums(add1, add1)[:, 0, :, 0]
+        if add2 is not None:
+            colsum[:, c1:c1 + c2] += channel_dot_sums(add2, add2)[:, 0, :, 0]
+    return out
 
 
 def gn_bwd_fused(x1, x2, groups, stats, gamma, dyh, dgamma, dbeta, add1=None, add2=None, colsum=None, dx1=None, dx2=None):
@@ -512,14 +516,17 @@ def channel_sums(x, out):
     return out
 
 
-def channel_dot_sums(a, b):
-    """[N, 1, C, 2] fp32 = per sample and channel (sum a, sum a * b) over the voxels: gnb_partials (one "tile" per sample) for
-    gn_bwd_fused when the gradient a = dL/dy of a plain GroupNorm did not come out of Conv.dgrad_gn."""
-    _contig(a, b)
-    assert a.shape == b.shape and a.dtype == b.dtype
+def channel_dot_sums(a, b1, b2=None):
+    """[N, 1, C, 2] fp32 = per sample and channel (sum a, sum a * b) over the voxels, b = concat(b1, b2): gnb_partials (one "tile" per
+    sample) for gn_bwd_fused when the gradient a of a GroupNorm did not come out of Conv.dgrad_gn."""
+    _contig(a, b1, b2)
     n, c = a.shape[0], a.shape[-1]
+    c1 = b1.shape[-1]
+    c2 = 0 if b2 is None else b2.shape[-1]
+    assert c1 + c2 == c and b1.dtype == a.dtype and b1.shape[:-1] == a.shape[:-1]
     out = torch.empty((n, 1, c, 2), dtype=torch.float32, device=a.device)
-    check(_lib.lib().vdm_channel_dot_sums(_p(a), _p(b), n, a.numel() // (n * c), c, dt_id(a.dtype), _p(out), _s()), "vdm_channel_dot_sums")
+    check(_lib.lib().vdm_channel_dot_sums(_p(a), _p(b1), c1, _p(b2), c2, n, a.numel() // (n * c), dt_id(a.dtype), _p(out), _s()),
+          "vdm_channel_dot_sums")
     return out
 
 
