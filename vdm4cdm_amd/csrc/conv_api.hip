@@ -367,7 +367,7 @@ extern "C" size_t vdm_conv_wgrad_workspace_bytes(const vdm_conv_desc* d) {
     const int taps = d->ksize * d->ksize * d->ksize;
     const int cls = d->upsample ? 8 : 1;                   // up-sampling conv: 8 parity classes x 8 merged taps
     const int npairs = cls * cdiv(d->cout, CL) * cdiv(d->cin, CL);
-    int P = 512 / npairs;
+    int P = wgrad_wgs() / npairs;
     if (P < 1) P = 1;
     const int slots = d->upsample ? 8 : (taps > 1 ? 1 : 4) * taps;
     return (size_t)npairs * P * slots * CL * CL * sizeof(float) + (size_t)cdiv(d->cout, CL) * cls * P * CL * sizeof(float);

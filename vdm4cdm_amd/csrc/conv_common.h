@@ -860,6 +860,12 @@ static bool ksplit_tile(const ConvArgs& a, int& tz, int& ty) {
     return true;
 }
 
+// persistent workgroups of a weight-gradient launch over all (cout, cin) block pairs (~2 per CU); VDM4CDM_WGRAD_WGS: experiments
+static int wgrad_wgs() {
+    static const int v = getenv("VDM4CDM_WGRAD_WGS") ? atoi(getenv("VDM4CDM_WGRAD_WGS")) : 512;
+    return v > 0 ? v : 512;
+}
+
 static bool uses_kpack(int dtype, int ks, int stride, int ups, int K, int O, int out_f32) {
     return dtype == VDM_BF16 && ks == 3 && stride == 1 && !ups && K <= 8 && O <= 32 && !out_f32 && getenv("VDM4CDM_NO_KPACK") == nullptr;
 }

@@ -355,7 +355,7 @@ static int launch_wgrad_cfg(WgradArgs w, float* dw, float* dbias, int accumulate
     a.ntz = cdiv(a.Dz, TZ); a.nty = cdiv(a.Dy, TY); a.ntx = cdiv(a.Dx, 16);
     w.ntiles = a.N * a.ntz * a.nty * a.ntx;
     const int npairs = w.ncb * w.nkb;
-    int P = 512 / npairs;                     // persistent: ~2 workgroups per CU over all (cout, cin) block pairs
+    int P = wgrad_wgs() / npairs;             // persistent: ~2 workgroups per CU over all (cout, cin) block pairs
     if (P < 1) P = 1;
     if (P > w.ntiles) P = w.ntiles;
     w.P = P;
@@ -396,7 +396,7 @@ static int launch_wgrad_cls(WgradArgs w, float* dw, float* dbias, int accumulate
     a.ntz = cdiv(a.Dz, G::TZ); a.nty = cdiv(a.Dy, G::TY); a.ntx = cdiv(a.Dx, 16);
     w.ntiles = a.N * a.ntz * a.nty * a.ntx;
     const int npairs = 8 * w.ncb * w.nkb;
-    int P = WGS / npairs;
+    int P = (WGS * wgrad_wgs() / 512) / npairs;
     if (P < 1) P = 1;
     if (P > w.ntiles) P = w.ntiles;
     w.P = P;
