@@ -23,6 +23,8 @@ SHAPES = [  # name, N, D (output), cin, cout, ks, stride, ups
     ("L3_128_256", 2, 16, 128, 256, 3, 1, 0),
     ("L3_256_256", 2, 16, 256, 256, 3, 1, 0),
     ("L0_down_32_32", 2, 64, 32, 32, 3, 2, 0),
+    ("L1_down_64_64", 2, 32, 64, 64, 3, 2, 0),
+    ("L2_down_128_128", 2, 16, 128, 128, 3, 2, 0),
     ("L0_skip_64_32", 2, 128, 64, 32, 1, 1, 0),
     ("L0_in_2_32", 2, 128, 2, 32, 3, 1, 0),
     ("L0_out_32_1", 2, 128, 32, 1, 3, 1, 0),

@@ -860,6 +860,13 @@ static bool ksplit_tile(const ConvArgs& a, int& tz, int& ty) {
     return true;
 }
 
+// stride-2 conv: output tile tz x 4 x 16.  2x4x16 needs a 5x9x33-voxel image (95 KB: ONE workgroup per CU, nothing overlaps its
+// staging); 1x4x16 needs 3x9x33 voxels (57 KB: two per CU).  VDM4CDM_S2_TZ selects (experiments).
+static int s2_tile_z() {
+    static const int v = getenv("VDM4CDM_S2_TZ") ? atoi(getenv("VDM4CDM_S2_TZ")) : 2;
+    return v == 1 ? 1 : 2;
+}
+
 // persistent workgroups of a weight-gradient launch over all (cout, cin) block pairs (~2 per CU); VDM4CDM_WGRAD_WGS: experiments
 static int wgrad_wgs() {
     static const int v = getenv("VDM4CDM_WGRAD_WGS") ? atoi(getenv("VDM4CDM_WGRAD_WGS")) : 512;
@@ -932,7 +939,7 @@ static void fill_dims(ConvArgs& a, const vdm_conv_desc* d) {
 // spatial tile (TZ, TY; TX = 16) that vdm_conv_fwd will use for this conv - mirrors launch_fwd / launch_fwd_geo
 static void fwd_tile_shape(const ConvArgs& a, int dtype, int out_f32, int ks, int stride, int ups, int& tz, int& ty) {
     tz = 4; ty = 8;
-    if (stride == 2) { tz = 2; ty = 4; return; }
+    if (stride == 2) { tz = s2_tile_z(); ty = 4; return; }
     if (uses_kpack(dtype, ks, stride, ups, a.Cin, a.Cout, out_f32)) return;
     if (ks == 3 && dtype == VDM_BF16) {
         small_grid_tile(a, tz, ty);

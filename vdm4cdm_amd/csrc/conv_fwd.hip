@@ -338,7 +338,7 @@ static int launch_ksplit(const ConvArgs& a0, hipStream_t s) {
 template <typename T, typename TO, int KS, int STRIDE, int UPS, int NC, bool GNB = false>
 static int launch_fwd_geo(const ConvArgs& a, hipStream_t s) {
     if constexpr (STRIDE == 2)
-        return launch_fwd_cfg<T, TO, KS, STRIDE, UPS, NC, 2, 4>(a, s);
+        return s2_tile_z() == 1 ? launch_fwd_cfg<T, TO, KS, STRIDE, UPS, NC, 1, 4>(a, s) : launch_fwd_cfg<T, TO, KS, STRIDE, UPS, NC, 2, 4>(a, s);
     else if constexpr (KS == 3 && sizeof(T) == 2) {
         int tz, ty;
         small_grid_tile(a, tz, ty);
