@@ -9,6 +9,10 @@ trainVDM3D128_c_c thick_lowbatch: chs [32,64,128,256], batch 2 per GPU, bf16 sto
 forward diffusion + UNet forward + ELBO + UNet backward + gradient all-reduce (N>1) + global-norm clip + AdamW,
 on synthetic lognormal density cubes already resident in HBM.  Metric: 3D voxels/s = N * B * D^3 / step time.
 
+Launch: under torchrun (RANK / LOCAL_RANK / WORLD_SIZE in the environment) every rank runs main(); a plain `python bench.py --gpus N`
+with N > 1 starts the N rank processes itself (fresh children, started before the parent touches the GPU) and forwards rank 0's line.
+A run that was asked for N GPUs never prints a line for fewer.
+
 Rank 0 prints ONE JSON line (contract in the task statement) with two extra objects:
   roofline     - the dominant kernel (3^3 implicit-GEMM conv on bf16 MFMA): algorithmic FLOPs of its launches in the
                  timed region / their summed HIP-event durations, against the 2.5 PFLOP/s dense bf16 MFMA peak;
@@ -103,6 +107,32 @@ def cpu_baseline(chs):
                       f"{med(t128):.2f} s (warm-up {w128:.1f} s); C2 64^3 batch 2 {med(t64):.2f} s (warm-up {w64:.1f} s)"}
 
 
+def self_spawn(n, argv):
+    """`python bench.py --gpus N` (N > 1) outside torchrun: start the N ranks as fresh child processes of this one - which has not
+    made a single HIP call (and never execs after one) - with the torchrun environment on 127.0.0.1, forward rank 0's stdout (the
+    JSON line) and return the worst exit code.  VDM4CDM_SHARE_GPU=1 (+ VDM4CDM_DIST_BACKEND=gloo) rehearses the same path on one GPU."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    procs = []
+    for rank in range(n):
+        env = dict(os.environ, RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env,
+                                      stdout=subprocess.PIPE if rank == 0 else subprocess.DEVNULL))
+    out0, _ = procs[0].communicate()
+    codes = [procs[0].returncode] + [p.wait() for p in procs[1:]]
+    sys.stdout.write(out0.decode("utf-8", "replace"))
+    sys.stdout.flush()
+    bad = [(r, c) for r, c in enumerate(codes) if c != 0]
+    if bad:
+        print(f"bench.py: rank processes failed (rank, exit code): {bad}", file=sys.stderr)
+    return max(abs(c) for c in codes)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -115,10 +145,15 @@ def main():
                     help="HIP events around EVERY kernel launch (full per-kernel table; ~600 event pairs per step cost ~6 %% of the step)."
                          " Default: only the 3^3 conv fwd/dgrad launches, the candidates for the dominant kernel (~50 per step)")
     ap.add_argument("--per-step", action="store_true", help="diagnostic: synchronise after every timed step and print its duration to stderr")
+    ap.add_argument("--sample-only", action="store_true",
+                    help="skip the training steps: only the --sample-steps reverse-diffusion sample is timed (e.g. --config c256 "
+                         "--sample-steps 250, the configuration of the reference's one published rate)")
     ap.add_argument("--sample-steps", type=int, default=1000,
                     help="after the training steps, rank 0 also times an n-step reverse-diffusion sample of one cube (second half of the "
                          "BASELINE metric: 1000-step sample wall-clock; reported under \"sample\", never part of \"value\"); 0 = skip")
     args = ap.parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:          # plain `python bench.py --gpus N`: become the launcher
+        sys.exit(self_spawn(args.gpus, sys.argv[1:]))
 
     import torch.distributed as dist
     from vdm4cdm_amd import hip_ops
@@ -126,7 +161,11 @@ def main():
 
     assert torch.cuda.is_available(), "bench.py needs a GPU (the HIP path has no CPU fallback)"
     rank, local_rank, world = init_distributed("cuda")
-    assert world == args.gpus or world == 1, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+    if world != args.gpus:                                        # never report a line for fewer GPUs than were asked for
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}: refusing to measure a different job than requested")
+    if local_rank >= torch.cuda.device_count():
+        raise SystemExit(f"bench.py: rank {rank} needs GPU {local_rank} but this node shows {torch.cuda.device_count()} "
+                         "(VDM4CDM_SHARE_GPU=1 VDM4CDM_DIST_BACKEND=gloo rehearses N ranks on one GPU)")
     device = f"cuda:{local_rank}"
     torch.cuda.set_device(local_rank)
 
@@ -154,85 +193,99 @@ def main():
         opt.step()
         return loss
 
-    for _ in range(2):          # setup, not warm-up: sizes the caching allocator's pools (main + side streams) and packs the weights once
-        step()
-    for _ in range(args.warmup):
-        step()
-    prof = None
-    if not args.no_kernel_events:
-        prof = hip_ops.PROFILER = hip_ops.KernelProfiler(None if args.all_kernel_events else {"conv3"})
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    per_step = []
-    for i in range(args.steps):
-        if args.per_step:
-            torch.cuda.synchronize()
+    loss, prof, elapsed, ms_per_step, value = None, None, 0.0, None, None
+    if not args.sample_only:
+        for _ in range(2):      # setup, not warm-up: sizes the caching allocator's pools (main + side streams) and packs the weights once
+            step()
+        for _ in range(args.warmup):
+            step()
+        if not args.no_kernel_events:
+            prof = hip_ops.PROFILER = hip_ops.KernelProfiler(None if args.all_kernel_events else {"conv3", "wgrad"})
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        per_step = []
+        for i in range(args.steps):
+            if args.per_step:
+                torch.cuda.synchronize()
+                per_step.append(time.perf_counter())
+            # per-launch events perturb the step (~3 % even for the conv launches alone): sample every 5th timed step unless asked for all
+            hip_ops.PROFILER = prof if (args.all_kernel_events or i % 5 == 0) else None
+            loss = step()
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        elapsed = time.perf_counter() - t0
+        if args.per_step and rank == 0:
             per_step.append(time.perf_counter())
-        # per-launch events perturb the step (~3 % even for the conv launches alone): sample every 5th timed step unless asked for all
-        hip_ops.PROFILER = prof if (args.all_kernel_events or i % 5 == 0) else None
-        loss = step()
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    elapsed = time.perf_counter() - t0
-    if args.per_step and rank == 0:
-        per_step.append(time.perf_counter())
-        print("per-step ms:", " ".join(f"{1e3 * (b - a):.2f}" for a, b in zip(per_step, per_step[1:])), file=sys.stderr, flush=True)
-    hip_ops.PROFILER = None
-    el = torch.tensor([elapsed], device=device, dtype=torch.float64)
-    if world > 1:
-        dist.all_reduce(el, op=dist.ReduceOp.MAX)
-    elapsed = el.item()
-    ms_per_step = 1e3 * elapsed / args.steps
-    voxels_per_step = world * B * D ** 3
-    value = voxels_per_step * args.steps / elapsed
+            print("per-step ms:", " ".join(f"{1e3 * (b - a):.2f}" for a, b in zip(per_step, per_step[1:])), file=sys.stderr, flush=True)
+        hip_ops.PROFILER = None
+        el = torch.tensor([elapsed], device=device, dtype=torch.float64)
+        if world > 1:
+            dist.all_reduce(el, op=dist.ReduceOp.MAX)
+        elapsed = el.item()
+        ms_per_step = 1e3 * elapsed / args.steps
+        value = world * B * D ** 3 * args.steps / elapsed
 
     if rank == 0:
         scale = 1.0 if chs == [32, 64, 128, 256] else None
         out = {
             "metric": f"3D voxels/sec UNet fwd+bwd @{D}^3 (VDM training step)", "value": value, "unit": "voxels/s",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
+            "n_gpus": world, "steps": 0 if args.sample_only else args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": precision, "data": "synthetic",
             "config": {"workload": f"{args.config}: {D}^3 conditional VDM (trainVDM3D128_c_c thick_lowbatch), chs {chs}, "
                                    f"batch {B}/GPU, full training step (diffuse + UNet fwd + ELBO + UNet bwd + clip + AdamW), dropout 0.1",
                        "global_batch": world * B, "cube": D, "parallelism": f"dp{world}"},
-            "loss": float(loss),
+            "loss": None if loss is None else float(loss),
         }
         roof = {}
         if prof is not None:
             agg = prof.summary()
-            conv = {k: v for k, v in agg.items() if k.startswith("conv_fwd_kernel") and ",k3,s1," in k}
-            dom_key = max(conv, key=lambda k: conv[k]["ms"]) if conv else None
-            total_ms = elapsed * 1e3
-            if dom_key:
-                d = conv[dom_key]
+            ev_steps = args.steps if args.all_kernel_events else len(range(0, args.steps, 5))
+            total_ms = elapsed * 1e3 * ev_steps / args.steps
+
+            def roofline_of(key):
+                d = agg[key]
                 ach = d["flops"] / (d["ms"] * 1e-3)
+                return {"kernel": key, "achieved": ach / 1e12, "peak": MFMA_PEAK[precision] / 1e12, "unit": "TFLOP/s",
+                        "frac": ach / MFMA_PEAK[precision],
+                        "algorithmic_flop_per_launch": d["flops"] / d["launches"], "executed_flop_per_launch": d["exec_flops"] / d["launches"],
+                        "algorithmic_bytes_per_launch": d["bytes"] / d["launches"], "launches_per_step": d["launches"] / ev_steps,
+                        "avg_launch_ms": d["ms"] / d["launches"], "ms_per_step": d["ms"] / ev_steps,
+                        "stream": "side (overlaps the main stream)" if d["side_launches"] == d["launches"] else "main (critical path)"}
+
+            # candidates: every MFMA conv family with FLOPs (3^3 forward / dgrad incl. the folded-GroupNorm and per-parity-class
+            # variants, and the weight gradients); "dominant" = the largest by summed duration on the critical path (main stream),
+            # "largest_by_total_time" = over all streams (the weight gradients run on a side stream and overlap the main stream)
+            cand = {k: v for k, v in agg.items() if v["flops"] > 0 and v["ms"] > 0}
+            main_c = {k: v for k, v in cand.items() if v["side_launches"] < v["launches"]}
+            if main_c:
+                dom_key = max(main_c, key=lambda k: main_c[k]["ms"])
                 # HBM bytes per launch: NOT measured in this run - a static profile from separate rocprofv3 --pmc passes of this same
                 # command (tools/round_profile.sh -> tools/pmc_traffic.py, FETCH_SIZE doubled per the gfx950 correction)
                 traffic, traffic_src = None, None
-                tpath = os.path.join(ROOT, "profiles", "r02_pmc_bench_traffic.json")
-                if args.config == "c3" and os.path.exists(tpath):
-                    t = json.load(open(tpath))["kernels"].get(dom_key)
-                    traffic = t["hbm_bytes_per_launch"] if t else None
-                    traffic_src = "static profile profiles/r02_pmc_bench_traffic.json (separate --pmc FETCH_SIZE / WRITE_SIZE passes)"
-                roof = {"bound": "mfma", "kernel": dom_key, "achieved": ach / 1e12, "peak": MFMA_PEAK[precision] / 1e12,
-                        "unit": "TFLOP/s", "frac": ach / MFMA_PEAK[precision], "traffic": traffic, "traffic_source": traffic_src,
-                        "algorithmic_flop_per_launch": d["flops"] / d["launches"],
-                        "executed_flop_per_launch": d["exec_flops"] / d["launches"],
-                        "algorithmic_bytes_per_launch": d["bytes"] / d["launches"],
-                        "launches": d["launches"], "avg_launch_ms": d["ms"] / d["launches"],
-                        "share_of_step_time": d["ms"] / (total_ms * (1.0 if args.all_kernel_events else len(range(0, args.steps, 5)) / args.steps)),
+                for tag in ("r03", "r02"):
+                    tpath = os.path.join(ROOT, "profiles", f"{tag}_pmc_bench_traffic.json")
+                    if args.config == "c3" and os.path.exists(tpath):
+                        t = json.load(open(tpath))["kernels"].get(dom_key)
+                        if t:
+                            traffic = t["hbm_bytes_per_launch"]
+                            traffic_src = f"static profile profiles/{tag}_pmc_bench_traffic.json (separate --pmc FETCH_SIZE / WRITE_SIZE passes)"
+                            break
+                roof = {"bound": "mfma", **roofline_of(dom_key), "traffic": traffic, "traffic_source": traffic_src,
+                        "selection": "largest summed duration among the MFMA conv families launched on the main stream",
+                        "share_of_step_time": main_c[dom_key]["ms"] / total_ms,
                         "events": "all launches, every timed step" if args.all_kernel_events
-                        else "HIP events around the 3^3 conv fwd/dgrad launches of every 5th timed step"}
-            ev_steps = args.steps if args.all_kernel_events else len(range(0, args.steps, 5))
-            out["kernels"] = {k: {"launches": v["launches"], "ms_per_step": v["ms"] / ev_steps,
+                        else "HIP events (on the launch stream) around the 3^3 conv fwd / dgrad / wgrad launches of every 5th timed step"}
+                big_key = max(cand, key=lambda k: cand[k]["ms"])
+                roof["largest_by_total_time"] = {"bound": "mfma", **roofline_of(big_key), "share_of_step_time": cand[big_key]["ms"] / total_ms}
+            out["kernels"] = {k: {"launches": v["launches"], "ms_per_step": v["ms"] / ev_steps, "side_stream": v["side_launches"] == v["launches"],
                                   "TFLOP/s": (v["flops"] / (v["ms"] * 1e-3) / 1e12) if v["flops"] else None,
                                   "executed_TFLOP/s": (v["exec_flops"] / (v["ms"] * 1e-3) / 1e12) if v["exec_flops"] else None,
                                   "GB/s": (v["bytes"] / (v["ms"] * 1e-3) / 1e9) if v["bytes"] else None}
                               for k, v in sorted(agg.items(), key=lambda kv: -kv[1]["ms"])}
-        if scale is not None:
+        if scale is not None and ms_per_step:
             alg_bytes = 3.0 * BYTES_PER_VOXEL_FWD[precision] * B * D ** 3          # per GPU per step (fwd+bwd)
             alg_flops = 3.0 * FLOP_PER_VOXEL_FWD * B * D ** 3
             roof["step_hbm_frac"] = alg_bytes / (ms_per_step * 1e-3) / HBM_PEAK
@@ -249,20 +302,34 @@ def main():
                 s = batch["conditioning"][:1]
                 v = [batch["conditioning_values"][0][:1]]
                 vdm.draw_samples(batch_size=1, n_sampling_steps=3, s_conditioning=s, v_conditionings=v)
+                z1 = torch.randn(1, 1, D, D, D, device=device)          # z_1 ~ N(0, I), resident before the clock starts
                 torch.cuda.synchronize()
                 t1 = time.perf_counter()
-                vdm.draw_samples(batch_size=1, n_sampling_steps=args.sample_steps, s_conditioning=s, v_conditionings=v)
+                z = vdm.draw_samples(batch_size=1, n_sampling_steps=args.sample_steps, z=z1, s_conditioning=s, v_conditionings=v, seed=1234)
                 torch.cuda.synchronize()
-                out["sample"] = {"steps": args.sample_steps, "seconds": time.perf_counter() - t1, "cube": D, "batch": 1,
-                                 "note": "one chain on rank 0, hipGraph-captured denoise step; chains on other GPUs are independent"}
+                secs = time.perf_counter() - t1
+                finite = bool(torch.isfinite(z).all())
+                out["sample"] = {"steps": args.sample_steps, "seconds": secs, "steps_per_s": args.sample_steps / secs, "cube": D, "batch": 1,
+                                 "finite": finite, "std": float(z.std()), "mean": float(z.mean()),
+                                 "note": "one chain on rank 0, hipGraph-captured denoise step, in-kernel Philox noise (seed 1234); "
+                                         "chains on other GPUs are independent"}
+                if not finite:
+                    raise RuntimeError(f"the {args.sample_steps}-step sample is not finite")
+                if args.config == "c256":      # context only: the one rate the reference publishes, other hardware
+                    out["sample"]["reference_published"] = {
+                        "value": 2.50, "unit": "denoise steps/s", "steps": 250, "cube": 256, "chs": [16, 32, 64, 128],
+                        "hardware": "one NVIDIA GPU of the 80 GB class (model not stated)",
+                        "source": "/root/reference ICML_figures.ipynb cell 103 (tqdm rate), configs.yaml:127-143, generate_3D.py:61"}
             except Exception as e:                          # never lose the training line over the secondary measurement
-                out["sample"] = {"error": repr(e)}
-        if not args.no_cpu_baseline and world == 1:
+                out["sample"] = dict(out.get("sample") or {}, error=repr(e))
+        if not args.no_cpu_baseline and world == 1 and not args.sample_only:
             try:
                 out["cpu_baseline"] = cpu_baseline(chs)
             except Exception as e:                          # never lose the GPU line over the host-side baseline
                 out["cpu_baseline"] = {"error": repr(e)}
         print(json.dumps(out), flush=True)
+        if "error" in (out.get("sample") or {}) and args.sample_only:
+            raise SystemExit(3)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()

@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define VDM_ABI_VERSION 5
+#define VDM_ABI_VERSION 6
 
 typedef enum { VDM_OK = 0, VDM_ERR_ARG = -1, VDM_ERR_HIP = -2, VDM_ERR_UNSUPPORTED = -3 } vdm_status;
 typedef enum { VDM_F32 = 0, VDM_BF16 = 1 } vdm_dtype;
@@ -185,7 +185,9 @@ int vdm_pack_input(const float* a, const float* b, int64_t nvox, int cpad, int d
  * table[row][w] = sum_k c_k[row] . wproj_k[w]   over the concatenated output channels w of all blocks.
  * `mlps` is a HOST array of n <= 4 descriptors holding DEVICE pointers.  saved: vdm_cond_saved_floats() floats kept for the
  * backward (may be NULL for inference).  bwd writes dw1/db1/dw2/db2/dwproj of every descriptor (plain stores) and, if dbias is
- * given, dbias[w] = sum_rows dtable[row][w] (the conv1 bias gradients); scratch: >= 2 * rows * sum_k dim_k floats.
+ * given, dbias[w] = sum_rows dtable[row][w] (the conv1 bias gradients); scratch: >= vdm_cond_bwd_scratch_floats() floats
+ * (the per-row (dh1, dh2) vectors + the fixed-order slab partials of dtable . Wproj).  Widths: in_dim, dim <= 256; a weight matrix whose
+ * row length is a multiple of 4 must be 16-byte aligned.  rows <= 65535 per call.
  * step: table[b] = table_t[*step_ptr] + table_v[b] (either may be NULL) - the per-step row gather of the captured sampler graph. */
 typedef struct vdm_cond_mlp {
     const float* input;
@@ -196,6 +198,7 @@ typedef struct vdm_cond_mlp {
     float* dw1; float* db1; float* dw2; float* db2; float* dwproj; /* backward outputs (NULL in forward) */
 } vdm_cond_mlp;
 size_t vdm_cond_saved_floats(const vdm_cond_mlp* mlps, int n, int rows);
+size_t vdm_cond_bwd_scratch_floats(const vdm_cond_mlp* mlps, int n, int rows, int width);
 int vdm_cond_table_fwd(const vdm_cond_mlp* mlps, int n, int rows, int width, float* table, float* saved, void* stream);
 int vdm_cond_table_bwd(const vdm_cond_mlp* mlps, int n, int rows, int width, const float* dtable, int64_t dtable_stride,
                        const float* saved, float* scratch, float* dbias, void* stream);

@@ -99,25 +99,70 @@ def test_astro_datamodule_host_logic(tmp_path):
     assert isinstance(syn, data.SyntheticAstroDataModule)
 
 
-def test_astro_datamodule_rank_shards_are_disjoint_and_complete(tmp_path):
-    """Data parallelism: rank r of `world` walks items r, r + world, ... of the same shuffled epoch (same seed on every rank)."""
+def _record_epochs(dm, rank, world, n_epochs, loader="train"):
+    """Item indices and augmentation tuples a rank draws per epoch (make_batch replaced by a recorder: no GPU)."""
+    picked = []
+    real_draw = dm.draw_sample
+    dm.draw_sample = lambda idx, train, gen=None: picked.append((idx, real_draw(idx, train, gen))) or picked[-1][1]
+    batches = []
+    dm.make_batch = lambda samples: batches.append(len(samples)) or {}
+    epochs = []
+    for _ in range(n_epochs):
+        del picked[:], batches[:]
+        it = dm.train_dataloader(rank, world) if loader == "train" else dm.val_dataloader(rank, world)
+        for _ in it:
+            pass
+        epochs.append((list(picked), list(batches)))
+    dm.draw_sample = real_draw
+    return epochs
+
+
+@pytest.mark.parametrize("world,n_sims,bs", [(2, 8, 2), (3, 7, 2), (8, 6, 2)], ids=["w2_even", "w3_ragged", "w8_tiny"])
+def test_astro_datamodule_rank_shards_are_equal_and_complete(tmp_path, world, n_sims, bs):
+    """Data parallelism: every rank walks a strided shard of the SAME shuffled epoch (same seed on every rank), all
+    shards have the same number of FULL batches also when len(train) % (world * batch) != 0 (wrap-around padding: DistributedSampler
+    semantics - repeat, never drop), and together they cover every training item; a rank is never left without a batch."""
     from vdm4cdm_amd import data
-    root = _dataset(tmp_path, n_sims=6, S=8)
+    root = _dataset(tmp_path, n_sims=n_sims, S=8)
     seen = []
-    for rank in range(2):
-        dm = data.get_dataset(dataset_name="CMD_128", stage="fit", batch_size=2, cropsize=8, data_root=root, seed=5)
-        picked = []
-        real_draw = dm.draw_sample
-        dm.draw_sample = lambda idx, train, picked=picked, real_draw=real_draw: picked.append(idx) or real_draw(idx, train)
-        dm.make_batch = lambda samples: {}                    # (record instead of launching)
-        epochs = []
-        for _ in range(3):                                    # the shards must stay disjoint epoch after epoch
-            del picked[:]
-            for _ in dm.train_dataloader(rank, 2):
-                pass
-            epochs.append(list(picked))
-        seen.append(epochs)
+    for rank in range(world):
+        dm = data.get_dataset(dataset_name="CMD_128", stage="fit", batch_size=bs, cropsize=8, data_root=root, seed=5)
+        seen.append(_record_epochs(dm, rank, world, 3))
+    n_train = len(dm.train_idx)
+    per_rank = -(-n_train // (world * bs)) * bs
     for e in range(3):
-        assert not set(seen[0][e]) & set(seen[1][e]), f"epoch {e}: ranks overlap"
-        assert sorted(seen[0][e] + seen[1][e]) == sorted(dm.train_idx)
-    assert seen[0][0] != seen[0][1], "epochs are reshuffled"
+        items = [[i for i, _ in seen[r][e][0]] for r in range(world)]
+        assert all(len(it) == per_rank for it in items), f"epoch {e}: unequal shards {[len(it) for it in items]}"
+        assert all(seen[r][e][1] == [bs] * (per_rank // bs) for r in range(world)), "every batch is full, same count on every rank"
+        flat = [i for it in items for i in it]
+        assert set(flat) == set(dm.train_idx), f"epoch {e}: items missing"
+        if n_train % (world * bs) == 0:
+            assert len(set(flat)) == len(flat), f"epoch {e}: ranks overlap without padding"
+    if n_train > 2:
+        assert any([i for i, _ in seen[0][0][0]] != [i for i, _ in seen[0][e][0]] for e in (1, 2)), "epochs are reshuffled"
+    # world = 1: the reference's single-process loader, nothing padded
+    dm = data.get_dataset(dataset_name="CMD_128", stage="fit", batch_size=bs, cropsize=8, data_root=root, seed=5)
+    ep = _record_epochs(dm, 0, 1, 1)[0]
+    assert sorted(i for i, _ in ep[0]) == sorted(dm.train_idx)
+
+
+def test_validation_never_touches_the_training_augmentation_stream(tmp_path):
+    """Regression (advisor, round 2): on rank r > 0 a validation pass used to re-seed the augmentation generator with rank 0's seed,
+    and the next training epoch re-seeded it again with the initial per-rank seed - the (shift, flip, permutation) draws of every
+    rank > 0 replayed with the validation period.  Now: train -> val -> train on rank 1 draws exactly what train -> train draws, the
+    second epoch does not replay the first, and rank 1's stream differs from rank 0's."""
+    from vdm4cdm_amd import data
+    root = _dataset(tmp_path, n_sims=8, S=16)
+    mk = lambda: data.get_dataset(dataset_name="CMD_128", stage="fit", batch_size=2, cropsize=8, data_root=root, seed=5)
+    augs = lambda ep: [a[1:] for _, a in ep[0]]                # (anchor, flips, perm) per drawn sample
+    a = mk()
+    plain = _record_epochs(a, 1, 2, 2)
+    b = mk()
+    first = _record_epochs(b, 1, 2, 1)[0]
+    _record_epochs(b, 1, 2, 1, loader="val")
+    _record_epochs(b, 0, 2, 1, loader="val")                   # (also the default-rank call of a user script)
+    second = _record_epochs(b, 1, 2, 1)[0]
+    assert augs(first) == augs(plain[0]) and augs(second) == augs(plain[1]), "validation disturbed the training augmentation stream"
+    assert augs(plain[0]) != augs(plain[1]), "epoch 2 replays the augmentation draws of epoch 1"
+    r0 = _record_epochs(mk(), 0, 2, 1)[0]
+    assert augs(r0) != augs(plain[0]), "ranks share one augmentation stream"

@@ -148,3 +148,18 @@ def test_train_uc_c_entry_runs_on_cpu(tmp_path):
                        capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stderr[-3000:]
     assert os.path.exists(tmp_path / "LH_uc_c_Mcdm" / "metrics.jsonl")
+
+
+def test_bench_never_prints_a_line_for_fewer_gpus_than_asked():
+    """`python bench.py --gpus 2` outside torchrun starts two rank processes itself; here (no GPU) they fail, and the launcher must
+    return non-zero WITHOUT printing a JSON line - in particular never an n_gpus = 1 line for a 2-GPU request."""
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present: the self-spawn path is covered by tests/test_entry_gpu.py::test_bench_self_spawn_two_ranks_share_one_gpu")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"], env=env, cwd=root,
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode != 0
+    assert not [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert "rank processes failed" in r.stderr

@@ -215,6 +215,28 @@ def test_bench_two_ranks_share_one_gpu(tmp_path):
     assert d["value"] == pytest.approx(2 * 2 * 32 ** 3 / (d["ms_per_step"] * 1e-3), rel=1e-6)
 
 
+def test_bench_self_spawn_two_ranks_share_one_gpu():
+    """`python bench.py --gpus 2` WITHOUT a torchrun environment: bench.py starts the two rank processes itself (the parent never
+    touches the GPU) and forwards rank 0's line, n_gpus = 2.  A mismatching WORLD_SIZE is refused instead of silently measured."""
+    import json
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT")}
+    env.update(VDM4CDM_SHARE_GPU="1", VDM4CDM_DIST_BACKEND="gloo")
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--config", "tiny", "--steps", "4", "--warmup", "2", "--no-cpu-baseline", "--sample-steps", "0"]
+    r = subprocess.run(cmd + ["--gpus", "2"], env=env, cwd=ROOT, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    lines = [ln for ln in r.stdout.strip().splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["config"]["global_batch"] == 4 and d["config"]["parallelism"] == "dp2"
+    assert d["value"] == pytest.approx(2 * 2 * 32 ** 3 / (d["ms_per_step"] * 1e-3), rel=1e-6)
+    assert d["roofline"]["kernel"] and d["roofline"]["largest_by_total_time"]["kernel"]
+    # --gpus 4 inside a WORLD_SIZE=1 environment: refused, no line
+    r = subprocess.run(cmd + ["--gpus", "4"], env=dict(env, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0"), cwd=ROOT, capture_output=True,
+                       text=True, timeout=900)
+    assert r.returncode != 0 and not [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert "refusing" in r.stderr
+
+
 def _ss_cases():
     import importlib.util
     spec = importlib.util.spec_from_file_location("test_entry_cpu_mod", os.path.join(ROOT, "tests", "test_entry_cpu.py"))

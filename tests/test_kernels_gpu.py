@@ -483,8 +483,9 @@ def test_gn_bwd_folded_into_dgrad(case, dtype):
 
 # ------------------------------------------------------------------------------------------ K6: conditioning table
 @pytest.mark.parametrize("cfg", [dict(t=True, vd=(6,), chs=(32, 64, 128, 256), B=2), dict(t=True, vd=(), chs=(16, 32), B=3),
-                                 dict(t=False, vd=(6, 3), chs=(16, 32, 64), B=1), dict(t=True, vd=(6, 3), chs=(16, 32), B=4)],
-                         ids=["c3", "t_only", "v_only_two", "t_and_two_v"])
+                                 dict(t=False, vd=(6, 3), chs=(16, 32, 64), B=1), dict(t=True, vd=(6, 3), chs=(16, 32), B=4),
+                                 dict(t=True, vd=(6,), chs=(48, 96, 192, 384), B=2), dict(t=True, vd=(5,), chs=(64, 128), B=3)],
+                         ids=["c3", "t_only", "v_only_two", "t_and_two_v", "chs48_width192", "chs64_width256"])
 def test_cond_table_kernel(cfg):
     """K6 (sinusoid -> 2 x (Linear + GELU) -> projections of all blocks, one launch) against the oracle's
     sinusoidal_embedding / _mlp2 / per-block Linear on the CPU (fp32, 1e-5 relative), and its backward (2 launches) against
@@ -540,6 +541,49 @@ def test_cond_table_kernel(cfg):
         out = torch.empty(B, net.table_width, device=DEV)
         ops.cond_table_step(tt, table, step, B, net.table_width, out)
         assert torch.equal(out, tt[3][None] + table)
+
+
+@pytest.mark.parametrize("rows", [250, 1000])
+def test_cond_table_all_sampling_steps(rows):
+    """C5: the sampler embeds the time values of ALL n steps with one K6 launch (rows = n_sampling_steps: 250 = the reference default,
+    generate_3D.py:61; 1000 = BASELINE C5) and gathers row *step inside the captured graph.  Every row of the table against the
+    oracle's sinusoidal_embedding / _mlp2 / per-block Linear on the fp32 time grid of VDM.step_table; then the device-side gather."""
+    import sys
+    import os
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from oracle import unet_oracle
+    from helpers import oracle_params, randomize
+    from vdm4cdm_amd.networks import CUNet
+    from vdm4cdm_amd.vdm_model import VDM
+    ops = _ops()
+    net = CUNet(shape=(1, 16, 16, 16), chs=[32, 64, 128, 256], s_conditioning_channels=0, v_conditioning_dims=[6], t_conditioning=True,
+                norm_groups=8, backend="hip", precision="fp32")
+    randomize(net, 6)
+    coef = VDM(net).step_table(rows).float()
+    t = coef[:, 3].contiguous()
+    assert t.shape == (rows,) and t[0].item() == 1.0 and 0.0 < t[-1].item() < 2.0 / rows
+    P = oracle_params(net)
+    c = unet_oracle._mlp2(P, "t_embed", unet_oracle.sinusoidal_embedding(t))
+    ref = torch.cat([F.linear(c, P[f"{b.name}.cond.0.weight"]) for b in net.blocks], dim=1)
+    flat = net.flat.detach().to(DEV)
+    tt = ops.CondTable(net.cond_specs(t.to(DEV), None, flat, which="t"), rows, net.table_width).forward(save=False)
+    assert tt.shape == ref.shape == (rows, net.table_width)
+    err = (tt.cpu() - ref).abs().max(dim=1).values
+    assert err.max().item() <= 1e-5 * ref.abs().max().item() + 1e-6, f"row {int(err.argmax())}: {err.max().item()}"
+    v = torch.rand(2, 6, generator=torch.Generator().manual_seed(2))
+    tv = ops.CondTable(net.cond_specs(None, [v.to(DEV)], flat, which="v"), 2, net.table_width).forward(save=False)
+    out = torch.empty(2, net.table_width, device=DEV)
+    for s in (0, 1, rows // 2, rows - 1):
+        ops.cond_table_step(tt, tv, torch.tensor([s], dtype=torch.int32, device=DEV), 2, net.table_width, out)
+        assert torch.equal(out, tt[s][None] + tv)
+
+
+def test_cond_table_rejects_unsupported_widths():
+    """4 * chs[0] > 256 exceeds the K6 kernel's LDS vectors: CUNet(backend="hip") must say so at construction, not at the first forward."""
+    from vdm4cdm_amd.networks import CUNet
+    with pytest.raises(ValueError, match="chs\\[0\\]"):
+        CUNet(shape=(1, 16, 16, 16), chs=[96, 192], t_conditioning=True, backend="hip")
+    CUNet(shape=(1, 16, 16), chs=[96, 192], t_conditioning=True, backend="torch")          # the torch backend has no such limit
 
 
 # ------------------------------------------------------------------------------------------ small ops

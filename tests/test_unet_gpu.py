@@ -14,6 +14,7 @@ import torch
 from helpers import grf, oracle_cfg, oracle_params, randomize
 
 pytestmark = pytest.mark.gpu
+import vdm4cdm_amd.vdm_model as vdm_model_mod            # noqa: E402
 DEV = "cuda:0"
 
 
@@ -531,6 +532,7 @@ def test_c4_192_training_step_properties():
         torch.manual_seed(11)
         import vdm4cdm_amd.unet_hip as uh
         uh._seed_counter[0] = 0
+        vdm_model_mod.reset_train_generators()
         vdm.zero_grad()
         loss = vdm.training_step(batch, 0)
         loss.backward()
@@ -582,6 +584,7 @@ def test_full_size_128_cfg_sfm_attention_properties():
     for rep in range(2):
         torch.manual_seed(3)
         uh._seed_counter[0] = 0
+        vdm_model_mod.reset_train_generators()
         sfm.zero_grad()
         loss = sfm.training_step({"x0": s, "x1": x, "conditioning_values": v}, 0)
         loss.backward()
@@ -642,6 +645,113 @@ def test_c5_sampler_128_power_spectrum():
             assert err <= 2e-3 * ref.abs().max().item(), f"fp32 sampler err {err} vs max|ref| {ref.abs().max().item()}"
         del vdm, net
         torch.cuda.empty_cache()
+
+
+def _randn_list(shape, n, seed):
+    g = torch.Generator().manual_seed(seed)
+    return [torch.randn(shape, generator=g) for _ in range(n)]
+
+
+@pytest.mark.parametrize("D,n", [(16, 1000), (16, 250), (32, 250)], ids=["16cube_1000", "16cube_250", "32cube_250"])
+def test_c5_long_chain_hipgraph_matches_oracle(D, n):
+    """BASELINE config C5 at its step counts: the hipGraph sampler with n = 1000 (C5) and n = 250 (the reference default,
+    generate_3D.py:61) - the n-row K6 time table, the n-row device step table and n replays of one captured graph - against
+    oracle/vdm_oracle.sample on the same weights, z_1 and per-step noise.  fp32: element-wise <= 2e-3 * max|ref| and P(k) <= 1 % per
+    k-bin; bf16 storage: P(k) <= 1 % per k-bin (the acceptance metric of BASELINE.json).  Weights: near-identity denoiser
+    (zero_init_std 0.01), the non-expansive chain a trained network produces; the expansive case is
+    test_c5_expansive_chain_bf16_power_spectrum."""
+    from oracle import unet_oracle, vdm_oracle
+    from vdm4cdm_amd import utils
+    torch.set_num_threads(min(64, os.cpu_count() or 8))
+    chs = (16, 32, 64) if D == 16 else (16, 32)
+    ref = None
+    for precision in ("fp32", "bf16"):
+        net = make_net(D=D, chs=chs, precision=precision, seed=4)
+        randomize(net, 4, zero_init_std=0.01)
+        x, _, s, v = inputs(net, 1, seed=7)
+        z1 = grf(x.shape, 9, slope=0.0)
+        noises = _randn_list(x.shape, n, 100)
+        if ref is None:
+            P = oracle_params(net)
+            with torch.no_grad():
+                ref = vdm_oracle.sample(lambda z, tn: unet_oracle.cunet_forward(P, oracle_cfg(net), z, tn, s, v),
+                                        vdm_oracle.Schedule(-13.3, 13.3), z1.clone(), n, noises)
+            _, pk_ref, n_ref = utils.pk(ref)
+        vdm = make_vdm(net).to(DEV).eval()
+        out = vdm.draw_samples(batch_size=1, n_sampling_steps=n, z=z1.clone(), noises=noises, use_graph=True,
+                               s_conditioning=s.to(DEV), v_conditionings=[a.to(DEV) for a in v])
+        assert torch.isfinite(out).all()
+        _, pk_hip, n_hip = utils.pk(out)
+        assert torch.equal(n_hip.cpu(), n_ref)
+        dpk = (pk_hip.cpu() / pk_ref - 1).abs().max().item()
+        err = (out.cpu() - ref).abs().max().item() / ref.abs().max().item()
+        print(f"C5 chain D={D} n={n} {precision}: max|d|/max|ref| {err:.3e}, max P(k) deviation {dpk:.3e}")
+        assert dpk < 1e-2, f"{precision}: P(k) off by {dpk:.3e} after {n} steps"
+        if precision == "fp32":
+            assert err <= 2e-3, f"fp32 chain err {err} after {n} steps"
+
+
+def test_c5_expansive_chain_bf16_power_spectrum():
+    """Where bf16 storage lands on an EXPANSIVE chain (random untrained weights with zero_init_std 0.05: every early step amplifies
+    perturbations by alpha_s/alpha_t-driven gains, see test_sampler_matches_oracle): 32^3, 50 steps, supplied noise, vs the oracle chain.
+    fp32 must still track the oracle (<= 2e-3 * max|ref| element-wise, P(k) <= 1 %); for bf16 the bound asserted here is the measured
+    one with margin (P(k) per k-bin <= 5 %) - the 1 % acceptance bound is a statement about the tame chain above, and this test pins
+    the distance between the two regimes."""
+    from oracle import unet_oracle, vdm_oracle
+    from vdm4cdm_amd import utils
+    torch.set_num_threads(min(64, os.cpu_count() or 8))
+    D, n = 32, 50
+    ref = None
+    for precision, tol_pk in (("fp32", 1e-2), ("bf16", 5e-2)):
+        net = make_net(D=D, chs=(16, 32, 64), precision=precision, seed=4)
+        randomize(net, 4, zero_init_std=0.05)
+        x, _, s, v = inputs(net, 1, seed=7)
+        z1 = grf(x.shape, 9, slope=0.0)
+        noises = _randn_list(x.shape, n, 200)
+        if ref is None:
+            P = oracle_params(net)
+            with torch.no_grad():
+                ref = vdm_oracle.sample(lambda z, tn: unet_oracle.cunet_forward(P, oracle_cfg(net), z, tn, s, v),
+                                        vdm_oracle.Schedule(-13.3, 13.3), z1.clone(), n, noises)
+            _, pk_ref, _ = utils.pk(ref)
+        vdm = make_vdm(net).to(DEV).eval()
+        out = vdm.draw_samples(batch_size=1, n_sampling_steps=n, z=z1.clone(), noises=noises, use_graph=True,
+                               s_conditioning=s.to(DEV), v_conditionings=[a.to(DEV) for a in v])
+        assert torch.isfinite(out).all()
+        _, pk_hip, _ = utils.pk(out)
+        dpk = (pk_hip.cpu() / pk_ref - 1).abs().max().item()
+        err = (out.cpu() - ref).abs().max().item() / ref.abs().max().item()
+        print(f"expansive chain {precision}: max|ref| {ref.abs().max().item():.3e}, max|d|/max|ref| {err:.3e}, max P(k) deviation {dpk:.3e}")
+        assert dpk < tol_pk, f"{precision}: P(k) off by {dpk:.3e}"
+        if precision == "fp32":
+            assert err <= 2e-3
+
+
+def test_return_all_runs_the_captured_graph():
+    """draw_samples(return_all=True) (frame vdm_model.py:429-442) on the HIP backend: the stack of z after every step comes from the
+    same captured graph as the plain call - last entry bit-identical to it, every entry identical to the eager (uncaptured) kernel
+    sequence, and the last entry equal to the oracle chain."""
+    from oracle import unet_oracle, vdm_oracle
+    net = make_net(precision="fp32", **CFGS[0])
+    vdm = make_vdm(net).to(DEV).eval()
+    n = 12
+    x, _, s, v = inputs(net, 1)
+    z1 = grf(x.shape, 60, slope=0.0)
+    noises = _randn_list(x.shape, n, 300)
+    kw = dict(s_conditioning=s.to(DEV), v_conditionings=[a.to(DEV) for a in v])
+    last = vdm.draw_samples(batch_size=1, n_sampling_steps=n, z=z1.clone(), noises=noises, **kw)
+    stack = vdm.draw_samples(batch_size=1, n_sampling_steps=n, z=z1.clone(), noises=noises, return_all=True, **kw)
+    eager = vdm.draw_samples(batch_size=1, n_sampling_steps=n, z=z1.clone(), noises=noises, return_all=True, use_graph=False, **kw)
+    assert stack.shape == (n, 1, 1, 16, 16, 16) and torch.equal(stack[-1], last) and torch.equal(stack, eager)
+    assert not torch.equal(stack[0], stack[1])
+    P = oracle_params(net)
+    ref = vdm_oracle.sample(lambda z, tn: unet_oracle.cunet_forward(P, oracle_cfg(net), z, tn, s, v), vdm_oracle.Schedule(-13.3, 13.3),
+                            z1.clone(), n, noises)
+    assert (stack[-1].cpu() - ref).abs().max().item() <= 2e-5 * ref.abs().max().item() + 1e-3
+    # seeded in-kernel noise: the stack is reproducible
+    a = vdm.draw_samples(batch_size=1, n_sampling_steps=5, return_all=True, seed=3, **kw)
+    b = vdm.draw_samples(batch_size=1, n_sampling_steps=5, return_all=True, seed=3, **kw)
+    assert torch.equal(a, b) and torch.isfinite(a).all()
 
 
 def test_dropout_follows_module_mode_not_autograd():

@@ -138,7 +138,12 @@ def main(argv=None, configs_path=None):
                 if i_batch in i_gens:
                     ground_truth(batch, names[i_gens.index(i_batch)])
             for name in names:
-                f = os.path.join(fol, f"{name}_{rep}.npy" if key == "1P_24" else f"{name}.npy")
+                # reference quirk (calc_SS.py:232-236): 1P_128 is read as <name>.npy although generate_3D_1P.py writes <name>_<rep>.npy;
+                # accept the reference's name first (files renamed by hand, as its authors must have) and fall back to what the
+                # in-repo generate_3D_1P.py actually wrote, so that generate -> calc_SS runs without a manual rename
+                cands = [os.path.join(fol, f"{name}_{rep}.npy")] if key == "1P_24" else \
+                    [os.path.join(fol, f"{name}.npy"), os.path.join(fol, f"{name}_{rep}.npy")]
+                f = next((c for c in cands if os.path.exists(c)), cands[0])
                 assert os.path.exists(f), f"File {f} does not exist"
                 generated(np.load(f), lambda j, name=name: f"{name}_{j}")
         summary[key] = results

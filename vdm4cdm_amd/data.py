@@ -109,11 +109,11 @@ class SyntheticAstroDataModule:
     def train_dataloader(self, rank=0, world=1):
         return self._loader(self.seed + 7919 * rank, self.n_train, self.batch_size, rank, world)
 
-    def val_dataloader(self):
-        return self._loader(self.seed + 500000, self.n_val, self.batch_size)
+    def val_dataloader(self, rank=0, world=1):
+        return self._loader(self.seed + 500000, self.n_val, self.batch_size, rank, world)
 
-    def test_dataloader(self):
-        return self._loader(self.seed + 900000, self.n_test, self.batch_size)
+    def test_dataloader(self, rank=0, world=1):
+        return self._loader(self.seed + 900000, self.n_test, self.batch_size, rank, world)
 
 
 # field -> alpha of log10(rho + alpha)  [/root/reference/src/dataset/alphas_3d.json]; (mean, std) [normalizations_3d.json]
@@ -195,8 +195,10 @@ class AstroDataModule:
         # draws are per rank
         self._seed = int(seed)
         self._gen = torch.Generator().manual_seed(self._seed)                      # split + epoch shuffles (same on all ranks)
-        self._aug_gen = torch.Generator().manual_seed(self._seed + 1)              # shifts / flips / permutations (re-seeded per rank)
-        self._aug_rank = 0
+        # shifts / flips / permutations: one generator per (training rank), seeded ONCE at its first use and never again, and a
+        # separate one for the validation / test loaders - a validation pass must not touch (let alone re-seed) the training stream
+        self._aug_gens = {}
+        self._aug_gen = self._aug_generator("train", 0)
         if stage == "fit":                                       # random_split(data, [95 %, 5 %])  (CAMELS_3D_dataset.py:134-137)
             order = torch.randperm(self.nsamples, generator=self._gen).tolist()
             n_train = int(self.nsamples * 0.95)
@@ -242,17 +244,25 @@ class AstroDataModule:
             self._dev_params = torch.from_numpy(self.params).to(dev)
         return self._dev_fields
 
-    def draw_sample(self, idx, train):
+    def _aug_generator(self, kind, rank):
+        key = (kind, int(rank))
+        g = self._aug_gens.get(key)
+        if g is None:
+            g = self._aug_gens[key] = torch.Generator().manual_seed(self._seed + 1 + 7919 * int(rank) + (0 if kind == "train" else 104729))
+        return g
+
+    def draw_sample(self, idx, train, gen=None):
         """(sim, anchor, flips, perm) of dataset item `idx`: bidx, icrop = divmod(idx, ncrops) (CAMELS_3D_dataset.py:55); in the
         "fit" stage the anchor is shifted by randint(crop) per axis, flips ~ randint(2), perm ~ randperm (augmentation.py:48-49,
-        69, 113-117), all from this module's generator."""
+        69, 113-117), all from `gen` (default: this module's rank-0 training generator)."""
+        gen = self._aug_gen if gen is None else gen
         sim, icrop = divmod(int(idx), self.ncrops)
         anchor = self.anchors[icrop].copy()
         flips, perm = [0, 0, 0], [0, 1, 2]
         if train:
-            anchor = anchor + torch.randint(self.crop, (3,), generator=self._aug_gen).numpy()
-            flips = torch.randint(2, (3,), generator=self._aug_gen).tolist()
-            perm = torch.randperm(3, generator=self._aug_gen).tolist()
+            anchor = anchor + torch.randint(self.crop, (3,), generator=gen).numpy()
+            flips = torch.randint(2, (3,), generator=gen).tolist()
+            perm = torch.randperm(3, generator=gen).tolist()
         return sim, anchor.tolist(), flips, perm
 
     def make_batch(self, samples):
@@ -264,25 +274,36 @@ class AstroDataModule:
         items = [self.return_func(fields=[o[b] for o in outs], params=self._dev_params[s[0]]) for b, s in enumerate(samples)]
         return self.collate_fn(items)
 
-    def _loader(self, indices, train, shuffle, rank=0, world=1):
-        if rank != self._aug_rank:                                # (first use on this rank: its own augmentation stream)
-            self._aug_rank = rank
-            self._aug_gen.manual_seed(self._seed + 1 + 7919 * rank)
+    def shard(self, idx, rank, world):
+        """This rank's items of one epoch order.  world == 1: all of them (the reference's single-process DataLoader, a short last
+        batch included).  world > 1: the order is padded by wrap-around to a multiple of world * batch_size and dealt out strided, so
+        every rank sees the SAME number of FULL batches (torch's DistributedSampler rule: repeat, never drop) - ranks cannot drift
+        across epoch boundaries, and the global time stratification (vdm_model.stratified_times) always sees equal local batches."""
+        idx = list(idx)
+        if world <= 1 or not idx:
+            return idx
+        unit = world * self.batch_size
+        total = -(-len(idx) // unit) * unit
+        idx = (idx * (total // len(idx) + 1))[:total]
+        return idx[rank::world]
+
+    def _loader(self, indices, train, shuffle, rank=0, world=1, kind="train"):
+        gen = self._aug_generator(kind, rank)                     # (seeded once per (kind, rank); never re-seeded)
         idx = list(indices)
         if shuffle:
             idx = [idx[i] for i in torch.randperm(len(idx), generator=self._gen).tolist()]
-        idx = idx[rank::world]                                   # data parallelism: disjoint strided shards of the epoch
+        idx = self.shard(idx, rank, world)                       # data parallelism: equal-length strided shards of the epoch
         for b0 in range(0, len(idx), self.batch_size):
-            yield self.make_batch([self.draw_sample(i, train) for i in idx[b0:b0 + self.batch_size]])
+            yield self.make_batch([self.draw_sample(i, train, gen) for i in idx[b0:b0 + self.batch_size]])
 
     def train_dataloader(self, rank=0, world=1):
-        return self._loader(self.train_idx, True, True, rank, world)
+        return self._loader(self.train_idx, True, True, rank, world, "train")
 
-    def val_dataloader(self):
-        return self._loader(self.valid_idx, True, False)          # (the reference's valid split shares the "fit" transforms)
+    def val_dataloader(self, rank=0, world=1):
+        return self._loader(self.valid_idx, True, False, rank, world, "eval")          # (the reference's valid split shares the "fit" transforms)
 
-    def test_dataloader(self):
-        return self._loader(self.test_idx, False, False)
+    def test_dataloader(self, rank=0, world=1):
+        return self._loader(self.test_idx, False, False, rank, world, "eval")
 
 
 def _cv_keep(n):

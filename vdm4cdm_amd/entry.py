@@ -35,6 +35,8 @@ def _seed_everything(seed=42):
     random.seed(seed)
     np.random.seed(seed)
     torch.manual_seed(seed)
+    from .vdm_model import reset_train_generators
+    reset_train_generators()                 # the training step's own generators restart from the new seed
 
 
 def _figure_closure(dm, thickness, with_values):

@@ -21,6 +21,7 @@ class KernelProfiler:
     def __init__(self, tags=None):
         self.records = []          # (key, start, end, flops, bytes)
         self.tags = tags           # None: every launch; else only launches whose tag is in this set (event records cost time too)
+        self.main_stream = None    # launches on any other stream are marked "side" (weight gradients, skip convs: off the critical path)
 
     def begin(self):
         e = torch.cuda.Event(enable_timing=True)
@@ -30,14 +31,18 @@ class KernelProfiler:
     def end(self, start, key, flops=0.0, nbytes=0.0, exec_flops=None):
         e = torch.cuda.Event(enable_timing=True)
         e.record()
-        self.records.append((key, start, e, flops, nbytes, flops if exec_flops is None else exec_flops))
+        if self.main_stream is None:
+            self.main_stream = torch.cuda.default_stream().cuda_stream
+        side = torch.cuda.current_stream().cuda_stream != self.main_stream
+        self.records.append((key, start, e, flops, nbytes, flops if exec_flops is None else exec_flops, side))
 
     def summary(self):
         torch.cuda.synchronize()
         agg = {}
-        for key, s, e, fl, nb, xf in self.records:
-            a = agg.setdefault(key, {"launches": 0, "ms": 0.0, "flops": 0.0, "bytes": 0.0, "exec_flops": 0.0})
+        for key, s, e, fl, nb, xf, side in self.records:
+            a = agg.setdefault(key, {"launches": 0, "ms": 0.0, "flops": 0.0, "bytes": 0.0, "exec_flops": 0.0, "side_launches": 0})
             a["launches"] += 1
+            a["side_launches"] += 1 if side else 0
             a["ms"] += s.elapsed_time(e)
             a["flops"] += fl
             a["bytes"] += nb
@@ -294,7 +299,7 @@ class Conv:
         if ws is None or ws.numel() < need:
             ws = torch.empty(max(need, 32 << 20), dtype=torch.uint8, device=x.device)
             Conv._ws[wkey] = ws
-        ev = _pb()
+        ev = _pb("wgrad" if self.ksize == 3 else "other")
         check(L.vdm_conv_wgrad(d, _p(x), _p(dout), _p(dw), _p(dbias), 1 if accumulate else 0, _p(ws), ws.numel(), _s()), "vdm_conv_wgrad")
         if ev is not None:
             es = x.element_size()
@@ -469,7 +474,7 @@ class CondTable:
         L = _lib.lib()
         assert self.saved is not None and dtable.dtype == torch.float32 and dtable.stride(1) == 1 and dtable.shape[0] == self.rows
         arr = self._descs(grads)
-        scratch = torch.empty(2 * self.rows * sum(int(sp["w2"].shape[0]) for sp in self.specs), dtype=torch.float32, device=dtable.device)
+        scratch = torch.empty(L.vdm_cond_bwd_scratch_floats(arr, len(self.specs), self.rows, self.width), dtype=torch.float32, device=dtable.device)
         check(L.vdm_cond_table_bwd(arr, len(self.specs), self.rows, self.width, _p(dtable), dtable.stride(0), _p(self.saved), _p(scratch),
                                    _p(dbias), _s()), "vdm_cond_table_bwd")
         self.saved = None

@@ -75,6 +75,9 @@ class CUNet(nn.Module):
         self.taps = 3 ** self.dim
 
         self.cond_dims = ([4 * self.chs[0]] if self.t_conditioning else []) + [V_EMB_DIM] * len(self.v_conditioning_dims)
+        if backend == "hip" and max(self.cond_dims + [0] + self.v_conditioning_dims) > 256:
+            raise ValueError(f"CUNet(backend='hip'): the conditioning kernel (K6) holds embeddings of at most 256 values; "
+                             f"chs[0] = {self.chs[0]} gives a time embedding of width {4 * self.chs[0]} (use chs[0] <= 64 or backend='torch')")
         self.blocks = self._block_list()
         self.table_width = sum(b.cout for b in self.blocks)
         self.spec = self._build_spec()

@@ -55,7 +55,8 @@ class SFM(nn.Module):
             xt = ops.diffuse(x1, x0, t.contiguous(), (1.0 - t).contiguous())            # t x1 + (1 - t) x0
             if self.sigma > 0.0:
                 if eps is None:
-                    eps = ops.randn(torch.empty_like(x1), int(torch.randint(0, 2 ** 62, (1,)).item()), 3)
+                    from .vdm_model import VDM, noise_seed
+                    eps = ops.randn(torch.empty_like(x1), noise_seed(), 2 * VDM._rank_world()[0] + 1)     # (per-rank Philox stream)
                 xt = ops.diffuse(xt, eps.contiguous(), one, self.sigma * one)
             u = ops.diffuse(x1, x0, one, -one)                                           # target velocity x1 - x0
             v = self.velocity(xt, t, x0, v_conditionings)

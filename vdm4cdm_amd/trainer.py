@@ -157,12 +157,22 @@ class Trainer:
     def validate(self, model, datamodule):
         model.eval()
         losses, last = [], None
-        for i, batch in enumerate(datamodule.val_dataloader()):
+        world = getattr(self, "world", 1)
+        try:                                                   # the validation split is sharded like the training split
+            loader = datamodule.val_dataloader(self.rank, world)
+        except TypeError:                                      # (a user datamodule with the reference's zero-argument signature)
+            loader = datamodule.val_dataloader()
+        for i, batch in enumerate(loader):
             if i >= self.limit_val_batches:
                 break
-            losses.append(float(model.validation_step(batch, i)))
+            losses.append(model.validation_step(batch, i).detach().float())
             last = batch
-        rec = {"step": self.global_step, "val_loss": sum(losses) / max(len(losses), 1), **dict(model.logged)}
+        dev = losses[0].device if losses else torch.device("cpu")
+        tot = torch.stack([torch.stack(losses).sum() if losses else torch.zeros((), device=dev),
+                           torch.tensor(float(len(losses)), device=dev)])
+        if world > 1:                                          # one collective, entered by EVERY rank (also one whose shard was empty)
+            dist.all_reduce(tot, op=dist.ReduceOp.SUM)
+        rec = {"step": self.global_step, "val_loss": float(tot[0] / tot[1].clamp(min=1.0)), **dict(model.logged)}
         if last is not None and model.draw_figure is not None and self.rank == 0:
             x, kw = model._unpack(last)
             samples = model.draw_samples(batch_size=x.shape[0], n_sampling_steps=self.n_val_sampling_steps, **model._filter(kw))
@@ -172,6 +182,8 @@ class Trainer:
                 fig.savefig(os.path.join(self.root, f"val_step{self.global_step}.png"))
             except Exception as e:                             # figures are diagnostics, never fatal to the fit loop
                 rec["figure_error"] = repr(e)
+        if world > 1:            # rank 0 drew the figure samples (n_val_sampling_steps denoise steps): the others wait HERE, explicitly,
+            dist.barrier()       # not inside the first gradient all-reduce of the next training step
         self._log(rec)
         model.train()
         return rec

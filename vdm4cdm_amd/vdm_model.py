@@ -119,6 +119,14 @@ class VDM(nn.Module):
             return dist.get_rank(), dist.get_world_size()
         return 0, 1
 
+    def _rank_noise_gen(self, device, rank):
+        g = getattr(self, "_noise_gen", None)
+        if g is None or g.device != torch.device(device) or self._noise_gen_key != (torch.initial_seed(), rank):
+            g = torch.Generator(device=device)
+            g.manual_seed((torch.initial_seed() + 0x9E3779B97F4A7C15 * (rank + 1)) & 0x7fffffffffffffff)
+            self._noise_gen, self._noise_gen_key = g, (torch.initial_seed(), rank)
+        return g
+
     def sample_times(self, B, device):
         return stratified_times(B, device, self.antithetic_time_sampling)
 
@@ -145,9 +153,9 @@ class VDM(nn.Module):
                                           "'learned_linear' needs d loss / d z_t which the HIP backward does not emit")
             rank, _ = self._rank_world()                   # (Philox stream id = 2*rank + {1,2}: different noise fields per rank)
             if eps is None:
-                eps = ops.randn(torch.empty_like(x), int(torch.randint(0, 2 ** 62, (1,)).item()), 2 * rank + 1)
+                eps = ops.randn(torch.empty_like(x), noise_seed(), 2 * rank + 1)
             if eps0 is None:
-                eps0 = ops.randn(torch.empty_like(x), int(torch.randint(0, 2 ** 62, (1,)).item()), 2 * rank + 2)
+                eps0 = ops.randn(torch.empty_like(x), noise_seed(), 2 * rank + 2)
             z_t = ops.diffuse(x, eps.contiguous(), self.alpha(g_t).contiguous(), self.sigma(g_t).contiguous())
             eps_hat = self.get_pred_noise(z_t, g_t, **kwargs)
             w = 0.5 * self.dgamma_dt(times) * bpd / B                      # per-sample weight of S_n
@@ -157,11 +165,10 @@ class VDM(nn.Module):
         else:
             red = tuple(range(1, x.dim()))
             rank, world = self._rank_world()
-            if (eps is None or eps0 is None) and world > 1:    # identical host seeds on all ranks: skip to this rank's draws
-                for _ in range(2 * rank):
-                    torch.randn_like(x)
-            eps = torch.randn_like(x) if eps is None else eps
-            eps0 = torch.randn_like(x) if eps0 is None else eps0
+            if eps is None or eps0 is None:                    # torch backend: a per-rank generator (seed ^ rank), never the global one
+                g = self._rank_noise_gen(x.device, rank)
+                eps = torch.randn(x.shape, device=x.device, generator=g) if eps is None else eps
+                eps0 = torch.randn(x.shape, device=x.device, generator=g) if eps0 is None else eps0
             z_t = self.alpha(g_t).view(bc) * x + self.sigma(g_t).view(bc) * eps
             eps_hat = self.get_pred_noise(z_t, g_t, **kwargs)
             diff = (0.5 * self.dgamma_dt(times) * ((eps - eps_hat) ** 2).sum(red)).mean() * bpd
@@ -230,8 +237,8 @@ class VDM(nn.Module):
         else:
             z = z.clone()                                    # the HIP path updates z in place: never the caller's tensor
         z = z.to(device=device, dtype=torch.float32).contiguous()
-        if self._hip(z) and not return_all:
-            return self._sample_hip(z, n_sampling_steps, noises, seed, verbose, use_graph, kwargs)
+        if self._hip(z):                                     # (return_all: the same captured step, z copied out after every replay)
+            return self._sample_hip(z, n_sampling_steps, noises, seed, verbose, use_graph, kwargs, return_all)
         steps = torch.linspace(1.0, 0.0, n_sampling_steps + 1, device=device)
         zs = []
         rng = range(n_sampling_steps)
@@ -255,21 +262,23 @@ class VDM(nn.Module):
                 zs.append(z)
         return torch.stack(zs, dim=0) if return_all else z
 
-    def _sample_hip(self, z, n, noises, seed, verbose, use_graph, kwargs):
+    def _sample_hip(self, z, n, noises, seed, verbose, use_graph, kwargs, return_all=False):
         coef = self.step_table(n).to(device=z.device, dtype=torch.float32).contiguous()
         cfg = self.w_cfg is not None and not self.training
         if cfg:
             assert "v_conditionings" in kwargs, "Need v_conditionings to mask out"
         return hip_graph_sampler(self.score_model, z, coef, noises, seed, verbose, use_graph, kwargs.get("s_conditioning"),
                                  list(kwargs.get("v_conditionings") or []), w_cfg=float(self.w_cfg) if cfg else None,
-                                 mask_fn=self.cfg_mask)
+                                 mask_fn=self.cfg_mask, return_all=return_all)
 
 
-def hip_graph_sampler(net, z, coef, noises, seed, verbose, use_graph, s_cond, v_conditionings, w_cfg=None, mask_fn=None):
+def hip_graph_sampler(net, z, coef, noises, seed, verbose, use_graph, s_cond, v_conditionings, w_cfg=None, mask_fn=None,
+                      return_all=False):
     """The multi-step sampling loop on the HIP backend, shared by the VDM ancestral sampler and the SFM Euler integrator: per step
     [conditioning-table row gather, UNet forward, fused update z <- ratio * (z - cs * net_out) + scale * noise, step counter + 1],
     captured once in a hipGraph and replayed; coef[n][4] = {ratio, cs, scale, network time} is read on the device at the row of the
-    device-side step counter.  z is updated in place and returned."""
+    device-side step counter.  z is updated in place and returned; return_all: the stack [n, B, ...] of z after every step instead
+    (frame vdm_model.py:429-442: ``return_all``), copied out between the replays of the same graph."""
     from . import hip_ops as ops
     from .unet_hip import hip_unet_apply
     dev = z.device
@@ -331,6 +340,7 @@ def hip_graph_sampler(net, z, coef, noises, seed, verbose, use_graph, s_cond, v_
             one_step()
         z.copy_(z_keep)             # capture does not execute, but keep the state explicit
         step.zero_()
+    zs = torch.empty((n,) + tuple(z.shape), dtype=z.dtype, device=dev) if return_all else None
     for i in range(n):
         if noise_buf is not None:
             noise_buf.copy_(noises[i].to(z))
@@ -338,21 +348,53 @@ def hip_graph_sampler(net, z, coef, noises, seed, verbose, use_graph, s_cond, v_
             graph.replay()
         else:
             one_step()
+        if zs is not None:
+            zs[i].copy_(z)
         if verbose and (i % 50 == 0 or i == n - 1):
             print(f"sampling: {i + 1}/{n}", flush=True)
-    return z
+    return zs if return_all else z
+
+
+_TRAIN_GENS = {}
+
+
+def train_generator(device):
+    """The generator of the TRAINING step's own random draws (the stratification offset u0, the Philox seeds of the noise fields) on
+    `device`: seeded once from torch.initial_seed() - identical on every rank after seed_everything(42) - and consumed by nothing
+    else, so validation sampling on rank 0, user code or a rank-dependent number of draws elsewhere can never de-synchronise the
+    ranks' u0 / seed sequence (the global generators are shared with all of those)."""
+    key = str(torch.device(device))
+    g = _TRAIN_GENS.get(key)
+    if g is None:
+        g = torch.Generator(device=device)
+        g.manual_seed(torch.initial_seed() ^ 0x5EED)
+        _TRAIN_GENS[key] = g
+    return g
+
+
+def reset_train_generators():
+    """Forget the training generators: the next training step re-creates them from torch.initial_seed().  Call after
+    torch.manual_seed / seed_everything when a run has to be reproduced inside one process (tests; entry.seed_everything does)."""
+    _TRAIN_GENS.clear()
+
+
+def noise_seed():
+    """A fresh Philox seed for one noise field of the training step (host side; same sequence on every rank - the Philox stream id
+    carries the rank)."""
+    return int(torch.randint(0, 2 ** 62, (1,), generator=train_generator("cpu")).item())
 
 
 def stratified_times(B, device, antithetic=True):
-    """D10 antithetic sampling t_i = (u0 + i/B) mod 1, stratified over the GLOBAL batch under data parallelism: every rank
-    seeds identically (seed_everything(42)), so u0 is the same on all ranks and rank r takes strata r*B .. r*B+B-1 of world*B -
-    the variance of the t-sampling shrinks with the world size instead of every rank drawing the same B times."""
+    """D10 antithetic sampling t_i = (u0 + i/B) mod 1, stratified over the GLOBAL batch under data parallelism: u0 comes from
+    train_generator (same on all ranks) and rank r takes strata r*B .. r*B+B-1 of world*B - the variance of the t-sampling shrinks
+    with the world size instead of every rank drawing the same B times."""
     rank, world = VDM._rank_world()
+    g = train_generator(device)
     if antithetic:
-        u0 = torch.rand(1, device=device)
+        u0 = torch.rand(1, device=device, generator=g)
         i = torch.arange(B, device=device, dtype=torch.float32) + rank * B
         return torch.remainder(u0 + i / (world * B), 1.0)
-    t = torch.rand(world * B, device=device)
+    t = torch.rand(world * B, device=device, generator=g)
     return t[rank * B:(rank + 1) * B]
 
 
