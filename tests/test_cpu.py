@@ -382,3 +382,24 @@ def test_load_state_dict_layouts():
     with torch.no_grad():
         assert torch.equal(a.eval()(x, t=torch.tensor([0.3]), s_conditioning=s, v_conditionings=v),
                            b.eval()(x, t=torch.tensor([0.3]), s_conditioning=s, v_conditionings=v))
+
+
+def test_host_side_under_asan_ubsan():
+    """SURVEY section 5 (sanitizers): the HOST code of the C-ABI - descriptor validation incl. hostile values, pack plans, tile /
+    workspace / scratch planners, kernel-variant selection, the argument-error paths of every launching entry point - runs under
+    AddressSanitizer + UBSan (`make asan`: -Xarch_host -fsanitize=address,undefined; the device code is compiled but never run).
+    CPU container only: GPU sanitizers are not available on the pool and the product never loads this build."""
+    import subprocess
+    import sys
+    if torch.cuda.is_available():
+        pytest.skip("sanitizer build is exercised on the CPU container only")
+    csrc = os.path.join(ROOT, "vdm4cdm_amd", "csrc")
+    subprocess.check_call(["make", "-C", csrc, "asan"], stdout=subprocess.DEVNULL)
+    rt = subprocess.check_output(["/opt/rocm/lib/llvm/bin/clang", "--print-file-name=libclang_rt.asan-x86_64.so"], text=True).strip()
+    assert os.path.exists(rt), "ASan runtime of the ROCm clang not found"
+    env = dict(os.environ, LD_PRELOAD=rt, ASAN_OPTIONS="detect_leaks=0:halt_on_error=1", UBSAN_OPTIONS="halt_on_error=1:print_stacktrace=1")
+    env.pop("VDM4CDM_LIB", None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "_asan_host_driver.py")], env=env, cwd=ROOT, capture_output=True, text=True,
+                       timeout=600)
+    assert r.returncode == 0 and "asan host driver ok" in r.stdout, (r.stdout[-1500:] + r.stderr[-3000:])
+    assert "runtime error" not in r.stderr and "AddressSanitizer" not in r.stderr, r.stderr[-3000:]

@@ -89,7 +89,7 @@ def test_astro_datamodule_batches_on_the_gpu(tmp_path):
                           cropsize=16, data_root=root, seed=2, device=DEV)
     drawn = []
     orig = dm.draw_sample
-    dm.draw_sample = lambda idx, train: drawn.append(orig(idx, train)) or drawn[-1]
+    dm.draw_sample = lambda idx, train, gen=None: drawn.append(orig(idx, train, gen)) or drawn[-1]
     batch = next(iter(dm.train_dataloader()))
     assert batch["x"].shape == (3, 1, 16, 16, 16) and batch["conditioning"].shape == (3, 1, 16, 16, 16) and batch["x"].is_cuda
     assert isinstance(batch["conditioning_values"], list) and batch["conditioning_values"][0].shape == (3, 6)

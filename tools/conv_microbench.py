@@ -59,7 +59,16 @@ def main():
         for op in args.ops.split(","):
             if op == "dgrad" and stride == 2:
                 continue
-            fn = {"fwd": lambda: conv.fwd(x), "dgrad": lambda: conv.dgrad(dout), "wgrad": lambda: conv.wgrad(x, dout, dw)}[op]
+            if op == "dgrad_gn":                            # dgrad with the GroupNorm backward folded into the epilogue (dropout mask on)
+                if not conv.gn_fold_ok(cin, 0, dt) or stride != 1 or ups:
+                    continue
+                G = 8
+                st = ops.gn_stats(x, None, G)
+                gam, bet = torch.ones(cin, device=dev), torch.zeros(cin, device=dev)
+                mask = torch.full((N, D * D * D, cin // ops.epl(dt)), 0xFF, dtype=torch.uint8, device=dev)
+            fn = {"fwd": lambda: conv.fwd(x), "fwd_gn": lambda: conv.fwd(x, gn=True), "dgrad": lambda: conv.dgrad(dout),
+                  "wgrad": lambda: conv.wgrad(x, dout, dw),
+                  "dgrad_gn": lambda: conv.dgrad_gn(dout, x, None, G, st, gam, bet, keep_mask=mask, dropout_p=0.1)}[op]
             for _ in range(3):
                 fn()
             torch.cuda.synchronize()

@@ -295,10 +295,12 @@ __device__ __forceinline__ void taps_rowreuse(f32x4 (&acc)[NV][NC], const char* 
 #pragma unroll
     for (int e = 0; e < 27; ++e) {
         const int g = e / 3, dy = e % 3;
+#ifndef VDM_EXP_NOWLOAD           // experiment (make variant DEFS=-DVDM_EXP_NOWLOAD): no weight loads inside the tap loop (WRONG results; timing only)
         if (e + WPD < 27) {
 #pragma unroll
             for (int c = 0; c < NC; ++c) wf[(e + WPD) % (WPD + 1)][c] = wk[(rr_tap(e + WPD) * NCW + c) * 64];
         }
+#endif
         if (dy < 2 || g == 8) {
 #pragma unroll
             for (int v = 0; v < NV; ++v)
@@ -766,12 +768,14 @@ static int validate(const vdm_conv_desc* d) {
     VDM_REQUIRE(!(d->upsample && ((d->od | d->oh | d->ow) & 1)), "conv: upsample needs even output dims");
     VDM_REQUIRE(d->dtype == VDM_F32 || d->dtype == VDM_BF16, "conv: bad dtype %d", d->dtype);
     VDM_REQUIRE(d->pad_mode == VDM_PAD_ZEROS || d->pad_mode == VDM_PAD_CIRCULAR, "conv: bad pad_mode %d", d->pad_mode);
-    // the kernels index voxels and elements INSIDE one sample with 32-bit arithmetic (24-bit multiplies on the coordinates)
-    const long long fine = (long long)d->od * d->oh * d->ow * (d->stride == 2 ? 8 : 1);
-    const long long cmax = cpad(d->cin > d->cout ? d->cin : d->cout, d->dtype);
-    VDM_REQUIRE(fine * cmax < (1LL << 32), "conv: %lld voxels x %lld channels per sample exceed the 32-bit in-sample index", fine, cmax);
+    // the kernels index voxels and elements INSIDE one sample with 32-bit arithmetic (24-bit multiplies on the coordinates).
+    // Order matters: bound every factor first, so that the products below cannot overflow for hostile descriptors (UBSan finding).
     VDM_REQUIRE((long long)(d->od > d->oh ? (d->od > d->ow ? d->od : d->ow) : (d->oh > d->ow ? d->oh : d->ow)) * d->stride < (1 << 12),
                 "conv: spatial extent too large");
+    VDM_REQUIRE(d->cin <= (1 << 16) && d->cout <= (1 << 16) && d->n <= (1 << 20), "conv: channel count / batch out of range");
+    const long long fine = (long long)d->od * d->oh * d->ow * (d->stride == 2 ? 8 : 1);           // < 2^36
+    const long long cmax = cpad(d->cin > d->cout ? d->cin : d->cout, d->dtype);                   // <= 2^16
+    VDM_REQUIRE(fine * cmax < (1LL << 32), "conv: %lld voxels x %lld channels per sample exceed the 32-bit in-sample index", fine, cmax);
     return VDM_OK;
 }
 
