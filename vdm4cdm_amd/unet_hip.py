@@ -410,12 +410,14 @@ class HipUNet:
                 dh = self.down[i].dgrad(dh, residual=dskips[i])      # per-parity-class conv: no zero-dilated intermediate
             dh, _ = self.res[f"downs.{i}.block"].bwd(P, GP, dh, dtable, ss)
         ss.run(lambda: self.conv_in.wgrad(xin, dh, GP("conv_in.weight"), GP("conv_in.bias")), xin, dh)
-        ss.join()
-        if cond is not None:      # K6 backward: conditioning MLPs + projections + the conv1 biases (column sums of dtable), 2 launches
+        # (the K6 backward only needs dtable - complete since the last block - and writes its own slice of gflat: it runs on the main
+        # stream WHILE the side stream finishes the conv_in weight gradient, instead of behind the join)
+        if cond is not None:      # K6 backward: conditioning MLPs + projections + the conv1 biases (column sums of dtable), 3 launches
             grads = [{k: sp[k] for k in ("w1", "b1", "w2", "b2", "wproj")} for sp in net.cond_specs(None, [None] * len(net.v_conditioning_dims), gflat)]
             cond.backward(dtable, grads, dbias=net.conv1_bias_all(gflat))
         else:                     # conv1 biases: column sums of the conditioning-table gradient (same additive broadcast)
             net.conv1_bias_all(gflat).copy_(dtable.sum(0))
+        ss.join()
         self._bucket_ready(gflat, "end", ss)
         if self.buckets is not None:
             done = self.buckets.finish()
