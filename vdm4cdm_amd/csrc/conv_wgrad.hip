@@ -1,6 +1,10 @@
 // conv_wgrad.hip - weight-gradient kernels and their slab reduce kernels (see conv_common.h).
 #include "conv_common.h"
 
+#ifndef VDM_WGRAD_LA
+#define VDM_WGRAD_LA 1          // taps of operand lookahead in the weight-gradient tap loop (experiment: 2)
+#endif
+
 namespace vdm {
 
 // ---------------------------------------------------------------------------------------------
@@ -207,6 +211,53 @@ __global__ void __launch_bounds__(256, 2) conv_wgrad_kernel(const WgradArgs w) {
 
     // one tile: (stage ->) barrier -> k-steps over the rows.  in_off(t, r): wave-uniform LDS byte offset of halo row r shifted by tap slot t.
     auto tile_compute = [&](auto&& in_off) {
+      if constexpr (VDM_WGRAD_LA == 2 && TPW == 7) {
+        // Software pipeline, TWO taps ahead: the transposed fragments of tap t+2 are issued before the MFMAs of tap t (ring of three
+        // fragment sets; TPW = 7 = 1 mod 3, so the ring is rotated by one set at the end of a k-step), the dOut fragments of the next
+        // k-step one tap before its end.
+        static_assert(TPW == 1 || TPW == 2 || TPW == 7, "ring rotation written for 7 (or fewer than 3) taps per wave");
+        uint4 af[NTA], afn[NTA], bf[3][NTB];
+#pragma unroll
+        for (int i = 0; i < NTA; ++i) af[i] = afn[i] = TF::template get<HI_DO>(lds_do, lo_do[i], row0 * 1024);
+#pragma unroll
+        for (int j = 0; j < NTB; ++j) bf[0][j] = TF::template get<HI_IN>(lds_in, lo_in[0][j], in_off(0, row0));
+        if (TPW > 1) {
+#pragma unroll
+            for (int j = 0; j < NTB; ++j) bf[1][j] = TF::template get<HI_IN>(lds_in, lo_in[TPW > 1 ? 1 : 0][j], in_off(TPW > 1 ? 1 : 0, row0));
+        }
+        for (int r = row0; r < G::ROWS; r += rowinc) {
+            const int rn = (r + rowinc < G::ROWS) ? r + rowinc : r;      // clamp: the last prefetches are harmless
+#pragma unroll
+            for (int t = 0; t < TPW; ++t) {
+                const int t2 = t + 2;                                    // the tap whose fragments are issued now
+                const int tt = t2 < TPW ? t2 : t2 - TPW, rr = t2 < TPW ? r : rn;
+                if (TPW >= 3 || t2 >= TPW) {
+#pragma unroll
+                    for (int j = 0; j < NTB; ++j) bf[t2 % 3][j] = TF::template get<HI_IN>(lds_in, lo_in[tt < TPW ? tt : 0][j], in_off(tt < TPW ? tt : 0, rr));
+                }
+                if (t == (TPW >= 2 ? TPW - 2 : 0)) {
+#pragma unroll
+                    for (int i = 0; i < NTA; ++i) afn[i] = TF::template get<HI_DO>(lds_do, lo_do[i], rn * 1024);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int i = 0; i < NTA; ++i)
+#pragma unroll
+                    for (int j = 0; j < NTB; ++j) mma16<T>(acc[t][i][j], af[i], bf[t % 3][j]);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+#pragma unroll
+            for (int i = 0; i < NTA; ++i) af[i] = afn[i];
+            // rotate: the next k-step's tap 0 / 1 sit in sets TPW % 3 and (TPW + 1) % 3
+            if (TPW % 3 == 1) {
+#pragma unroll
+                for (int j = 0; j < NTB; ++j) { bf[0][j] = bf[1][j]; bf[1][j] = bf[2][j]; }
+            } else if (TPW % 3 == 2) {
+#pragma unroll
+                for (int j = 0; j < NTB; ++j) { const uint4 t0 = bf[0][j]; bf[0][j] = bf[2][j]; bf[1][j] = t0; }
+            }
+        }
+      } else {
         // Software pipeline: while the MFMAs of tap t run, the transposed fragments of tap t+1 (or of the next
         // row's tap 0 and its dOut fragments) are already in flight; sched_barrier(0) pins that order.
         uint4 af[NTA], afn[NTA], bfA[NTB], bfB[NTB];
@@ -243,6 +294,7 @@ __global__ void __launch_bounds__(256, 2) conv_wgrad_kernel(const WgradArgs w) {
                 for (int j = 0; j < NTB; ++j) bfA[j] = bfB[j];
             }
         }
+      }
         // bias gradient: column sums of this dOut tile (already in LDS), by the workgroups with cin block 0; every wave
         // takes a quarter of the rows.  Lane l sums the 16-B slot (l & 3) of voxels x = l >> 2: with the x-swizzle that
         // is always the same channel piece, so the sums stay in EPL registers until the kernel ends.
