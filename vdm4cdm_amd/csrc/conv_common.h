@@ -295,12 +295,10 @@ __device__ __forceinline__ void taps_rowreuse(f32x4 (&acc)[NV][NC], const char* 
 #pragma unroll
     for (int e = 0; e < 27; ++e) {
         const int g = e / 3, dy = e % 3;
-#ifndef VDM_EXP_NOWLOAD           // experiment (make variant DEFS=-DVDM_EXP_NOWLOAD): no weight loads inside the tap loop (WRONG results; timing only)
         if (e + WPD < 27) {
 #pragma unroll
             for (int c = 0; c < NC; ++c) wf[(e + WPD) % (WPD + 1)][c] = wk[(rr_tap(e + WPD) * NCW + c) * 64];
         }
-#endif
         if (dy < 2 || g == 8) {
 #pragma unroll
             for (int v = 0; v < NV; ++v)
@@ -741,8 +739,6 @@ struct WgradArgs {
     int P;               // persistent workgroups per (cout block, cin block) pair
     int ntiles;          // N * ntz * nty * ntx
     int ncb, nkb;        // cout blocks, cin blocks (64 B each)
-    int rsegs, rseglen;  // rolling z window (conv_wgrad_kernel<..., ROLL>): segments per (n, ty, tx) column, z tiles per segment;
-                         // ntiles then counts RUNS (columns x segments)
 };
 
 template <typename T> struct WG;     // 16x16 tiles per 64-byte channel block
@@ -871,22 +867,6 @@ static bool ksplit_tile(const ConvArgs& a, int& tz, int& ty) {
 static int s2_tile_z() {
     static const int v = getenv("VDM4CDM_S2_TZ") ? atoi(getenv("VDM4CDM_S2_TZ")) : 2;
     return v == 1 ? 1 : 2;
-}
-
-// stride-1 3x3x3 weight gradient (conv_wgrad.hip): VDM4CDM_WGRAD_GEN=2 (default) the double-buffered 8-wave kernel, one workgroup per CU
-// (conv_wgrad2_kernel); =1 the first-generation kernel (two independent workgroups per CU), with VDM4CDM_WGRAD_ROLL=1 its rolling-z-window
-// variant (fewer staged bytes, same duration: kept for the A/B record)
-static int wgrad_gen() {
-    static const int v = getenv("VDM4CDM_WGRAD_GEN") ? atoi(getenv("VDM4CDM_WGRAD_GEN")) : 2;
-    return v == 1 ? 1 : 2;
-}
-static bool wgrad_roll() {
-    static const int v = getenv("VDM4CDM_WGRAD_ROLL") ? atoi(getenv("VDM4CDM_WGRAD_ROLL")) : 0;
-    return v != 0;
-}
-static int wgrad2_wgs() {
-    static const int v = getenv("VDM4CDM_WGRAD2_WGS") ? atoi(getenv("VDM4CDM_WGRAD2_WGS")) : 256;
-    return v > 0 ? v : 256;
 }
 
 // persistent workgroups of a weight-gradient launch over all (cout, cin) block pairs (~2 per CU); VDM4CDM_WGRAD_WGS: experiments

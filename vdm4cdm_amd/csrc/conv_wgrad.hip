@@ -1,10 +1,6 @@
 // conv_wgrad.hip - weight-gradient kernels and their slab reduce kernels (see conv_common.h).
 #include "conv_common.h"
 
-#ifndef VDM_WGRAD_LA
-#define VDM_WGRAD_LA 1          // taps of operand lookahead in the weight-gradient tap loop (experiment: 2)
-#endif
-
 namespace vdm {
 
 // ---------------------------------------------------------------------------------------------
@@ -54,49 +50,6 @@ __device__ __forceinline__ void stage_dout_dma_sub(char* lds, const T* __restric
     }
 }
 
-// Rolling z window of the stride-1 3x3x3 weight gradient (ROLL): a persistent workgroup walks a run of z-consecutive tiles of one
-// (y, x) column, so consecutive tiles share HZ - TZ = 2 of their 4 halo slices.  The input image is a ring of 4 slice slots
-// (a slice = HY x HX halo voxels, padded to whole 1-KiB DMA chunks); logical slice s of the k-th tile of a run lives in slot
-// (s + 2 k) & 3, so after the first tile only the 2 NEW slices are staged (into the slots of the 2 oldest): 23 KB instead of 46 KB of
-// LDS-DMA per 256-voxel tile - the kernel is bound by that staging (1.8 us of MFMA work against 62 KB of DMA per tile and workgroup).
-template <typename G> struct Roll {
-    static constexpr int SVOX = G::HY * G::HX;                       // voxels of one z slice of the halo
-    static constexpr int SCHUNK = (SVOX + 15) / 16;                  // 1-KiB chunks per slice slot
-    static constexpr int SBYTES = SCHUNK * 1024;
-    static constexpr int IMG = G::HZ * SBYTES;
-};
-
-template <typename T, typename G>
-__device__ __forceinline__ void stage_slices_dma(char* lds, const T* __restrict__ x, const ConvArgs& a, int n, int oz0, int oy0, int ox0,
-                                                 int kb, int wave, int lane, int s_lo, int s_hi, int phase) {
-    constexpr int EPL = DT<T>::EPL, KB = DT<T>::KB;
-    using R = Roll<G>;
-    static_assert(G::HZ == 4, "ring of 4 slots");
-    const int k = lane >> 2, j = lane & 3;
-    const T* xn = x + (size_t)n * ((size_t)a.Sz * a.Sy * a.Sx * a.CinStride);
-    const int nq = (s_hi - s_lo) * R::SCHUNK;
-    for (int q = wave; q < nq; q += 4) {
-        const int s = s_lo + q / R::SCHUNK, c = q % R::SCHUNK;
-        const int i = c * 16 + k;                                   // voxel inside the slice
-        const int hy = i / G::HX, hx = i - hy * G::HX;
-        const int pc = j ^ ((hx >> 1) & 3);
-        const int ci = kb * KB + pc * EPL;
-        int iz = oz0 - G::PAD + s, iy = oy0 - G::PAD + hy, ix = ox0 - G::PAD + hx;
-        bool ok = ci < a.Cin && i < R::SVOX;
-        if (a.circular) {
-            iz = wrap(iz, a.Iz); iy = wrap(iy, a.Iy); ix = wrap(ix, a.Ix);
-        } else {
-            ok = ok && (unsigned)iz < (unsigned)a.Iz && (unsigned)iy < (unsigned)a.Iy && (unsigned)ix < (unsigned)a.Ix;
-        }
-        const unsigned row = __umul24((unsigned)iz & 0xffffffu, (unsigned)a.Sy) + ((unsigned)iy & 0xffffffu);
-        const unsigned vox = __umul24(row, (unsigned)a.Sx) + ((unsigned)ix & 0xffffffu);
-        const unsigned eoff = vox * (unsigned)a.CinStride + (unsigned)ci;
-        const void* src = ok ? static_cast<const void*>(xn + eoff) : static_cast<const void*>(g_zero_page);
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-                                         (__attribute__((address_space(3))) void*)(lds + ((s + phase) & 3) * R::SBYTES + c * 1024), 16, 0, 0);
-    }
-}
-
 template <typename T> struct TrFetch;
 template <> struct TrFetch<bf16_t> {
     static constexpr int NOFF = 1;
@@ -141,7 +94,7 @@ template <> struct TrFetch<float> {
 
 // NTA / NTB: 16-channel tiles of the 64-byte cout / cin block that hold real channels (conv_out has 1 output channel, conv_in 2
 // input channels: half of the MFMAs and transposed reads of the block would multiply padding).
-template <typename T, int KS, int STRIDE, int UPS, int TZ, int TY, int NTA = WG<T>::NT, int NTB = WG<T>::NT, bool ROLL = false>
+template <typename T, int KS, int STRIDE, int UPS, int TZ, int TY, int NTA = WG<T>::NT, int NTB = WG<T>::NT>
 __global__ void __launch_bounds__(256, 2) conv_wgrad_kernel(const WgradArgs w) {
     using G = Geo<KS, STRIDE, TZ, TY>;
     using TF = TrFetch<T>;
@@ -153,8 +106,7 @@ __global__ void __launch_bounds__(256, 2) conv_wgrad_kernel(const WgradArgs w) {
     constexpr int TAPS = CLS ? 8 : G::TAPS;
     constexpr int TPW = (TAPS + 3) / 4;                    // taps per wave (KS=3: 7; class mode: 2; KS=1: 1)
     constexpr int RSTEP = (sizeof(T) == 2) ? 2 : 1;        // rows consumed per k-step
-    static_assert(!ROLL || (KS == 3 && STRIDE == 1 && UPS == 0 && TZ == 2), "rolling z window: stride-1 3x3x3, tiles of 2 z slices");
-    constexpr int IN_BYTES = ROLL ? Roll<G>::IMG : ((G::HVOX + 15) / 16) * 1024;
+    constexpr int IN_BYTES = ((G::HVOX + 15) / 16) * 1024;
     static_assert(sizeof(T) == 4 || (TY % 2) == 0, "bf16 k-step = two rows of the same z-slab");
     constexpr int HI_IN = STRIDE * G::HX * 64;             // byte delta to the second row of a bf16 k-step
     constexpr int HI_DO = 16 * 64;
@@ -183,7 +135,6 @@ __global__ void __launch_bounds__(256, 2) conv_wgrad_kernel(const WgradArgs w) {
 
     // KS=3: wave owns taps wave, wave+4, ... over all rows.  KS=1: all waves own tap 0, rows split.
     int tap_u[TPW];                       // wave-uniform byte offset of the tap's (dz, dy) shift
-    int tap_dz[TPW], tap_yo[TPW];         // (ROLL: the z shift selects a ring slot per tile; the dy shift stays a byte offset)
     int lo_in[TPW][NTB][NOFF];             // per-lane offsets (depend on the tap's dx through the x-swizzle)
     int lo_do[NTA][NOFF];
 #pragma unroll
@@ -193,7 +144,6 @@ __global__ void __launch_bounds__(256, 2) conv_wgrad_kernel(const WgradArgs w) {
         const int dz = CLS ? ((tap >> 2) & 1) + pz : tap / (KS * KS), dy = CLS ? ((tap >> 1) & 1) + py : (tap / KS) % KS,
                   dx = CLS ? (tap & 1) + px : tap % KS;
         tap_u[t] = (dz * G::HY + dy) * G::HX * 64;
-        tap_dz[t] = dz; tap_yo[t] = dy * G::HX * 64;
 #pragma unroll
         for (int j = 0; j < NTB; ++j) TF::lane_off(lo_in[t][j], j, STRIDE, dx, lane);
     }
@@ -209,76 +159,42 @@ __global__ void __launch_bounds__(256, 2) conv_wgrad_kernel(const WgradArgs w) {
     for (int j = 0; j < DT<T>::EPL; ++j) bsum[j] = 0.f;
     auto in_base = [&](int r) { return (((r / TY) * STRIDE * G::HY + (r % TY) * STRIDE) * G::HX) * 64; };
 
-    // one tile: (stage ->) barrier -> k-steps over the rows.  in_off(t, r): wave-uniform LDS byte offset of halo row r shifted by tap slot t.
-    auto tile_compute = [&](auto&& in_off) {
-      if constexpr (VDM_WGRAD_LA == 2 && TPW == 7) {
-        // Software pipeline, TWO taps ahead: the transposed fragments of tap t+2 are issued before the MFMAs of tap t (ring of three
-        // fragment sets; TPW = 7 = 1 mod 3, so the ring is rotated by one set at the end of a k-step), the dOut fragments of the next
-        // k-step one tap before its end.
-        static_assert(TPW == 1 || TPW == 2 || TPW == 7, "ring rotation written for 7 (or fewer than 3) taps per wave");
-        uint4 af[NTA], afn[NTA], bf[3][NTB];
-#pragma unroll
-        for (int i = 0; i < NTA; ++i) af[i] = afn[i] = TF::template get<HI_DO>(lds_do, lo_do[i], row0 * 1024);
-#pragma unroll
-        for (int j = 0; j < NTB; ++j) bf[0][j] = TF::template get<HI_IN>(lds_in, lo_in[0][j], in_off(0, row0));
-        if (TPW > 1) {
-#pragma unroll
-            for (int j = 0; j < NTB; ++j) bf[1][j] = TF::template get<HI_IN>(lds_in, lo_in[TPW > 1 ? 1 : 0][j], in_off(TPW > 1 ? 1 : 0, row0));
-        }
-        for (int r = row0; r < G::ROWS; r += rowinc) {
-            const int rn = (r + rowinc < G::ROWS) ? r + rowinc : r;      // clamp: the last prefetches are harmless
-#pragma unroll
-            for (int t = 0; t < TPW; ++t) {
-                const int t2 = t + 2;                                    // the tap whose fragments are issued now
-                const int tt = t2 < TPW ? t2 : t2 - TPW, rr = t2 < TPW ? r : rn;
-                if (TPW >= 3 || t2 >= TPW) {
-#pragma unroll
-                    for (int j = 0; j < NTB; ++j) bf[t2 % 3][j] = TF::template get<HI_IN>(lds_in, lo_in[tt < TPW ? tt : 0][j], in_off(tt < TPW ? tt : 0, rr));
-                }
-                if (t == (TPW >= 2 ? TPW - 2 : 0)) {
-#pragma unroll
-                    for (int i = 0; i < NTA; ++i) afn[i] = TF::template get<HI_DO>(lds_do, lo_do[i], rn * 1024);
-                }
-                __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                for (int i = 0; i < NTA; ++i)
-#pragma unroll
-                    for (int j = 0; j < NTB; ++j) mma16<T>(acc[t][i][j], af[i], bf[t % 3][j]);
-                __builtin_amdgcn_sched_barrier(0);
-            }
-#pragma unroll
-            for (int i = 0; i < NTA; ++i) af[i] = afn[i];
-            // rotate: the next k-step's tap 0 / 1 sit in sets TPW % 3 and (TPW + 1) % 3
-            if (TPW % 3 == 1) {
-#pragma unroll
-                for (int j = 0; j < NTB; ++j) { bf[0][j] = bf[1][j]; bf[1][j] = bf[2][j]; }
-            } else if (TPW % 3 == 2) {
-#pragma unroll
-                for (int j = 0; j < NTB; ++j) { const uint4 t0 = bf[0][j]; bf[0][j] = bf[2][j]; bf[1][j] = t0; }
-            }
-        }
-      } else {
+    for (int tile = pidx; tile < w.ntiles; tile += w.P) {
+        int b = tile;
+        const int tx = b % a.ntx; b /= a.ntx;
+        const int ty = b % a.nty; b /= a.nty;
+        const int tz = b % a.ntz; b /= a.ntz;
+        const int n = b;
+        const int oz0 = tz * TZ, oy0 = ty * TY, ox0 = tx * 16;
+        __syncthreads();                                   // every wave is done reading the previous tile
+        stage_halo_dma<T, G, CLS ? 0 : UPS>(lds_in, x, a, n, oz0, oy0, ox0, kb, wave, lane);
+        if constexpr (CLS)
+            stage_dout_dma_sub<T, G>(lds_do, g, a, n, oz0, oy0, ox0, cb, w.dout_stride, pz, py, px, wave, lane);
+        else
+            stage_dout_dma<T, G>(lds_do, g, a, n, oz0, oy0, ox0, cb, w.dout_stride, wave, lane);
+        __syncthreads();                                   // (drains the LDS-DMA: vmcnt(0) + barrier)
         // Software pipeline: while the MFMAs of tap t run, the transposed fragments of tap t+1 (or of the next
         // row's tap 0 and its dOut fragments) are already in flight; sched_barrier(0) pins that order.
         uint4 af[NTA], afn[NTA], bfA[NTB], bfB[NTB];
 #pragma unroll
         for (int i = 0; i < NTA; ++i) af[i] = TF::template get<HI_DO>(lds_do, lo_do[i], row0 * 1024);
 #pragma unroll
-        for (int j = 0; j < NTB; ++j) bfA[j] = TF::template get<HI_IN>(lds_in, lo_in[0][j], in_off(0, row0));
+        for (int j = 0; j < NTB; ++j) bfA[j] = TF::template get<HI_IN>(lds_in, lo_in[0][j], in_base(row0) + tap_u[0]);
         for (int r = row0; r < G::ROWS; r += rowinc) {
             const int rn = (r + rowinc < G::ROWS) ? r + rowinc : r;      // clamp: the last prefetch is harmless
+            const int i0 = in_base(r), in0 = in_base(rn);
 #pragma unroll
             for (int t = 0; t < TPW; ++t) {
                 uint4 (&cur)[NTB] = (t & 1) ? bfB : bfA;
                 uint4 (&nxt)[NTB] = (t & 1) ? bfA : bfB;
                 if (t + 1 < TPW) {
 #pragma unroll
-                    for (int j = 0; j < NTB; ++j) nxt[j] = TF::template get<HI_IN>(lds_in, lo_in[t + 1 < TPW ? t + 1 : 0][j], in_off(t + 1 < TPW ? t + 1 : 0, r));
+                    for (int j = 0; j < NTB; ++j) nxt[j] = TF::template get<HI_IN>(lds_in, lo_in[t + 1 < TPW ? t + 1 : 0][j], i0 + tap_u[t + 1 < TPW ? t + 1 : 0]);
                 } else {
 #pragma unroll
                     for (int i = 0; i < NTA; ++i) afn[i] = TF::template get<HI_DO>(lds_do, lo_do[i], rn * 1024);
 #pragma unroll
-                    for (int j = 0; j < NTB; ++j) nxt[j] = TF::template get<HI_IN>(lds_in, lo_in[0][j], in_off(0, rn));
+                    for (int j = 0; j < NTB; ++j) nxt[j] = TF::template get<HI_IN>(lds_in, lo_in[0][j], in0 + tap_u[0]);
                 }
                 __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -294,7 +210,6 @@ __global__ void __launch_bounds__(256, 2) conv_wgrad_kernel(const WgradArgs w) {
                 for (int j = 0; j < NTB; ++j) bfA[j] = bfB[j];
             }
         }
-      }
         // bias gradient: column sums of this dOut tile (already in LDS), by the workgroups with cin block 0; every wave
         // takes a quarter of the rows.  Lane l sums the 16-B slot (l & 3) of voxels x = l >> 2: with the x-swizzle that
         // is always the same channel piece, so the sums stay in EPL registers until the kernel ends.
@@ -307,46 +222,6 @@ __global__ void __launch_bounds__(256, 2) conv_wgrad_kernel(const WgradArgs w) {
 #pragma unroll
                 for (int j = 0; j < DT<T>::EPL; ++j) bsum[j] += pz.f[j];
             }
-        }
-    };
-
-    if constexpr (ROLL) {
-        // runs of z-consecutive tiles: run = (column (n, ty, tx), segment of the column); w.ntiles = number of runs here
-        for (int run = pidx; run < w.ntiles; run += w.P) {
-            const int col = run / w.rsegs, seg = run - col * w.rsegs;
-            const int tx = col % a.ntx, ty = (col / a.ntx) % a.nty, n = col / (a.ntx * a.nty);
-            const int tz0 = seg * w.rseglen, tz1 = min(a.ntz, tz0 + w.rseglen);
-            const int oy0 = ty * TY, ox0 = tx * 16;
-            for (int tz = tz0; tz < tz1; ++tz) {
-                const int phase = (2 * (tz - tz0)) & 3, oz0 = tz * TZ;
-                __syncthreads();                               // every wave is done reading the previous tile
-                stage_slices_dma<T, G>(lds_in, x, a, n, oz0, oy0, ox0, kb, wave, lane, tz == tz0 ? 0 : 2, 4, phase);
-                stage_dout_dma<T, G>(lds_do, g, a, n, oz0, oy0, ox0, cb, w.dout_stride, wave, lane);
-                __syncthreads();                               // (drains the LDS-DMA: vmcnt(0) + barrier)
-                int zo[TPW][2];                                // ring slot of (row z-slab rz) + (tap dz), plus the tap's dy shift
-#pragma unroll
-                for (int t = 0; t < TPW; ++t)
-#pragma unroll
-                    for (int rz = 0; rz < 2; ++rz) zo[t][rz] = ((rz + tap_dz[t] + phase) & 3) * Roll<G>::SBYTES + tap_yo[t];
-                tile_compute([&](int t, int r) { return zo[t][r >= TY ? 1 : 0] + (r >= TY ? r - TY : r) * (G::HX * 64); });
-            }
-        }
-    } else {
-        for (int tile = pidx; tile < w.ntiles; tile += w.P) {
-            int b = tile;
-            const int tx = b % a.ntx; b /= a.ntx;
-            const int ty = b % a.nty; b /= a.nty;
-            const int tz = b % a.ntz; b /= a.ntz;
-            const int n = b;
-            const int oz0 = tz * TZ, oy0 = ty * TY, ox0 = tx * 16;
-            __syncthreads();                                   // every wave is done reading the previous tile
-            stage_halo_dma<T, G, CLS ? 0 : UPS>(lds_in, x, a, n, oz0, oy0, ox0, kb, wave, lane);
-            if constexpr (CLS)
-                stage_dout_dma_sub<T, G>(lds_do, g, a, n, oz0, oy0, ox0, cb, w.dout_stride, pz, py, px, wave, lane);
-            else
-                stage_dout_dma<T, G>(lds_do, g, a, n, oz0, oy0, ox0, cb, w.dout_stride, wave, lane);
-            __syncthreads();                                   // (drains the LDS-DMA: vmcnt(0) + barrier)
-            tile_compute([&](int t, int r) { return in_base(r) + tap_u[t]; });
         }
     }
 
@@ -385,247 +260,6 @@ __global__ void __launch_bounds__(256, 2) conv_wgrad_kernel(const WgradArgs w) {
 #pragma unroll
                 for (int rg = 0; rg < 4; ++rg)
                     slab[(tap * CL + i * 16 + gq * 4 + rg) * CL + j * 16 + col] = (i < NTA && j < NTB) ? acc[t][i < NTA ? i : 0][j < NTB ? j : 0][rg] : 0.f;
-    }
-}
-
-// ---------------------------------------------------------------------------------------------
-// Weight gradient of the stride-1 3x3x3 convs, second generation (conv_wgrad2_kernel): ONE persistent workgroup of 8 waves per CU
-// that overlaps the staging of tile k+1 with the MFMAs of tile k.
-//
-// Why: the tap loop of a weight gradient reads only LDS (no weights stream through the vector memory path), so a wave's in-order
-// vmcnt - which keeps the forward kernel from prefetching its next halo behind the weight loads - is no obstacle here; and the
-// first-generation kernel (two independent 62-KB workgroups per CU, stage -> barrier -> 16 k-steps -> barrier per tile) spent as
-// long waiting for its LDS-DMA to land as in the MFMAs: halving the staged bytes (rolling z window, ROLL above) did not change its
-// duration, i.e. it was bound by the exposed DMA LATENCY per tile, not by bytes.
-//   * ring of 6 z-slice slots (72 KB): tile k of a run reads its 4 halo slices from slots (2k + s) mod 6, the 2 new slices of tile
-//     k+1 land in the 2 slots tile k-1 has released; dOut tiles double-buffered (2 x 16 KB).  One barrier per tile.
-//   * 8 waves = 4 tap groups (7/7/7/6 taps, as before) x 2 row groups (alternate k-steps); the two row groups are summed through LDS
-//     once, at the end, in a fixed order (deterministic) -> one partial slab per workgroup, half the slab traffic of generation 1.
-//   * LDS budget of the tap loop: 585 B of operand reads per MFMA (dOut fragments shared by a wave's 7 taps) = 4.6 clocks of the
-//     128 B/clk LDS pipe per MFMA against 4 clocks of MFMA issue per CU: the kernel now runs against the LDS pipe.
-// ---------------------------------------------------------------------------------------------
-template <typename T, int NTA = WG<T>::NT, int NTB = WG<T>::NT>
-__global__ void __launch_bounds__(512, 1) conv_wgrad2_kernel(const WgradArgs w) {
-    constexpr int TZ = 2, TY = 8;
-    using G = Geo<3, 1, TZ, TY>;
-    using TF = TrFetch<T>;
-    using R = Roll<G>;
-    constexpr int NT = WG<T>::NT, NOFF = TF::NOFF;
-    constexpr int TAPS = 27, TPW = 7, NSLOT = 6;
-    constexpr int RSTEP = (sizeof(T) == 2) ? 2 : 1;        // rows consumed per k-step
-    constexpr int RING = NSLOT * R::SBYTES, DO_BYTES = G::OVOX * 64;
-    constexpr int HI_IN = G::HX * 64, HI_DO = 16 * 64;
-    extern __shared__ __attribute__((aligned(16))) char lds[];
-    char* lds_in = lds;
-    const ConvArgs& a = w.c;
-
-    const int tid = threadIdx.x;
-    const int lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int tg = wave & 3, rg = wave >> 2;               // tap group, row group
-    const int pair = blockIdx.x / w.P, pidx = blockIdx.x % w.P;
-    const int cb = pair / w.nkb, kb = pair % w.nkb;        // cout block, cin block
-
-    f32x4 acc[TPW][NTA][NTB];
-#pragma unroll
-    for (int t = 0; t < TPW; ++t)
-#pragma unroll
-        for (int i = 0; i < NTA; ++i)
-#pragma unroll
-            for (int j = 0; j < NTB; ++j) acc[t][i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-    int tap_dz[TPW], tap_yo[TPW];
-    int lo_in[TPW][NTB][NOFF], lo_do[NTA][NOFF];
-#pragma unroll
-    for (int t = 0; t < TPW; ++t) {
-        int tap = tg + 4 * t;
-        if (tap >= TAPS) tap = TAPS - 1;                   // dummy (result discarded)
-        const int dz = tap / 9, dy = (tap / 3) % 3, dx = tap % 3;
-        tap_dz[t] = dz; tap_yo[t] = dy * G::HX * 64;
-#pragma unroll
-        for (int j = 0; j < NTB; ++j) TF::lane_off(lo_in[t][j], j, 1, dx, lane);
-    }
-#pragma unroll
-    for (int i = 0; i < NTA; ++i) TF::lane_off(lo_do[i], i, 1, 0, lane);
-    const T* x = reinterpret_cast<const T*>(a.x);
-    const T* g = reinterpret_cast<const T*>(w.dout);
-    float bsum[DT<T>::EPL];
-#pragma unroll
-    for (int j = 0; j < DT<T>::EPL; ++j) bsum[j] = 0.f;
-    const bool do_bias = w.bslabs != nullptr && kb == 0;   // workgroup-uniform
-
-    // staging of one tile: z slices [s_lo, 4) of the halo into their ring slots + the dOut tile into buffer `buf`; the (slice, chunk)
-    // and dOut-row items are dealt round-robin over the 8 waves
-    auto stage = [&](int n, int oz0, int oy0, int ox0, int s_lo, int phase, int buf) {
-        constexpr int EPL = DT<T>::EPL, KB = DT<T>::KB;
-        const int k = lane >> 2, j = lane & 3;
-        const T* xn = x + (size_t)n * ((size_t)a.Sz * a.Sy * a.Sx * a.CinStride);
-        const int nq = (4 - s_lo) * R::SCHUNK;
-        for (int q = wave; q < nq; q += 8) {
-            const int sl = s_lo + q / R::SCHUNK, c = q % R::SCHUNK;
-            const int i = c * 16 + k;
-            const int hy = i / G::HX, hx = i - hy * G::HX;
-            const int pc = j ^ ((hx >> 1) & 3);
-            const int ci = kb * KB + pc * EPL;
-            int iz = oz0 - 1 + sl, iy = oy0 - 1 + hy, ix = ox0 - 1 + hx;
-            bool ok = ci < a.Cin && i < R::SVOX;
-            if (a.circular) {
-                iz = wrap(iz, a.Iz); iy = wrap(iy, a.Iy); ix = wrap(ix, a.Ix);
-            } else {
-                ok = ok && (unsigned)iz < (unsigned)a.Iz && (unsigned)iy < (unsigned)a.Iy && (unsigned)ix < (unsigned)a.Ix;
-            }
-            const unsigned row = __umul24((unsigned)iz & 0xffffffu, (unsigned)a.Sy) + ((unsigned)iy & 0xffffffu);
-            const unsigned vox = __umul24(row, (unsigned)a.Sx) + ((unsigned)ix & 0xffffffu);
-            const void* src = ok ? static_cast<const void*>(xn + (vox * (unsigned)a.CinStride + (unsigned)ci)) : static_cast<const void*>(g_zero_page);
-            int slot = sl + phase;
-            slot -= slot >= NSLOT ? NSLOT : 0;
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-                                             (__attribute__((address_space(3))) void*)(lds_in + slot * R::SBYTES + c * 1024), 16, 0, 0);
-        }
-        char* ldo = lds + RING + buf * DO_BYTES;
-        const int pcd = j ^ ((k >> 1) & 3);
-        const int co = cb * KB + pcd * EPL;
-        for (int r = wave; r < G::ROWS; r += 8) {
-            const int oz = oz0 + r / TY, oy = oy0 + r % TY, ox = ox0 + k;
-            const bool ok = co < a.Cout && oz < a.Dz && oy < a.Dy && ox < a.Dx;
-            const size_t off = ((((size_t)n * a.Dz + oz) * a.Dy + oy) * a.Dx + ox) * w.dout_stride + co;
-            const void* src = ok ? static_cast<const void*>(g + off) : static_cast<const void*>(g_zero_page);
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-                                             (__attribute__((address_space(3))) void*)(ldo + r * 1024), 16, 0, 0);
-        }
-    };
-
-    const int row0 = rg * RSTEP, rowinc = 2 * RSTEP;
-    for (int run = pidx; run < w.ntiles; run += w.P) {     // (w.ntiles counts runs: columns x segments)
-        const int col = run / w.rsegs, seg = run - col * w.rsegs;
-        const int tx = col % a.ntx, ty = (col / a.ntx) % a.nty, n = col / (a.ntx * a.nty);
-        const int tz0 = seg * w.rseglen, tz1 = min(a.ntz, tz0 + w.rseglen);
-        const int oy0 = ty * TY, ox0 = tx * 16;
-        __syncthreads();                                   // the previous run's last tile has been consumed by every wave
-        stage(n, tz0 * TZ, oy0, ox0, 0, 0, 0);             // first tile of the run: all four slices (not overlapped)
-        int phase = 0;
-        for (int tz = tz0; tz < tz1; ++tz) {
-            const int buf = (tz - tz0) & 1;
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __syncthreads();                               // tile tz has landed; tile tz-1 is fully consumed -> its slots / buffer are free
-            int nphase = phase + 2;
-            nphase -= nphase >= NSLOT ? NSLOT : 0;
-            if (tz + 1 < tz1) stage(n, (tz + 1) * TZ, oy0, ox0, 2, nphase, buf ^ 1);      // in flight behind the MFMAs below
-            const char* ldo = lds + RING + buf * DO_BYTES;
-            int zo[TPW][2];
-#pragma unroll
-            for (int t = 0; t < TPW; ++t)
-#pragma unroll
-                for (int rz = 0; rz < 2; ++rz) {
-                    int slot = rz + tap_dz[t] + phase;
-                    slot -= slot >= NSLOT ? NSLOT : 0;
-                    zo[t][rz] = slot * R::SBYTES + tap_yo[t];
-                }
-            auto in_off = [&](int t, int r) { return zo[t][r >= TY ? 1 : 0] + (r >= TY ? r - TY : r) * (G::HX * 64); };
-            uint4 af[NTA], afn[NTA], bfA[NTB], bfB[NTB];
-#pragma unroll
-            for (int i = 0; i < NTA; ++i) af[i] = TF::template get<HI_DO>(ldo, lo_do[i], row0 * 1024);
-#pragma unroll
-            for (int j = 0; j < NTB; ++j) bfA[j] = TF::template get<HI_IN>(lds_in, lo_in[0][j], in_off(0, row0));
-            for (int r = row0; r < G::ROWS; r += rowinc) {
-                const int rn = (r + rowinc < G::ROWS) ? r + rowinc : r;
-#pragma unroll
-                for (int t = 0; t < TPW; ++t) {
-                    uint4 (&cur)[NTB] = (t & 1) ? bfB : bfA;
-                    uint4 (&nxt)[NTB] = (t & 1) ? bfA : bfB;
-                    if (t + 1 < TPW) {
-#pragma unroll
-                        for (int j = 0; j < NTB; ++j) nxt[j] = TF::template get<HI_IN>(lds_in, lo_in[t + 1 < TPW ? t + 1 : 0][j], in_off(t + 1 < TPW ? t + 1 : 0, r));
-                    } else {
-#pragma unroll
-                        for (int i = 0; i < NTA; ++i) afn[i] = TF::template get<HI_DO>(ldo, lo_do[i], rn * 1024);
-#pragma unroll
-                        for (int j = 0; j < NTB; ++j) nxt[j] = TF::template get<HI_IN>(lds_in, lo_in[0][j], in_off(0, rn));
-                    }
-                    __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                    for (int i = 0; i < NTA; ++i)
-#pragma unroll
-                        for (int j = 0; j < NTB; ++j) mma16<T>(acc[t][i][j], af[i], cur[j]);
-                    __builtin_amdgcn_sched_barrier(0);
-                }
-#pragma unroll
-                for (int i = 0; i < NTA; ++i) af[i] = afn[i];
-                if (TPW & 1) {
-#pragma unroll
-                    for (int j = 0; j < NTB; ++j) bfA[j] = bfB[j];
-                }
-            }
-            if (do_bias) {                                 // column sums of the dOut tile (see conv_wgrad_kernel); rows dealt over the 8 waves
-                const int vx = lane >> 2, sl = lane & 3;
-#pragma unroll
-                for (int r = wave; r < G::ROWS; r += 8) {
-                    Piece<T> pz;
-                    pz.load(*reinterpret_cast<const uint4*>(ldo + r * 1024 + vx * 64 + sl * 16));
-#pragma unroll
-                    for (int j = 0; j < DT<T>::EPL; ++j) bsum[j] += pz.f[j];
-                }
-            }
-            phase = nphase;
-        }
-    }
-
-    constexpr int CL = NT * 16;
-    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-    __syncthreads();                                       // all tiles are done: the LDS is free
-    if (do_bias) {
-        float* shb = reinterpret_cast<float*>(lds);
-        constexpr int EPLc = DT<T>::EPL;
-#pragma unroll
-        for (int j = 0; j < EPLc; ++j) shb[tid * EPLc + j] = bsum[j];
-        __syncthreads();
-        if (tid < CL) {                                    // fixed-order fold (bit-reproducible)
-            const int piece = tid / EPLc, j = tid % EPLc;
-            float tot = 0.f;
-            for (int wv = 0; wv < 8; ++wv)
-                for (int vx = 0; vx < 16; ++vx) {
-                    const int ln = vx * 4 + (piece ^ ((vx >> 1) & 3));
-                    tot += shb[(wv * 64 + ln) * EPLc + j];
-                }
-            w.bslabs[((size_t)cb * w.P + pidx) * CL + tid] = tot;
-        }
-        __syncthreads();
-    }
-    // fold the two row groups (waves w and w + 4 own the same taps) through LDS, taps in two passes (4 + 3 taps of 16 VGPRs each:
-    // 64 KB for the four waves), then the rg = 0 waves write the slab: slab[tap][co_local][ci_local]
-    f32x4* red = reinterpret_cast<f32x4*>(lds);
-    constexpr int SLAB = TAPS * CL * CL;
-    float* slab = w.slabs + (size_t)(pair * w.P + pidx) * SLAB;
-    const int gq = lane >> 4, colq = lane & 15;
-#pragma unroll
-    for (int pass = 0; pass < 2; ++pass) {
-        constexpr int PT = 4;                              // taps per pass (the second pass has TPW - 4 = 3)
-        if (pass) __syncthreads();
-        if (rg == 1) {
-#pragma unroll
-            for (int t = pass * PT; t < TPW && t < (pass + 1) * PT; ++t)
-#pragma unroll
-                for (int i = 0; i < NTA; ++i)
-#pragma unroll
-                    for (int j = 0; j < NTB; ++j) red[((tg * PT + (t - pass * PT)) * 4 + i * 2 + j) * 64 + lane] = acc[t][i][j];
-        }
-        __syncthreads();
-        if (rg == 0) {
-#pragma unroll
-            for (int t = pass * PT; t < TPW && t < (pass + 1) * PT; ++t) {
-                const int tap = tg + 4 * t;
-#pragma unroll
-                for (int i = 0; i < NT; ++i)
-#pragma unroll
-                    for (int j = 0; j < NT; ++j) {
-                        f32x4 v = f32x4{0.f, 0.f, 0.f, 0.f};
-                        if (i < NTA && j < NTB) v = acc[t][i < NTA ? i : 0][j < NTB ? j : 0] + red[((tg * PT + (t - pass * PT)) * 4 + (i < NTA ? i : 0) * 2 + (j < NTB ? j : 0)) * 64 + lane];
-                        if (tap < TAPS) {
-#pragma unroll
-                            for (int rgi = 0; rgi < 4; ++rgi) slab[(tap * CL + i * 16 + gq * 4 + rgi) * CL + j * 16 + colq] = v[rgi];
-                        }
-                    }
-            }
-        }
     }
 }
 
@@ -713,7 +347,7 @@ __global__ void __launch_bounds__(256) wgrad_cls_reduce_kernel(const float* __re
     }
 }
 
-template <typename T, int KS, int STRIDE, int UPS, int TZ, int TY, int NTA = WG<T>::NT, int NTB = WG<T>::NT, bool ROLL = false>
+template <typename T, int KS, int STRIDE, int UPS, int TZ, int TY, int NTA = WG<T>::NT, int NTB = WG<T>::NT>
 static int launch_wgrad_cfg(WgradArgs w, float* dw, float* dbias, int accumulate, int cout, int cin, size_t ws_bytes, hipStream_t s) {
     using G = Geo<KS, STRIDE, TZ, TY>;
     constexpr int CL = WG<T>::NT * 16;
@@ -724,17 +358,6 @@ static int launch_wgrad_cfg(WgradArgs w, float* dw, float* dbias, int accumulate
     int P = wgrad_wgs() / npairs;             // persistent: ~2 workgroups per CU over all (cout, cin) block pairs
     if (P < 1) P = 1;
     if (P > w.ntiles) P = w.ntiles;
-    if constexpr (ROLL) {
-        // runs of z-consecutive tiles (rolling halo window): every (n, ty, tx) column is cut into rsegs segments so that at least P
-        // runs exist; a workgroup takes runs pidx, pidx + P, ...
-        const int cols = a.N * a.nty * a.ntx;
-        int segs = cdiv(P, cols);
-        if (segs > a.ntz) segs = a.ntz;
-        w.rseglen = cdiv(a.ntz, segs);
-        w.rsegs = cdiv(a.ntz, w.rseglen);
-        w.ntiles = cols * w.rsegs;            // (runs)
-        if (P > w.ntiles) P = w.ntiles;
-    }
     w.P = P;
     const int per_wg = (G::TAPS > 1) ? 1 : 4;
     const size_t slab_bytes = (size_t)npairs * P * per_wg * G::TAPS * CL * CL * sizeof(float);
@@ -742,8 +365,8 @@ static int launch_wgrad_cfg(WgradArgs w, float* dw, float* dbias, int accumulate
     if (need > ws_bytes) { set_error("conv_wgrad: workspace too small (%zu < %zu)", ws_bytes, need); return VDM_ERR_ARG; }
     if (dbias != nullptr && G::TAPS == 1) { set_error("conv_wgrad: fused bias gradient is only built for ksize 3"); return VDM_ERR_UNSUPPORTED; }
     w.bslabs = dbias ? reinterpret_cast<float*>(reinterpret_cast<char*>(w.slabs) + slab_bytes) : nullptr;
-    const size_t lds = (ROLL ? (size_t)Roll<G>::IMG : (size_t)((G::HVOX + 15) / 16) * 1024) + (size_t)G::OVOX * 64;
-    auto kern = conv_wgrad_kernel<T, KS, STRIDE, UPS, TZ, TY, NTA, NTB, ROLL>;
+    const size_t lds = (size_t)((G::HVOX + 15) / 16) * 1024 + (size_t)G::OVOX * 64;
+    auto kern = conv_wgrad_kernel<T, KS, STRIDE, UPS, TZ, TY, NTA, NTB>;
     static unsigned long long lds_done = 0;
     {
         int e = set_lds(kern, lds, lds_done);
@@ -754,47 +377,6 @@ static int launch_wgrad_cfg(WgradArgs w, float* dw, float* dbias, int accumulate
     const int total = G::TAPS * cout * cin;
     hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(cdiv(total, WRED_OUT)), dim3(256), 0, s,
                        (const float*)w.slabs, dw, G::TAPS, cout, cin, w.ncb, w.nkb, CL, P * per_wg, accumulate);
-    VDM_LAUNCH_CHECK("wgrad_reduce_kernel");
-    if (dbias) {
-        hipLaunchKernelGGL(wgrad_bias_reduce_kernel, dim3(cdiv(cout, 16)), dim3(256), 0, s, (const float*)w.bslabs, dbias, cout, CL, P, accumulate);
-        VDM_LAUNCH_CHECK("wgrad_bias_reduce_kernel");
-    }
-    return VDM_OK;
-}
-
-template <typename T, int NTA = WG<T>::NT, int NTB = WG<T>::NT>
-static int launch_wgrad2(WgradArgs w, float* dw, float* dbias, int accumulate, int cout, int cin, size_t ws_bytes, hipStream_t s) {
-    using G = Geo<3, 1, 2, 8>;
-    constexpr int CL = WG<T>::NT * 16;
-    ConvArgs& a = w.c;
-    a.ntz = cdiv(a.Dz, 2); a.nty = cdiv(a.Dy, 8); a.ntx = cdiv(a.Dx, 16);
-    const int npairs = w.ncb * w.nkb;
-    int P = wgrad2_wgs() / npairs;            // persistent: ONE 104-KB workgroup per CU over all (cout, cin) block pairs
-    if (P < 1) P = 1;
-    const int cols = a.N * a.nty * a.ntx;     // runs of z-consecutive tiles: columns x segments, at least P of them
-    int segs = cdiv(P, cols);
-    if (segs > a.ntz) segs = a.ntz;
-    w.rseglen = cdiv(a.ntz, segs);
-    w.rsegs = cdiv(a.ntz, w.rseglen);
-    w.ntiles = cols * w.rsegs;
-    if (P > w.ntiles) P = w.ntiles;
-    w.P = P;
-    const size_t slab_bytes = (size_t)npairs * P * 27 * CL * CL * sizeof(float);
-    const size_t need = slab_bytes + (size_t)w.ncb * P * CL * sizeof(float);
-    if (need > ws_bytes) { set_error("conv_wgrad: workspace too small (%zu < %zu)", ws_bytes, need); return VDM_ERR_ARG; }
-    w.bslabs = dbias ? reinterpret_cast<float*>(reinterpret_cast<char*>(w.slabs) + slab_bytes) : nullptr;
-    const size_t lds = (size_t)6 * Roll<G>::SBYTES + 2 * (size_t)G::OVOX * 64;
-    auto kern = conv_wgrad2_kernel<T, NTA, NTB>;
-    static unsigned long long lds_done = 0;
-    {
-        int e = set_lds(kern, lds, lds_done);
-        if (e) return e;
-    }
-    hipLaunchKernelGGL(kern, dim3(npairs * P), dim3(512), lds, s, w);
-    VDM_LAUNCH_CHECK("conv_wgrad2_kernel");
-    const int total = 27 * cout * cin;
-    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(cdiv(total, WRED_OUT)), dim3(256), 0, s,
-                       (const float*)w.slabs, dw, 27, cout, cin, w.ncb, w.nkb, CL, P, accumulate);
     VDM_LAUNCH_CHECK("wgrad_reduce_kernel");
     if (dbias) {
         hipLaunchKernelGGL(wgrad_bias_reduce_kernel, dim3(cdiv(cout, 16)), dim3(256), 0, s, (const float*)w.bslabs, dbias, cout, CL, P, accumulate);
@@ -847,22 +429,7 @@ static int launch_wgrad(const WgradArgs& w, float* dw, float* db, int acc, int c
     if (ks == 1) return launch_wgrad_cfg<T, 1, 1, 0, 4, 8>(w, dw, db, acc, cout, cin, ws, s);
     if (stride == 2) return launch_wgrad_cfg<T, 3, 2, 0, 2, 4>(w, dw, db, acc, cout, cin, ws, s);
     if (ups) return launch_wgrad_cls<T, 2, 8, 512>(w, dw, db, acc, cout, cin, ws, s);      // (2x4x16 tiles with 1024 workgroups: same time)
-    constexpr int NT = WG<T>::NT;
-    if (wgrad_gen() == 2) {                                  // second generation: one double-buffered 8-wave workgroup per CU
-        if constexpr (sizeof(T) == 2) {
-            if (cin <= 16) return launch_wgrad2<T, 2, 1>(w, dw, db, acc, cout, cin, ws, s);
-            if (cout <= 16) return launch_wgrad2<T, 1, 2>(w, dw, db, acc, cout, cin, ws, s);
-        }
-        return launch_wgrad2<T>(w, dw, db, acc, cout, cin, ws, s);
-    }
-    if (wgrad_roll()) {                                      // rolling z window: consecutive tiles of a workgroup share 2 of 4 halo slices
-        if constexpr (sizeof(T) == 2) {                      // 64-byte blocks with a single real 16-channel tile
-            if (cin <= 16) return launch_wgrad_cfg<T, 3, 1, 0, 2, 8, 2, 1, true>(w, dw, db, acc, cout, cin, ws, s);
-            if (cout <= 16) return launch_wgrad_cfg<T, 3, 1, 0, 2, 8, 1, 2, true>(w, dw, db, acc, cout, cin, ws, s);
-        }
-        return launch_wgrad_cfg<T, 3, 1, 0, 2, 8, NT, NT, true>(w, dw, db, acc, cout, cin, ws, s);
-    }
-    if constexpr (sizeof(T) == 2) {
+    if constexpr (sizeof(T) == 2) {                          // 64-byte blocks with a single real 16-channel tile
         if (cin <= 16) return launch_wgrad_cfg<T, 3, 1, 0, 2, 8, 2, 1>(w, dw, db, acc, cout, cin, ws, s);
         if (cout <= 16) return launch_wgrad_cfg<T, 3, 1, 0, 2, 8, 1, 2>(w, dw, db, acc, cout, cin, ws, s);
     }
