@@ -189,7 +189,7 @@ def main():
         for p in params:
             if p.grad is not None and not (synced and p is net.flat):
                 allreduce_mean_(p.grad, world)
-        clip_grad_norm_flat_(params, 0.5, use_hip=True)
+        clip_grad_norm_flat_(params, 0.5, use_hip=True, want_norm=False)
         opt.step()
         return loss
 

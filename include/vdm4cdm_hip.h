@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define VDM_ABI_VERSION 6
+#define VDM_ABI_VERSION 7
 
 typedef enum { VDM_OK = 0, VDM_ERR_ARG = -1, VDM_ERR_HIP = -2, VDM_ERR_UNSUPPORTED = -3 } vdm_status;
 typedef enum { VDM_F32 = 0, VDM_BF16 = 1 } vdm_dtype;
@@ -248,6 +248,19 @@ int vdm_channel_sums(const void* x, int64_t rows, int c, int dtype, float* out, 
  * NULL): with a = dyh and b = x of a GroupNorm these are the "one tile per sample" partials vdm_gn_bwd_finalize / vdm_gn_bwd_apply take. */
 int vdm_channel_dot_sums(const void* a, const void* b1, int c1, const void* b2, int c2, int n, int64_t rows_per_sample, int dtype,
                          float* out, void* stream);
+
+/* ---- scalar glue of the training step [R7, R11; D9-D11] (replaces ~60 five-microsecond ATen launches on the critical path) --------
+ * train_scalars: out[5][batch] = {t, alpha_t, sigma_t, coef = gamma'(t) bpd / batch, t_norm} of the fixed linear schedule; with u0
+ *   (DEVICE pointer to one uniform draw) t_i = (u0 + (rank batch + i) / (world batch)) mod 1 - the antithetic time grid stratified over
+ *   the global batch - else t_i = times[i].  [REF trainVDM3D128...py:128-132 -> LightVDM.training_step; NB vdm_model.py:320-324]
+ * elbo_assemble: out[4] = {elbo, diffusion, latent, reconstruction} in bits/dim from the sums of vdm_loss_terms:
+ *   diffusion = 0.5 sum_n coef_n S0_n, latent = mean_n (c_lat0 + c_lat1 S1_n), reconstruction = mean_n (c_rec0 S2_n + c_rec1).
+ * clip_scale: x *= min(1, max_norm / (sqrt(*sumsq) + 1e-6)) - gradient_clip_val [REF trainVDM3D128...py:45] on the device. */
+int vdm_train_scalars(const float* u0, const float* times, int batch, int rank, int world, float gamma_min, float gamma_max,
+                      float bpd_over_batch, float* out, void* stream);
+int vdm_elbo_assemble(const float* sums, const float* coef, int batch, float c_lat0, float c_lat1, float c_rec0, float c_rec1,
+                      float* out, void* stream);
+int vdm_clip_scale(float* x, int64_t n, const float* sumsq, float max_norm, void* stream);
 
 /* ---- K9: ancestral update [NB vdm_model.py:370-378] ----------------------------------------
  * z <- ratio*(z - c_sigma_t*eps_hat) + scale*noise ; the four scalars are read from the DEVICE table

@@ -687,6 +687,62 @@ __global__ void __launch_bounds__(256) channel_dot_sums_kernel(const T* __restri
 
 __global__ void step_inc_kernel(int32_t* p) { *p += 1; }
 
+// ---------------------------------------------------------------------------------------------
+// The scalar glue of a VDM training step as three tiny kernels (it used to be ~60 ATen launches of 5 us each, all on the critical
+// path: time grid, alpha / sigma, the ELBO terms, the clip coefficient).
+// train_scalars: out[5][B] = {t, alpha_t, sigma_t, coef = gamma'(t) * bpd / B, t_norm} for the fixed linear schedule [D9, D10];
+//   t_i = (u0 + (rank * B + i) / (world * B)) mod 1 (antithetic stratification over the global batch) when u0 != NULL, else times[i].
+__global__ void train_scalars_kernel(const float* __restrict__ u0, const float* __restrict__ times, int B, int rank, int world,
+                                     float gamma_min, float gamma_max, float bpd_over_B, float* __restrict__ out) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= B) return;
+    float t;
+    if (u0) {
+        t = u0[0] + (float)(rank * B + i) / (float)(world * B);
+        t -= floorf(t);                                        // torch.remainder(., 1.0)
+    } else {
+        t = times[i];
+    }
+    const float g = gamma_min + (gamma_max - gamma_min) * t;
+    out[i] = t;
+    out[B + i] = sqrtf(1.0f / (1.0f + expf(g)));              // alpha = sqrt(sigmoid(-gamma))
+    out[2 * B + i] = sqrtf(1.0f / (1.0f + expf(-g)));         // sigma = sqrt(sigmoid(gamma))
+    out[3 * B + i] = (gamma_max - gamma_min) * bpd_over_B;    // 2 w_n, w_n = 0.5 gamma'(t) bpd / B
+    out[4 * B + i] = (g - gamma_min) / (gamma_max - gamma_min);
+}
+
+// elbo_assemble: out[4] = {elbo, diffusion, latent, reconstruction} (bits/dim, batch means) from the per-sample sums of
+// vdm_loss_terms: diffusion = 0.5 sum_n coef_n S0_n;  latent = mean_n (c_lat0 + c_lat1 S1_n);  recons = mean_n (c_rec0 S2_n + c_rec1)
+// (the constants fold numel, var_1, data_noise and bits-per-dim; computed in fp64 on the host).  One wave, fixed order.
+__global__ void elbo_assemble_kernel(const float* __restrict__ sums, const float* __restrict__ coef, int B, float c_lat0, float c_lat1,
+                                     float c_rec0, float c_rec1, float* __restrict__ out) {
+    if (threadIdx.x != 0) return;
+    float diff = 0.f, lat = 0.f, rec = 0.f;
+    for (int n = 0; n < B; ++n) {
+        diff += 0.5f * coef[n] * sums[3 * n];
+        lat += c_lat0 + c_lat1 * sums[3 * n + 1];
+        rec += c_rec0 * sums[3 * n + 2] + c_rec1;
+    }
+    lat /= (float)B; rec /= (float)B;
+    out[0] = diff + lat + rec; out[1] = diff; out[2] = lat; out[3] = rec;
+}
+
+// clip_scale: x *= min(1, max_norm / (sqrt(sumsq) + 1e-6)) - the global-norm clip [D11, gradient_clip_val] with the coefficient
+// computed from the device-side sum of squares inside the scaling pass (no host sync, no separate coefficient kernels).
+__global__ void __launch_bounds__(256) clip_scale_kernel(float* __restrict__ x, int64_t n, const float* __restrict__ sumsq, float max_norm) {
+    const float coef = fminf(max_norm / (sqrtf(sumsq[0]) + 1.0e-6f), 1.0f);
+    if (coef == 1.0f) return;                                  // (uniform) nothing to do below the threshold
+    const int64_t n4 = n >> 2;
+    float4* x4 = reinterpret_cast<float4*>(x);
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) {
+        float4 v = x4[i];
+        v.x *= coef; v.y *= coef; v.z *= coef; v.w *= coef;
+        x4[i] = v;
+    }
+    if (blockIdx.x == 0)
+        for (int64_t i = (n4 << 2) + threadIdx.x; i < n; i += 256) x[i] *= coef;
+}
+
 __global__ void __launch_bounds__(256) sumsq_kernel(const float* __restrict__ x, int64_t n, float* __restrict__ part) {
     float acc[1] = {0.f};
     const int64_t n4 = n >> 2;
@@ -973,5 +1029,31 @@ extern "C" int vdm_sumsq(const float* x, int64_t n, float* out, float* workspace
     hipLaunchKernelGGL(sumsq_kernel, dim3(g), dim3(256), 0, (hipStream_t)stream, x, n, workspace);
     hipLaunchKernelGGL(fold_partials_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, (const float*)workspace, (int)g, 1, out, 1);
     VDM_LAUNCH_CHECK("sumsq_kernel");
+    return VDM_OK;
+}
+
+extern "C" int vdm_train_scalars(const float* u0, const float* times, int batch, int rank, int world, float gamma_min, float gamma_max,
+                                 float bpd_over_batch, float* out, void* stream) {
+    VDM_REQUIRE(out && batch > 0 && (u0 || times) && world > 0 && rank >= 0 && rank < world, "train_scalars: bad arguments");
+    VDM_REQUIRE(gamma_max > gamma_min, "train_scalars: gamma_max must exceed gamma_min");
+    hipLaunchKernelGGL(train_scalars_kernel, dim3((batch + 63) / 64), dim3(64), 0, (hipStream_t)stream, u0, times, batch, rank, world, gamma_min,
+                       gamma_max, bpd_over_batch, out);
+    VDM_LAUNCH_CHECK("train_scalars_kernel");
+    return VDM_OK;
+}
+
+extern "C" int vdm_elbo_assemble(const float* sums, const float* coef, int batch, float c_lat0, float c_lat1, float c_rec0, float c_rec1,
+                                 float* out, void* stream) {
+    VDM_REQUIRE(sums && coef && out && batch > 0, "elbo_assemble: bad arguments");
+    hipLaunchKernelGGL(elbo_assemble_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, sums, coef, batch, c_lat0, c_lat1, c_rec0, c_rec1, out);
+    VDM_LAUNCH_CHECK("elbo_assemble_kernel");
+    return VDM_OK;
+}
+
+extern "C" int vdm_clip_scale(float* x, int64_t n, const float* sumsq, float max_norm, void* stream) {
+    VDM_REQUIRE(x && sumsq && n > 0 && max_norm > 0.f, "clip_scale: bad arguments");
+    VDM_REQUIRE(((uintptr_t)x & 15) == 0, "clip_scale: x must be 16-byte aligned");
+    hipLaunchKernelGGL(clip_scale_kernel, dim3(grid_for(n, 256 * 16)), dim3(256), 0, (hipStream_t)stream, x, n, sumsq, max_norm);
+    VDM_LAUNCH_CHECK("clip_scale_kernel");
     return VDM_OK;
 }

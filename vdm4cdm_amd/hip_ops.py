@@ -616,6 +616,29 @@ def sumsq(x, out):
     return out
 
 
+def train_scalars(B, device, rank, world, gamma_min, gamma_max, bpd_over_B, u0=None, times=None):
+    """[5, B] fp32 = {t, alpha_t, sigma_t, coef, t_norm} (vdm_train_scalars); u0: device tensor with one uniform draw, or times [B]."""
+    out = torch.empty((5, B), dtype=torch.float32, device=device)
+    _contig(u0, times)
+    check(_lib.lib().vdm_train_scalars(_p(u0), _p(times), B, rank, world, float(gamma_min), float(gamma_max), float(bpd_over_B), _p(out), _s()),
+          "vdm_train_scalars")
+    return out
+
+
+def elbo_assemble(sums, coef, c_lat0, c_lat1, c_rec0, c_rec1):
+    _contig(sums, coef)
+    out = torch.empty(4, dtype=torch.float32, device=sums.device)
+    check(_lib.lib().vdm_elbo_assemble(_p(sums), _p(coef), sums.shape[0], float(c_lat0), float(c_lat1), float(c_rec0), float(c_rec1), _p(out), _s()),
+          "vdm_elbo_assemble")
+    return out
+
+
+def clip_scale_(x, sumsq_acc, max_norm):
+    _contig(x)
+    check(_lib.lib().vdm_clip_scale(_p(x), x.numel(), _p(sumsq_acc), float(max_norm), _s()), "vdm_clip_scale")
+    return x
+
+
 class PackPlan:
     """All (conv, form) weight packings of a network as one launch (vdm_conv_pack_many): the item and chunk tables are built
     once per (parameter storage, dtype, forms) and live on the device."""

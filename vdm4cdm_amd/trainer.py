@@ -45,20 +45,28 @@ def allreduce_mean_(t, world):
     return t
 
 
-def clip_grad_norm_flat_(params, max_norm, use_hip):
-    """Global-norm clipping without a host sync.  Returns the (device) total norm."""
+def clip_grad_norm_flat_(params, max_norm, use_hip, want_norm=True):
+    """Global-norm clipping without a host sync.  Returns the (device) total norm (None with want_norm=False on the HIP path, where
+    the coefficient never exists as a tensor: K10 sums the squares, vdm_clip_scale derives min(1, max_norm / (norm + 1e-6)) inside the
+    scaling pass)."""
     grads = [p.grad for p in params if p.grad is not None]
     if use_hip:
         from . import hip_ops as ops
         acc = torch.zeros(1, device=grads[0].device)
-        for g in grads:
-            if g.numel() >= 1024 and g.is_contiguous() and g.data_ptr() % 16 == 0:
-                ops.sumsq(g, acc)                                   # K10
-            else:
-                acc += (g.float() ** 2).sum()
-        total = acc.sqrt()
-    else:
-        total = torch.sqrt(sum((g.float() ** 2).sum() for g in grads))
+        big = [g for g in grads if g.numel() >= 1024 and g.is_contiguous() and g.data_ptr() % 16 == 0 and g.dtype == torch.float32]
+        small = [g for g in grads if not any(g is b for b in big)]
+        for g in big:
+            ops.sumsq(g, acc)                                   # K10
+        for g in small:
+            acc += (g.float() ** 2).sum()
+        for g in big:
+            ops.clip_scale_(g, acc, max_norm)
+        if small:
+            coef = torch.clamp(max_norm / (acc.sqrt() + 1e-6), max=1.0)
+            for g in small:
+                g.mul_(coef.to(g.device))
+        return acc.sqrt() if want_norm else None
+    total = torch.sqrt(sum((g.float() ** 2).sum() for g in grads))
     coef = torch.clamp(max_norm / (total + 1e-6), max=1.0)
     for g in grads:
         g.mul_(coef.to(g.device))
@@ -130,8 +138,9 @@ class Trainer:
                     if p.grad is not None and not (synced and p is getattr(sm, "flat", None)):
                         allreduce_mean_(p.grad, self.world)
                 gnorm = None
+                will_log = (self.global_step + 1) % self.log_every_n_steps == 0 or self.global_step == 0
                 if self.gradient_clip_val:
-                    gnorm = clip_grad_norm_flat_(params, self.gradient_clip_val, use_hip)
+                    gnorm = clip_grad_norm_flat_(params, self.gradient_clip_val, use_hip, want_norm=will_log)
                 opt.step()
                 self.global_step += 1
                 if self.global_step % self.log_every_n_steps == 0 or self.global_step == 1:

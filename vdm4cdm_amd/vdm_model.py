@@ -41,6 +41,28 @@ class _DiffusionLossFn(torch.autograd.Function):
         return g * d, None, None, None, None, None, None
 
 
+class _ElboFn(torch.autograd.Function):
+    """(elbo, [diffusion, latent, reconstruction]) in bits/dim: K8 (fused per-sample reductions + d eps_hat) and the scalar assembly
+    (vdm_elbo_assemble) - three launches; the metrics are not differentiable, d elbo / d eps_hat = coef_n (eps_hat - eps)."""
+
+    @staticmethod
+    def forward(ctx, eps_hat, x, eps, eps0, s0a0, coef, consts):
+        from . import hip_ops as ops
+        d = torch.empty_like(eps_hat)
+        sums = torch.zeros(x.shape[0], 3, device=x.device)
+        ops.loss_terms(x, eps, eps_hat.contiguous(), eps0, s0a0, coef, sums, d)
+        out = ops.elbo_assemble(sums, coef, *consts)
+        ctx.save_for_backward(d)
+        elbo, parts = out[0], out[1:]
+        ctx.mark_non_differentiable(parts)
+        return elbo, parts
+
+    @staticmethod
+    def backward(ctx, g, _):
+        (d,) = ctx.saved_tensors
+        return g * d, None, None, None, None, None, None
+
+
 class VDM(nn.Module):
     def __init__(self, score_model, noise_schedule="fixed_linear", gamma_min=-13.3, gamma_max=13.3,
                  antithetic_time_sampling=True, data_noise=DATA_NOISE, w_cfg=None):
@@ -136,9 +158,11 @@ class VDM(nn.Module):
         numel = x[0].numel()
         bpd = 1.0 / (numel * math.log(2.0))
         x = x.to(torch.float32).contiguous()
-        if times is None:
-            times = self.sample_times(B, x.device)
-        g_t = self.gamma(times)
+        hip = self._hip(x)
+        if not hip:
+            if times is None:
+                times = self.sample_times(B, x.device)
+            g_t = self.gamma(times)
         # 0-dim CPU tensors act as scalars (no device sync for the fixed schedule)
         # (fp64: var1 - log(var1) - 1 ~ 1e-12 cancels catastrophically in fp32)
         g0 = self.gamma(torch.zeros((), dtype=torch.float64))
@@ -146,22 +170,37 @@ class VDM(nn.Module):
         var1 = torch.sigmoid(g1)
         a0, s0 = self.alpha(g0), self.sigma(g0)
         bc = (B,) + (1,) * (x.dim() - 1)
-        if self._hip(x):
+        if hip:
             from . import hip_ops as ops
             if self.noise_schedule != "fixed_linear":
                 raise NotImplementedError("HIP training path supports noise_schedule='fixed_linear' (all 3D scripts); "
                                           "'learned_linear' needs d loss / d z_t which the HIP backward does not emit")
-            rank, _ = self._rank_world()                   # (Philox stream id = 2*rank + {1,2}: different noise fields per rank)
+            rank, world = self._rank_world()               # (Philox stream id = 2*rank + {1,2}: different noise fields per rank)
             if eps is None:
                 eps = ops.randn(torch.empty_like(x), noise_seed(), 2 * rank + 1)
             if eps0 is None:
                 eps0 = ops.randn(torch.empty_like(x), noise_seed(), 2 * rank + 2)
-            z_t = ops.diffuse(x, eps.contiguous(), self.alpha(g_t).contiguous(), self.sigma(g_t).contiguous())
-            eps_hat = self.get_pred_noise(z_t, g_t, **kwargs)
-            w = 0.5 * self.dgamma_dt(times) * bpd / B                      # per-sample weight of S_n
-            sums = torch.zeros(B, 3, device=x.device)
-            diff = _DiffusionLossFn.apply(eps_hat, x, eps, eps0.contiguous(), float(s0 / a0), (2.0 * w).contiguous(), sums)
-            sum_x2, sum_r2 = sums[:, 1], sums[:, 2]
+            # the scalar side of the step in ONE launch: time grid (stratified over the global batch), alpha_t, sigma_t, the per-sample
+            # loss weight 2 w_n = gamma'(t) bpd / B and the network's normalised time - no ATen launch between the noise draw and K7
+            if times is None and self.antithetic_time_sampling:
+                u0 = torch.rand(1, device=x.device, generator=train_generator(x.device))
+                sc = ops.train_scalars(B, x.device, rank, world, self.gamma_min, self.gamma_max, bpd / B, u0=u0)
+            else:
+                if times is None:
+                    times = self.sample_times(B, x.device)
+                sc = ops.train_scalars(B, x.device, 0, 1, self.gamma_min, self.gamma_max, bpd / B,
+                                       times=times.to(device=x.device, dtype=torch.float32).contiguous())
+            z_t = ops.diffuse(x, eps.contiguous(), sc[1], sc[2])
+            if self.w_cfg is None or self.training:        # get_pred_noise's plain branch, t_norm straight from the scalar kernel
+                eps_hat = self.score_model(z_t, t=sc[4], **kwargs)
+            else:
+                eps_hat = self.get_pred_noise(z_t, self.gamma(sc[0]), **kwargs)
+            dn = self.data_noise
+            consts = (float(0.5 * numel * (var1 - torch.log(var1) - 1.0) * bpd), float(0.5 * (1.0 - var1) * bpd),
+                      float(0.5 / dn ** 2 * bpd), float(numel * (math.log(dn) + 0.5 * math.log(2 * math.pi)) * bpd))
+            loss, parts = _ElboFn.apply(eps_hat, x, eps, eps0.contiguous(), float(s0 / a0), sc[3], consts)
+            metrics = {"elbo": loss.detach(), "diffusion_loss": parts[0], "latent_loss": parts[1], "reconstruction_loss": parts[2]}
+            return loss, metrics
         else:
             red = tuple(range(1, x.dim()))
             rank, world = self._rank_world()
@@ -459,7 +498,11 @@ class LightVDM(nn.Module):
         opt = torch.optim.AdamW(self.parameters(), lr=self.learning_rate, fused=fused)       # D11
         sm = self.model.score_model
         if hasattr(sm, "mark_weights_dirty"):      # fused steps do not bump Tensor._version: tell the HIP executor to re-pack
-            opt.register_step_post_hook(lambda *_: sm.mark_weights_dirty())
+            def _after_step(*_):
+                sm.mark_weights_dirty()
+                if hasattr(sm, "repack_weights"):
+                    sm.repack_weights()
+            opt.register_step_post_hook(_after_step)
         return opt
 
     def draw_samples(self, batch_size, n_sampling_steps=250, verbose=False, return_all=False, **kwargs):
