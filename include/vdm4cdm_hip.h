@@ -238,8 +238,23 @@ int vdm_augment_batch(const vdm_augment_channel* host_channels, int n_channels, 
 
 /* ---- attention block of the mid level (CUNet(mid_attn=True, n_attention_heads)) [REF trainSFM_c_uc_from_field_name.py:61,104-118;
  * NB blocks.py:169-170 `x = self.attention_blocks[i](x)`] ---------------------------------------------------------------------
- * scores[rows][cols] (fp32, in place) <- softmax over each row of scale * scores; the backward turns dprobs (in place) into the
- * gradient w.r.t. the un-scaled scores: scale * p * (dp - sum_j dp_j p_j).  The batched GEMMs around them are library GEMMs. */
+ * Fused core  out_i = sum_j softmax_j(scale q_i . k_j) v_j  per sample and head on the matrix cores, forward and backward, without
+ * the [N, heads, V, V] score tensor (csrc/attention.hip).  Operands in `dtype` (bf16 MFMA / exact fp32 MFMA), softmax and sums fp32.
+ *   split_heads: src[n][v][src_stride] (channels src_offset + h*hd ...) -> rowmajor [n][h][v][hd] and / or transposed [n][h][hd][v]
+ *                (either may be NULL).  The q, k, v of the block's 1x1x1 qkv conv ([n][v][3][C]: stride 3C, offsets 0, C, 2C).
+ *   fwd:   q, k row-major, vt transposed -> out [n][v][heads*hd] (the layout the projection conv reads), lse [n][h][v] (may be NULL).
+ *   rowdot: out[n][h][v] = sum_d a[n][v][h*hd+d] b[n][v][h*hd+d]   (dsum = rowsum(dOut * out) of the backward).
+ *   bwd:   -> dqkv [n][v][3][heads*hd]; dQ in its own pass over the keys: no float atomics, bit-reproducible.
+ * voxels % 4 == 0; head_dim in {16, 32, 64, 96, 128}.
+ * (vdm_softmax_rows / _bwd: the row softmax of a materialised score matrix - kept for callers that hold one; off the network path.) */
+int vdm_attn_split_heads(const void* src, int64_t src_stride, int64_t src_offset, int n, int64_t voxels, int heads, int head_dim,
+                         int dtype, void* rowmajor, void* transposed, void* stream);
+int vdm_attn_fwd(const void* q, const void* k, const void* vt, int n, int64_t voxels, int heads, int head_dim, int dtype, float scale,
+                 void* out, float* lse, void* stream);
+int vdm_attn_rowdot(const void* a, const void* b, int n, int64_t voxels, int heads, int head_dim, int dtype, float* out, void* stream);
+int vdm_attn_bwd(const void* q, const void* k, const void* v, const void* qt, const void* kt, const void* do_rowmajor,
+                 const void* do_transposed, const float* lse, const float* dsum, int n, int64_t voxels, int heads, int head_dim,
+                 int dtype, float scale, void* dqkv, void* stream);
 int vdm_softmax_rows(float* scores, int64_t rows, int cols, float scale, void* stream);
 int vdm_softmax_rows_bwd(const float* probs, float* dprobs, int64_t rows, int cols, float scale, void* stream);
 /* out[c] = sum over rows of x[row][c] (x: [rows][c] in `dtype`): bias gradients of the block's two 1x1x1 projections. */

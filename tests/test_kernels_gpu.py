@@ -9,6 +9,11 @@ import pytest
 import torch
 import torch.nn.functional as F
 
+
+def _lib_mod():
+    from vdm4cdm_amd import _lib
+    return _lib
+
 pytestmark = pytest.mark.gpu
 
 DEV = "cuda:0"
@@ -584,6 +589,52 @@ def test_cond_table_rejects_unsupported_widths():
     with pytest.raises(ValueError, match="chs\\[0\\]"):
         CUNet(shape=(1, 16, 16, 16), chs=[96, 192], t_conditioning=True, backend="hip")
     CUNet(shape=(1, 16, 16), chs=[96, 192], t_conditioning=True, backend="torch")          # the torch backend has no such limit
+
+
+# ------------------------------------------------------------------------------------------ fused attention core
+@pytest.mark.parametrize("dtype", DTYPES, ids=["f32", "bf16"])
+@pytest.mark.parametrize("N,V,H,hd", [(2, 64, 4, 16), (1, 100, 2, 32), (1, 4096, 4, 64), (2, 216, 3, 96), (1, 36, 1, 128)],
+                         ids=["v64_hd16", "v100_ragged_hd32", "v4096_hd64", "v216_hd96", "v36_hd128"])
+def test_fused_attention_core(dtype, N, V, H, hd):
+    """csrc/attention.hip (scores, online softmax, P V on the matrix cores; dK/dV and dQ passes) against softmax(q k^T / sqrt(hd)) v and
+    its autograd gradients in fp32 on the CPU.  Ragged voxel counts (not a multiple of the 16 / 32-key tiles) exercise the masks.
+    fp32 operands: exact MFMA, <= 2e-5 relative; bf16 operands: inputs are rounded to bf16 first (the reference sees the same values),
+    the remaining difference is the bf16 rounding of P / dS inside the kernel: <= 2e-2 of max|ref|."""
+    ops = _ops()
+    C = H * hd
+    g = torch.Generator().manual_seed(V + hd)
+    qkv = (torch.randn(N, V, 3 * C, generator=g) * 0.7).to(dtype)
+    dout = torch.randn(N, V, C, generator=g).to(dtype)
+    scale = 1.0 / math.sqrt(hd)
+    ref_in = qkv.float().clone().requires_grad_(True)
+    q, k, v = (ref_in[:, :, i * C:(i + 1) * C].reshape(N, V, H, hd).permute(0, 2, 1, 3) for i in range(3))
+    p = torch.softmax(torch.matmul(q, k.transpose(-1, -2)) * scale, dim=-1)
+    ref = torch.matmul(p, v).permute(0, 2, 1, 3).reshape(N, V, C)
+    ref.backward(dout.float())
+    dev = qkv.to(DEV)
+    qh, qt = ops.attn_split_heads(dev, 0, 3, H)
+    kh, kt = ops.attn_split_heads(dev, 1, 3, H)
+    vh, vt = ops.attn_split_heads(dev, 2, 3, H)
+    assert torch.equal(qh.cpu(), qkv[:, :, :C].reshape(N, V, H, hd).permute(0, 2, 1, 3)) and torch.equal(vt.cpu(), vh.cpu().transpose(-1, -2))
+    out, lse = ops.attn_fwd(qh, kh, vt, scale, (N, V, C))
+    tol = 2e-5 if dtype == torch.float32 else 2e-2
+    err = (out.float().cpu() - ref.detach()).abs().max().item()
+    assert err <= tol * ref.abs().max().item(), f"forward {err} vs {ref.abs().max().item()}"
+    ref_lse = torch.logsumexp(torch.matmul(q, k.transpose(-1, -2)) * scale, dim=-1).detach()
+    assert (lse.cpu() - ref_lse).abs().max().item() <= (1e-4 if dtype == torch.float32 else 5e-2)
+    dqkv = ops.attn_bwd(qh, kh, vh, qt, kt, dout.to(DEV), out, lse, scale)
+    gerr = (dqkv.float().cpu() - ref_in.grad).abs().max().item()
+    assert gerr <= (2e-4 if dtype == torch.float32 else 3e-2) * ref_in.grad.abs().max().item(), f"backward {gerr} vs {ref_in.grad.abs().max().item()}"
+    dqkv2 = ops.attn_bwd(qh, kh, vh, qt, kt, dout.to(DEV), out, lse, scale)
+    assert torch.equal(dqkv, dqkv2), "attention backward is not bit-reproducible"
+
+
+def test_fused_attention_rejects_unbuilt_head_widths():
+    from vdm4cdm_amd.networks import CUNet
+    with pytest.raises(ValueError, match="head width"):
+        CUNet(shape=(1, 16, 16, 16), chs=[16, 40], mid_attn=True, n_attention_heads=1, backend="hip")
+    with pytest.raises(_lib_mod().VdmError, match="multiple of 4"):
+        _ops().attn_split_heads(torch.zeros(1, 6, 48, device=DEV), 0, 3, 1)
 
 
 # ------------------------------------------------------------------------------------------ small ops

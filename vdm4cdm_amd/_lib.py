@@ -95,6 +95,10 @@ SIGNATURES = {
     "vdm_cond_table_bwd": (_i, [C.POINTER(CondMlp), _i, _i, _i, _p, _i64, _p, _p, _p, _p]),
     "vdm_cond_table_step": (_i, [_p, _p, _p, _i, _i, _p, _p]),
     "vdm_augment_batch": (_i, [C.POINTER(AugmentChannel), _i, _i, _i, C.POINTER(AugmentSample), _i, _p]),
+    "vdm_attn_split_heads": (_i, [_p, _i64, _i64, _i, _i64, _i, _i, _i, _p, _p, _p]),
+    "vdm_attn_fwd": (_i, [_p, _p, _p, _i, _i64, _i, _i, _i, _f, _p, _p, _p]),
+    "vdm_attn_rowdot": (_i, [_p, _p, _i, _i64, _i, _i, _i, _p, _p]),
+    "vdm_attn_bwd": (_i, [_p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i64, _i, _i, _i, _f, _p, _p]),
     "vdm_softmax_rows": (_i, [_p, _i64, _i, _f, _p]),
     "vdm_softmax_rows_bwd": (_i, [_p, _p, _i64, _i, _f, _p]),
     "vdm_channel_sums": (_i, [_p, _i64, _i, _i, _p, _p]),

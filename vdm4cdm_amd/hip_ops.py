@@ -535,6 +535,44 @@ def channel_dot_sums(a, b1, b2=None):
     return out
 
 
+def attn_split_heads(src, sub, nsub, heads, rowmajor=True, transposed=True):
+    """src: [N, ..., nsub * C] activations (sub-tensor `sub` of nsub: the q / k / v of the qkv conv, or nsub = 1) -> (row-major
+    [N, H, V, hd], transposed [N, H, hd, V]) in src's dtype (either None when not requested)."""
+    _contig(src)
+    N = src.shape[0]
+    C = src.shape[-1] // nsub
+    V = src.numel() // (N * nsub * C)
+    hd = C // heads
+    rm = torch.empty((N, heads, V, hd), dtype=src.dtype, device=src.device) if rowmajor else None
+    tr = torch.empty((N, heads, hd, V), dtype=src.dtype, device=src.device) if transposed else None
+    check(_lib.lib().vdm_attn_split_heads(_p(src), nsub * C, sub * C, N, V, heads, hd, dt_id(src.dtype), _p(rm), _p(tr), _s()), "vdm_attn_split_heads")
+    return rm, tr
+
+
+def attn_fwd(q, k, vt, scale, out_shape, want_lse=True):
+    """q, k: [N, H, V, hd]; vt: [N, H, hd, V] -> out (out_shape = [N, ..., H*hd], the NDHWC tensor the projection conv reads), lse [N, H, V]."""
+    _contig(q, k, vt)
+    N, H, V, hd = q.shape
+    out = torch.empty(out_shape, dtype=q.dtype, device=q.device)
+    lse = torch.empty((N, H, V), dtype=torch.float32, device=q.device) if want_lse else None
+    check(_lib.lib().vdm_attn_fwd(_p(q), _p(k), _p(vt), N, V, H, hd, dt_id(q.dtype), float(scale), _p(out), _p(lse), _s()), "vdm_attn_fwd")
+    return out, lse
+
+
+def attn_bwd(q, k, v, qt, kt, dout, out, lse, scale):
+    """-> dqkv [N, ..., 3 * H*hd] (the gradient of the qkv conv's output).  dout / out: [N, ..., H*hd]."""
+    _contig(q, k, v, qt, kt, dout, out, lse)
+    N, H, V, hd = q.shape
+    L = _lib.lib()
+    doh, dot = attn_split_heads(dout, 0, 1, H)
+    dsum = torch.empty((N, H, V), dtype=torch.float32, device=q.device)
+    check(L.vdm_attn_rowdot(_p(dout), _p(out), N, V, H, hd, dt_id(q.dtype), _p(dsum), _s()), "vdm_attn_rowdot")
+    dqkv = torch.empty(tuple(dout.shape[:-1]) + (3 * H * hd,), dtype=q.dtype, device=q.device)
+    check(L.vdm_attn_bwd(_p(q), _p(k), _p(v), _p(qt), _p(kt), _p(doh), _p(dot), _p(lse), _p(dsum), N, V, H, hd, dt_id(q.dtype), float(scale),
+                         _p(dqkv), _s()), "vdm_attn_bwd")
+    return dqkv
+
+
 def softmax_rows_(scores, scale):
     """In-place row softmax of scale * scores (fp32, last dim = row)."""
     _contig(scores)

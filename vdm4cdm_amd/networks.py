@@ -70,6 +70,9 @@ class CUNet(nn.Module):
         self.n_attention_heads = int(n_attention_heads)
         self.mid_attn = bool(mid_attn)                # D13: self-attention between the two mid blocks
         assert not self.mid_attn or chs[-1] % self.n_attention_heads == 0, "chs[-1] must be divisible by n_attention_heads"
+        if backend == "hip" and self.mid_attn and chs[-1] // self.n_attention_heads not in (16, 32, 64, 96, 128):
+            raise ValueError(f"CUNet(backend='hip', mid_attn=True): head width chs[-1] / n_attention_heads = "
+                             f"{chs[-1] // self.n_attention_heads} is not built by the fused attention kernels (16, 32, 64, 96, 128)")
         self.backend = backend
         self.precision = precision            # "bf16" | "fp32": activation storage of the HIP backend
         self.taps = 3 ** self.dim

@@ -159,10 +159,9 @@ class _Res:
 
 class _Attn:
     """Self-attention between the two mid blocks (CUNet(mid_attn=True), spec D13): GroupNorm (no activation) -> 1x1x1 conv to q, k, v
-    -> softmax(q k^T / sqrt(hd)) v over all voxels of the level -> 1x1x1 projection + residual.  GroupNorm, the two projections
-    (MFMA convs), the row softmax and its backward are kernels of this library; the four batched GEMMs (Q K^T, P V and their
-    transposes) are plain library GEMMs (rocBLAS via torch.matmul), computed in fp32: the level has 16^3 voxels at 128^3 input, the
-    [N, heads, V, V] score tensor is 0.5 GB there."""
+    -> softmax(q k^T / sqrt(hd)) v over all voxels of the level -> 1x1x1 projection + residual.  Everything is a kernel of this library:
+    GroupNorm, the two projections (MFMA convs) and the fused attention core (csrc/attention.hip: scores, online softmax and P V on the
+    matrix cores, forward and backward, no [N, heads, V, V] tensor - 0.5 GB at 16^3 voxels before)."""
 
     def __init__(self, net):
         self.net = net
@@ -175,43 +174,30 @@ class _Attn:
     def convs(self):
         return [(self.qkv, "mid_attn.qkv.weight"), (self.proj, "mid_attn.proj.weight")]
 
-    def _heads(self, t):
-        """[N, V, C] -> [N, heads, V, hd] fp32 (contiguous)."""
-        N, V = t.shape[0], t.shape[1]
-        return t.reshape(N, V, self.H, self.C // self.H).permute(0, 2, 1, 3).float().contiguous()
-
     def fwd(self, P, x, save):
         G, C, H = self.net.norm_groups, self.C, self.H
-        N = x.shape[0]
-        V = x.numel() // (N * C)
         st = ops.gn_stats(x, None, G)
         xn = ops.gn_silu_fwd(x, None, G, st, P("mid_attn.norm.weight"), P("mid_attn.norm.bias"), linear=True)
-        qkv = self.qkv.fwd(xn, P("mid_attn.qkv.bias")).reshape(N, V, 3, C)
-        q, k, v = (self._heads(qkv[:, :, i]) for i in range(3))
+        qkv = self.qkv.fwd(xn, P("mid_attn.qkv.bias"))                                   # [N, d, h, w, 3C]
         scale = 1.0 / (C // H) ** 0.5
-        prob = ops.softmax_rows_(torch.matmul(q, k.transpose(-1, -2)), scale)            # [N, H, V, V] fp32
-        a = torch.matmul(prob, v).permute(0, 2, 1, 3).reshape(x.shape).to(x.dtype).contiguous()
+        q, qt = ops.attn_split_heads(qkv, 0, 3, H, transposed=save)
+        k, kt = ops.attn_split_heads(qkv, 1, 3, H, transposed=save)
+        v, vt = ops.attn_split_heads(qkv, 2, 3, H, rowmajor=save)
+        a, lse = ops.attn_fwd(q, k, vt, scale, x.shape, want_lse=save)
         out = self.proj.fwd(a, P("mid_attn.proj.bias"), None, x, gn=FUSED_GN)          # + residual; feeds mid.1's GroupNorm
         if save:
-            self.saved = (x, st, xn, q, k, v, prob, a)
+            self.saved = (x, st, xn, q, k, v, qt, kt, a, lse)
         return out
 
     def bwd(self, P, GP, dout, ss):
         G, C, H = self.net.norm_groups, self.C, self.H
-        x, st, xn, q, k, v, prob, a = self.saved
+        x, st, xn, q, k, v, qt, kt, a, lse = self.saved
         self.saved = None
-        N = x.shape[0]
-        V = x.numel() // (N * C)
         scale = 1.0 / (C // H) ** 0.5
         ss.run(lambda: self.proj.wgrad(a, dout, GP("mid_attn.proj.weight")), a, dout)
         ops.channel_sums(dout, GP("mid_attn.proj.bias"))
-        do = self._heads(self.proj.dgrad(dout).reshape(N, V, C))                          # [N, H, V, hd]
-        dv = torch.matmul(prob.transpose(-1, -2), do)
-        ds = ops.softmax_rows_bwd_(prob, torch.matmul(do, v.transpose(-1, -2)), scale)   # gradient w.r.t. q k^T
-        dq = torch.matmul(ds, k)
-        dk = torch.matmul(ds.transpose(-1, -2), q)
-        dqkv = torch.stack([t.permute(0, 2, 1, 3).reshape(N, V, C) for t in (dq, dk, dv)], dim=2)     # [N, V, 3, C]
-        dqkv = dqkv.to(x.dtype).reshape(*x.shape[:-1], 3 * C).contiguous()
+        da = self.proj.dgrad(dout)                                                       # gradient of the attention output [N, ..., C]
+        dqkv = ops.attn_bwd(q, k, v, qt, kt, da, a, lse, scale)                          # [N, ..., 3C]
         ss.run(lambda: self.qkv.wgrad(xn, dqkv, GP("mid_attn.qkv.weight")), xn, dqkv)
         ops.channel_sums(dqkv, GP("mid_attn.qkv.bias"))
         dxn = self.qkv.dgrad(dqkv)
