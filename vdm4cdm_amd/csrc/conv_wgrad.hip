@@ -374,6 +374,8 @@ static int launch_wgrad_cfg(WgradArgs w, float* dw, float* dbias, int accumulate
     }
     hipLaunchKernelGGL(kern, dim3(npairs * P), dim3(256), lds, s, w);
     VDM_LAUNCH_CHECK("conv_wgrad_kernel");
+    static const bool no_reduce = getenv("VDM4CDM_ABLATE_REDUCE") != nullptr;      // timing ablation only (wrong results)
+    if (no_reduce) return VDM_OK;
     const int total = G::TAPS * cout * cin;
     hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(cdiv(total, WRED_OUT)), dim3(256), 0, s,
                        (const float*)w.slabs, dw, G::TAPS, cout, cin, w.ncb, w.nkb, CL, P * per_wg, accumulate);
@@ -413,6 +415,8 @@ static int launch_wgrad_cls(WgradArgs w, float* dw, float* dbias, int accumulate
     }
     hipLaunchKernelGGL(kern, dim3(npairs * P), dim3(256), lds, s, w);
     VDM_LAUNCH_CHECK("conv_wgrad_kernel(class)");
+    static const bool no_reduce = getenv("VDM4CDM_ABLATE_REDUCE") != nullptr;      // timing ablation only (wrong results)
+    if (no_reduce) return VDM_OK;
     hipLaunchKernelGGL(wgrad_cls_reduce_kernel, dim3(cdiv(27 * cout * cin, 64)), dim3(256), 0, s, (const float*)w.slabs, dw, cout, cin, w.ncb,
                        w.nkb, CL, P, accumulate);
     VDM_LAUNCH_CHECK("wgrad_cls_reduce_kernel");

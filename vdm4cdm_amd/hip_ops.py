@@ -12,6 +12,9 @@ from . import _lib
 from ._lib import CondMlp, ConvDesc, GnFold, PACK_DGRAD, PACK_FWD, VDM_BF16, VDM_F32, check
 
 GN_EPS = 1e-5
+# timing ablations (tools/ablate_step.sh): kernels named here are NOT launched (wrong results - only bench.py timing runs set this)
+import os as _os
+ABLATE = set(filter(None, _os.environ.get("VDM4CDM_ABLATE", "").split(",")))
 
 
 class KernelProfiler:
@@ -187,6 +190,9 @@ class Conv:
             tiles = L.vdm_conv_gn_tiles(d)
             if tiles > 0:
                 part = torch.empty((shp[0], tiles, self.cout, 2), dtype=torch.float32, device=x.device)
+        if "conv1" in ABLATE and self.ksize == 1:
+            out.gn_partials = None
+            return out
         ev = _pb("conv3" if self.ksize == 3 else "other")
         check(L.vdm_conv_fwd(d, _p(x), _p(self.wf), _p(bias), _p(nbias), nstride, _p(residual), _p(out), _p(part), _s()), "vdm_conv_fwd")
         out.gn_partials = part
@@ -225,6 +231,8 @@ class Conv:
             out = torch.empty(ishape, dtype=dout.dtype, device=dout.device)
         assert tuple(out.shape) == ishape and (residual is None or tuple(residual.shape) == ishape)
         d = self.desc(n, od, oh, ow, dout.dtype)
+        if "conv1" in ABLATE and self.ksize == 1:
+            return out
         ev = _pb("conv3" if self.ksize == 3 else "other")
         check(L.vdm_conv_dgrad(d, _p(dout), _p(self.wd), _p(residual), _p(out), _s()), "vdm_conv_dgrad")
         if ev is not None:
@@ -299,6 +307,8 @@ class Conv:
         if ws is None or ws.numel() < need:
             ws = torch.empty(max(need, 32 << 20), dtype=torch.uint8, device=x.device)
             Conv._ws[wkey] = ws
+        if "wgrad" in ABLATE or ("wgrad1" in ABLATE and self.ksize == 1):
+            return dw
         ev = _pb("wgrad" if self.ksize == 3 else "other")
         check(L.vdm_conv_wgrad(d, _p(x), _p(dout), _p(dw), _p(dbias), 1 if accumulate else 0, _p(ws), ws.numel(), _s()), "vdm_conv_wgrad")
         if ev is not None:
@@ -356,6 +366,9 @@ def gn_silu_fwd(x1, x2, groups, stats, gamma, beta, dropout_p=0.0, seed=0, out=N
     mask = None
     if want_mask and dropout_p > 0.0:
         mask = torch.empty((n, v, (c1 + c2) // epl(x1.dtype)), dtype=torch.uint8, device=x1.device)
+    if "gn_fwd" in ABLATE:
+        out.keep_mask = mask
+        return out
     ev = _pb()
     check(L.vdm_gn_silu_fwd(_p(x1), c1, _p(x2), c2, n, v, groups, dt_id(x1.dtype), _p(stats), _p(gamma), _p(beta), GN_EPS,
                             float(dropout_p), int(seed), _p(out), _p(mask), int(bool(linear)), _s()), "vdm_gn_silu_fwd")
@@ -418,7 +431,8 @@ def gn_bwd_fused(x1, x2, groups, stats, gamma, dyh, dgamma, dbeta, add1=None, ad
     ev = _pb()
     check(L.vdm_gn_bwd_finalize(_p(part), part.shape[1], n, C_, groups, v, _p(stats), _p(gamma), GN_EPS, _p(chsum), _p(red), _p(chan),
                                 _p(colsum), cstride, _s()), "vdm_gn_bwd_finalize")
-    check(L.vdm_gn_bwd_apply(_p(x1), c1, _p(x2), c2, n, v, groups, dt_id(x1.dtype), _p(stats), _p(gamma), GN_EPS, _p(dyh), _p(red), _p(chan),
+    if "gn_apply" not in ABLATE:
+      check(L.vdm_gn_bwd_apply(_p(x1), c1, _p(x2), c2, n, v, groups, dt_id(x1.dtype), _p(stats), _p(gamma), GN_EPS, _p(dyh), _p(red), _p(chan),
                              _p(add1), _p(add2), _p(dx1), _p(dx2), _p(dgamma), _p(dbeta), _s()), "vdm_gn_bwd_apply")
     _pe(ev, "gn_bwd(finalize+apply)", 0.0, (3.0 + (1.0 if add1 is not None else 0.0)) * dyh.numel() * dyh.element_size())
     return dx1, dx2
@@ -707,4 +721,7 @@ class PackPlan:
         self.dtype = dtype
 
     def run(self):
+        if "pack" in ABLATE and getattr(self, "_ran", False):
+            return
+        self._ran = True
         check(_lib.lib().vdm_conv_pack_many(_p(self.items), _p(self.chunks), self.nchunks, dt_id(self.dtype), _s()), "vdm_conv_pack_many")
