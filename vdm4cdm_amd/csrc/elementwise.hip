@@ -144,14 +144,13 @@ __global__ void __launch_bounds__(256) gn_stats_finalize_kernel(const float* __r
 // (S = the largest multiple of gs <= 256) owns channel t % gs and takes the tiles t / gs, t / gs + S / gs, ...; the S partial
 // sums are folded per channel and then over the channels in a fixed order (deterministic).  chsum (optional): the per-channel
 // sums chsum[n][c0 + c] = sum_v x[n][v][c] (the analytic column sums of the GroupNorm backward need them).
-template <int NT>
-__global__ void __launch_bounds__(NT) gn_stats_from_partials_kernel(const float* __restrict__ part, int tiles, int C, int gs, int G,
-                                                                    int g0, float* __restrict__ stats, float* __restrict__ chsum,
-                                                                    int chsum_stride, int c0) {
+__global__ void __launch_bounds__(256) gn_stats_from_partials_kernel(const float* __restrict__ part, int tiles, int C, int gs, int G,
+                                                                     int g0, float* __restrict__ stats, float* __restrict__ chsum,
+                                                                     int chsum_stride, int c0) {
     const int gc = C / gs;
     const int n = blockIdx.x / gc, g = blockIdx.x % gc;
     const float2* p2 = reinterpret_cast<const float2*>(part) + (size_t)n * tiles * C + (size_t)g * gs;
-    const int per = NT / gs, S = per * gs;                  // tiles in flight per sweep, active threads
+    const int per = 256 / gs, S = per * gs;                 // tiles in flight per sweep, active threads
     const int t = threadIdx.x, c = t % gs, b0 = t / gs;
     float s0 = 0.f, s1 = 0.f;
     if (t < S) {
@@ -167,7 +166,7 @@ __global__ void __launch_bounds__(NT) gn_stats_from_partials_kernel(const float*
             for (int u = 0; u < U; ++u) { s0 += v[u].x; s1 += v[u].y; }
         }
     }
-    __shared__ float sm[2][NT];
+    __shared__ float sm[2][256];
     sm[0][t] = s0; sm[1][t] = s1;
     __syncthreads();
     if (t < gs) {                                           // per-channel totals, fixed order
@@ -337,8 +336,7 @@ __device__ __forceinline__ bool pc_is_first(const GnArgs& a, int epl, int bid, i
 // apply: dx = rstd * (gamma * dyh - m1 - xhat * m2) (+ add), m = red / cnt; block 0 also writes dgamma / dbeta = sum_n chan.
 // No float atomics anywhere: the backward pass is bit-reproducible.
 // ---------------------------------------------------------------------------------------------
-template <int NT>
-__global__ void __launch_bounds__(NT) gn_bwd_finalize_kernel(const float* __restrict__ part, int tiles, int C, int gs, int64_t V,
+__global__ void __launch_bounds__(256) gn_bwd_finalize_kernel(const float* __restrict__ part, int tiles, int C, int gs, int64_t V,
                                                               const float* __restrict__ stats, const float* __restrict__ gamma,
                                                               float eps, const float* __restrict__ chsum, float* __restrict__ red,
                                                               float* __restrict__ chan, float* __restrict__ colsum,
@@ -346,7 +344,7 @@ __global__ void __launch_bounds__(NT) gn_bwd_finalize_kernel(const float* __rest
     const int G = C / gs;
     const int n = blockIdx.x / G, g = blockIdx.x % G;
     const float2* p2 = reinterpret_cast<const float2*>(part) + (size_t)n * tiles * C + (size_t)g * gs;
-    const int per = NT / gs, S = per * gs;
+    const int per = 256 / gs, S = per * gs;
     const int t = threadIdx.x, c = t % gs, b0 = t / gs;
     float s0 = 0.f, s1 = 0.f;
     if (t < S) {
@@ -362,7 +360,7 @@ __global__ void __launch_bounds__(NT) gn_bwd_finalize_kernel(const float* __rest
             for (int u = 0; u < U; ++u) { s0 += v[u].x; s1 += v[u].y; }
         }
     }
-    __shared__ float sm[2][NT];
+    __shared__ float sm[2][256];
     __shared__ float gr[2];
     sm[0][t] = s0; sm[1][t] = s1;
     __syncthreads();
@@ -809,14 +807,8 @@ extern "C" int vdm_gn_stats(const void* x1, int c1, const void* x2, int c2, int 
     for (int k = 0; k < 2; ++k) {
         if (cs[k] == 0) continue;
         if (parts[k]) {                                   // statistics already reduced per tile by the producing conv
-            // one block per (sample, group): with thousands of tiles (level 0) a 1024-thread block keeps 4x the loads in flight - the
-            // kernel is pure latency (10 -> 4 us at 4096 tiles); the per-channel fold then walks 1024 / gs LDS entries per thread
-            if (tiles[k] >= 1024 && gs <= 64)
-                hipLaunchKernelGGL(gn_stats_from_partials_kernel<1024>, dim3(n * (cs[k] / gs)), dim3(1024), 0, s, parts[k], tiles[k], cs[k], gs, groups,
-                                   g0, stats, chsum, c1 + c2, g0 * gs);
-            else
-                hipLaunchKernelGGL(gn_stats_from_partials_kernel<256>, dim3(n * (cs[k] / gs)), dim3(256), 0, s, parts[k], tiles[k], cs[k], gs, groups, g0,
-                                   stats, chsum, c1 + c2, g0 * gs);
+            hipLaunchKernelGGL(gn_stats_from_partials_kernel, dim3(n * (cs[k] / gs)), dim3(256), 0, s, parts[k], tiles[k], cs[k], gs, groups, g0, stats,
+                               chsum, c1 + c2, g0 * gs);
             VDM_LAUNCH_CHECK("gn_stats_from_partials_kernel");
             g0 += cs[k] / gs;
             continue;
@@ -891,12 +883,8 @@ extern "C" int vdm_gn_bwd_finalize(const float* partials, int tiles, int n, int 
     VDM_REQUIRE(tiles > 0 && n > 0 && groups > 0 && c > 0 && c % groups == 0 && voxels > 0, "gn_bwd_finalize: bad sizes");
     VDM_REQUIRE(c / groups <= 256, "gn_bwd_finalize: more than 256 channels per group");
     VDM_REQUIRE(!colsum || chsum, "gn_bwd_finalize: the analytic column sums need the per-channel sums of the GroupNorm input");
-    if (tiles >= 1024 && c / groups <= 64)                  // (level 0: thousands of tile partials per group - more loads in flight, see gn_stats)
-        hipLaunchKernelGGL(gn_bwd_finalize_kernel<1024>, dim3(n * groups), dim3(1024), 0, (hipStream_t)stream, partials, tiles, c, c / groups, voxels,
-                           stats, gamma, eps, chsum, red, chan, colsum, (long long)colsum_stride);
-    else
-        hipLaunchKernelGGL(gn_bwd_finalize_kernel<256>, dim3(n * groups), dim3(256), 0, (hipStream_t)stream, partials, tiles, c, c / groups, voxels,
-                           stats, gamma, eps, chsum, red, chan, colsum, (long long)colsum_stride);
+    hipLaunchKernelGGL(gn_bwd_finalize_kernel, dim3(n * groups), dim3(256), 0, (hipStream_t)stream, partials, tiles, c, c / groups, voxels,
+                       stats, gamma, eps, chsum, red, chan, colsum, (long long)colsum_stride);
     VDM_LAUNCH_CHECK("gn_bwd_finalize_kernel");
     return VDM_OK;
 }
