@@ -3,7 +3,7 @@
 (make -C vdm4cdm_amd/csrc timeline -> libvdm4cdm_hip_timeline.so; never used by the product) and prints, per phase, the
 distribution of durations over workgroups plus per-CU occupancy of the phases.
 
-    VDM4CDM_LIB=vdm4cdm_amd/libvdm4cdm_hip_timeline.so python tools/conv_timeline.py [--shape L0_32_32] [--op fwd|dgrad] [--n 2]
+    VDM4CDM_LIB=vdm4cdm_amd/libvdm4cdm_hip_timeline.so python tools/conv_timeline.py [--shape L0_32_32] [--op fwd|dgrad|dgrad_gn] [--n 2]
 
 Stamps (s_memrealtime, 100 MHz, per wave): 0 kernel entry, 5 index decode done, 6 staging DMA issued, 1 first weights issued, 2 staging barrier passed (data
 landed), 3 tap loop done, 4 epilogue stores retired.  Read the SHARES, not the kernel's length (the stamps fence the schedule).
@@ -37,7 +37,13 @@ def main():
     conv.pack(torch.randn(27, cout, cin, device=dev) * 0.05, dt, need_dgrad=True)
     x = torch.randn(args.n, D, D, D, cin, device=dev).to(dt)
     dout = torch.randn(args.n, D, D, D, cout, device=dev).to(dt)
-    fn = (lambda: conv.fwd(x, gn=True)) if args.op == "fwd" else (lambda: conv.dgrad(dout))
+    if args.op == "dgrad_gn":                                # dgrad with the folded GroupNorm backward (dropout keep mask on)
+        st = ops.gn_stats(x, None, 8)
+        gam, bet = torch.ones(cin, device=dev), torch.zeros(cin, device=dev)
+        mask = torch.full((args.n, D * D * D, cin // 8), 0xFF, dtype=torch.uint8, device=dev)
+        fn = lambda: conv.dgrad_gn(dout, x, None, 8, st, gam, bet, keep_mask=mask, dropout_p=0.1)
+    else:
+        fn = (lambda: conv.fwd(x, gn=True)) if args.op == "fwd" else (lambda: conv.dgrad(dout))
     for _ in range(5):
         fn()
     torch.cuda.synchronize()
