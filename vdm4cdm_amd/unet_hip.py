@@ -49,6 +49,33 @@ class SideStream:
             torch.cuda.current_stream().wait_stream(self.side)
 
 
+class DeferredSide:
+    """A SideStream whose run() only RECORDS the launch: the weight-gradient kernels of the level-0 up path are not started while the
+    main stream is in its own level-0 kernels (every one of them fills the chip alone: co-running them is time-slicing, the folded
+    dgrad convs there ran 1.7-2.5x longer than alone) but flushed onto the side stream when the main stream moves on to the deeper
+    levels, whose small grids leave most CUs idle.  second / join / enabled are the real stream's (the skip-path input gradients feed
+    the main chain and are never deferred)."""
+
+    def __init__(self, ss):
+        self.ss, self.pending = ss, []
+        self.enabled, self.second, self.side = ss.enabled, ss.second, ss.side
+
+    def run(self, fn, *tensors):
+        self.pending.append((fn, tensors))
+
+    def join(self):
+        self.ss.join()
+
+    def flush(self):
+        for fn, tensors in self.pending:
+            self.ss.run(fn, *tensors)
+        self.pending = []
+
+
+# weight gradients of the up path's first N levels are deferred until the main stream starts the next level (0: launch immediately)
+DEFER_WGRAD_LEVELS = int(os.environ.get("VDM4CDM_DEFER_WGRAD_LEVELS", "1"))
+
+
 class _Res:
     """ResNetBlock (D4) on HIP kernels; input may be two tensors (skip concat, never materialised)."""
 
@@ -114,7 +141,7 @@ class _Res:
                 skip_grads.append(self.skip2.dgrad(dout) if self.skip2 is not None else None)
             ss.second.run(side_skip_dgrad, dout)
 
-        def side_conv2():                      # conv2 (+ the 1x1 skip convs share dout)
+        def side_conv2(a2=a2, dout=dout, x1=x1, x2=x2):      # conv2 (+ the 1x1 skip convs share dout); tensors bound now: may run deferred
             self.conv2.wgrad(a2, dout, GP(n + ".conv2.weight"), GP(n + ".conv2.bias"))      # bias grad fused (column sums of dout)
             if self.skip1 is not None:
                 self.skip1.wgrad(x1, dout, GP(n + ".skip.weight"))
@@ -133,7 +160,7 @@ class _Res:
                                     GP(n + ".norm2.weight"), GP(n + ".norm2.bias"), colsum=tcols, dropout_p=p, seed=seed, dx1=da2)
         del a2
         # conv1
-        ss.run(lambda: self.conv1.wgrad(a1, dh, GP(n + ".conv1.weight")), a1, dh)
+        ss.run(lambda a1=a1, dh=dh: self.conv1.wgrad(a1, dh, GP(n + ".conv1.weight")), a1, dh)
         if fused:
             dyh1 = self.conv1.dgrad_gn(dh, x1, x2, G, st1, P(n + ".norm1.weight"), P(n + ".norm1.bias"))
         else:
@@ -365,8 +392,10 @@ class HipUNet:
 
         ss = self._side_stream(flat.device)
         ss.run(lambda: None, gflat)                   # (orders the side stream after the zero-fill of gflat)
+        defer = DeferredSide(ss) if (DEFER_WGRAD_LEVELS > 0 and ss.enabled and L > 1) else None
+        ss0 = defer if defer is not None else ss      # stream of the level-0 tail (conv_out) and up block
         dpad = ops.pack_input(d_eps.contiguous(), None, dtype)
-        ss.run(lambda: self.conv_out.wgrad(a, dpad, GP("conv_out.weight")), a, dpad)
+        ss0.run(lambda a=a, dpad=dpad: self.conv_out.wgrad(a, dpad, GP("conv_out.weight")), a, dpad)
         GP("conv_out.bias").copy_(d_eps.sum().reshape(1))
         if FUSED_GNB and self.conv_out.gn_fold_ok(net.chs[0], 0, dtype):
             dyh = self.conv_out.dgrad_gn(dpad, h_last, None, net.norm_groups, st, P("norm_out.weight"), P("norm_out.bias"))
@@ -377,10 +406,13 @@ class HipUNet:
                                     GP("norm_out.weight"), GP("norm_out.bias"), dx1=da)
         dskips = [None] * (L - 1)
         for i in range(L - 1):
-            du, dskips[i] = self.res[f"ups.{i}.block"].bwd(P, GP, dh, dtable, ss)
-            ss.run(lambda i=i, du=du: self.up[i].wgrad(coarse[i], du, GP(f"ups.{i}.up.weight"), GP(f"ups.{i}.up.bias")), coarse[i], du)
+            ssi = defer if (defer is not None and i < DEFER_WGRAD_LEVELS) else ss
+            du, dskips[i] = self.res[f"ups.{i}.block"].bwd(P, GP, dh, dtable, ssi)
+            ssi.run(lambda i=i, du=du: self.up[i].wgrad(coarse[i], du, GP(f"ups.{i}.up.weight"), GP(f"ups.{i}.up.bias")), coarse[i], du)
             dh = self.up[i].dgrad(du)              # gradient w.r.t. the coarse source (per-parity-class conv, no pooling pass)
             del du
+            if defer is not None and i == min(DEFER_WGRAD_LEVELS, L - 1) - 1:
+                defer.flush()                      # the main stream is entering the deeper levels: the held-back weight gradients start now
         self._bucket_ready(gflat, "ups", ss)       # norm_out / conv_out / every up block and up conv: final (RCCL starts on them)
         for j in reversed(range(2)):
             dh, _ = self.res[f"mid.{j}"].bwd(P, GP, dh, dtable, ss)
