@@ -22,8 +22,10 @@ def main():
     vdm = LightVDM(score_model=net, gamma_min=-13.3, gamma_max=13.3, noise_schedule="learned_linear")
     dm = SyntheticAstroDataModule(cropsize=16, batch_size=2, dim=2, conditioning=False, n_params=0, n_train=8,
                                   return_func=lambda f, p: {"x": f[1], "conditioning": None, "conditioning_values": None})
-    tr = Trainer(max_steps=2, val_check_interval=0, gradient_clip_val=0.5, every_n_train_steps=2, default_root_dir=out_dir,
-                 experiment_name="ddp", device="cpu", enable_progress=False, log_every_n_steps=1)
+    max_steps = int(os.environ.get("DDP_MAX_STEPS", "2"))
+    tr = Trainer(max_steps=max_steps, val_check_interval=int(os.environ.get("DDP_VAL_EVERY", "0")), gradient_clip_val=0.5,
+                 every_n_train_steps=max_steps, default_root_dir=out_dir, experiment_name="ddp", device="cpu", enable_progress=False,
+                 log_every_n_steps=1, limit_val_batches=2)
     tr.fit(vdm, dm)
     torch.save({"flat": net.flat.detach().clone(), "gamma_w": vdm.model.gamma_w.detach().clone(), "steps": tr.global_step,
                 "history": tr.history}, os.path.join(out_dir, f"rank{rank}.pt"))

@@ -34,6 +34,25 @@ def test_trainer_ddp_gloo_world2(tmp_path):
     assert a["history"][0]["loss"] != b["history"][0]["loss"]
 
 
+def test_trainer_ddp_gloo_world3_epoch_boundaries_and_validation(tmp_path):
+    """World 3 with a data set that does not divide (8 items, batch 2): 5 steps cross several epoch boundaries and two validation passes
+    (sharded split, all-reduced loss, barrier after rank 0's part).  Every rank must take exactly the same number of steps, log the same
+    validation loss and end with bit-identical parameters - a rank that ran one batch more or less per epoch would hang or diverge."""
+    env = dict(os.environ, OMP_NUM_THREADS="2", DDP_MAX_STEPS="5", DDP_VAL_EVERY="2")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "3", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(ROOT, "tests", "_ddp_worker.py"), str(tmp_path)]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    outs = [torch.load(tmp_path / f"rank{k}.pt") for k in range(3)]
+    assert [o["steps"] for o in outs] == [5, 5, 5]
+    for o in outs[1:]:
+        assert torch.equal(o["flat"], outs[0]["flat"]) and torch.equal(o["gamma_w"], outs[0]["gamma_w"]), "ranks diverged"
+    vals = [[h["val_loss"] for h in o["history"] if "val_loss" in h] for o in outs]
+    assert len(vals[0]) == 2 and vals[0] == vals[1] == vals[2], f"validation loss not shared by the ranks: {vals}"
+    train = [[h["loss"] for h in o["history"] if "loss" in h] for o in outs]
+    assert all(len(t) == 5 for t in train) and train[0] != train[1], "every rank logs 5 steps on its own shard"
+
+
 def test_single_process_matches_itself(tmp_path):
     """Sanity: the same worker without torchrun (world 1) runs and is deterministic."""
     outs = []
