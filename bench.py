@@ -145,6 +145,9 @@ def main():
                     help="HIP events around EVERY kernel launch (full per-kernel table; ~600 event pairs per step cost ~6 %% of the step)."
                          " Default: only the 3^3 conv fwd/dgrad launches, the candidates for the dominant kernel (~50 per step)")
     ap.add_argument("--per-step", action="store_true", help="diagnostic: synchronise after every timed step and print its duration to stderr")
+    ap.add_argument("--graph", action="store_true",
+                    help="after the eager timed region (N = 1), also time the same step as ONE hipGraph replay (trainer.GraphedTrainStep), reported "
+                         "under \"graph_step\": faster where the host is the limiter (32^3: 1.9 vs 5.2 ms), slower at the BASELINE sizes (128^3: 15.0 vs 14.7 ms)")
     ap.add_argument("--sample-only", action="store_true",
                     help="skip the training steps: only the --sample-steps reverse-diffusion sample is timed (e.g. --config c256 "
                          "--sample-steps 250, the configuration of the reference's one published rate)")
@@ -176,7 +179,7 @@ def main():
     if world > 1:
         for p in params:
             dist.broadcast(p.data, src=0)
-    opt = vdm.configure_optimizers()
+    opt = vdm.configure_optimizers(capturable=(world == 1 and args.graph))
     batch = make_batch(D, B, rank, device)
     vdm.train()
     net.enable_ddp(world)            # N > 1: the backward all-reduces the flat gradient in 4 buckets, overlapped with its own tail
@@ -221,6 +224,8 @@ def main():
             per_step.append(time.perf_counter())
             print("per-step ms:", " ".join(f"{1e3 * (b - a):.2f}" for a, b in zip(per_step, per_step[1:])), file=sys.stderr, flush=True)
         hip_ops.PROFILER = None
+        loss = float(loss.detach())          # (drop the autograd graph of the last eager step: a live AccumulateGrad node bound to the
+                                             # default stream would be run inside the stream capture of the graphed step below)
         el = torch.tensor([elapsed], device=device, dtype=torch.float64)
         if world > 1:
             dist.all_reduce(el, op=dist.ReduceOp.MAX)
@@ -237,7 +242,7 @@ def main():
             "config": {"workload": f"{args.config}: {D}^3 conditional VDM (trainVDM3D128_c_c thick_lowbatch), chs {chs}, "
                                    f"batch {B}/GPU, full training step (diffuse + UNet fwd + ELBO + UNet bwd + clip + AdamW), dropout 0.1",
                        "global_batch": world * B, "cube": D, "parallelism": f"dp{world}"},
-            "loss": None if loss is None else float(loss),
+            "loss": loss,
         }
         roof = {}
         if prof is not None:
@@ -296,6 +301,26 @@ def main():
             roof["step_algorithmic_GB"] = alg_bytes / 1e9
             roof["step_algorithmic_TFLOP"] = alg_flops / 1e12
         out["roofline"] = roof
+        if world == 1 and args.graph and not args.sample_only:
+            # the same step as ONE hipGraph replay (trainer.GraphedTrainStep: what Trainer.fit runs at N = 1): K timed replays after W warm-up
+            # replays.  `value` above stays the eager run - its kernels carry the per-launch events of the roofline object.
+            try:
+                from vdm4cdm_amd.trainer import GraphedTrainStep
+                gs = GraphedTrainStep(vdm, opt, params, 0.5, batch)
+                for _ in range(max(args.warmup, 2)):
+                    gs(batch)
+                torch.cuda.synchronize()
+                tg = time.perf_counter()
+                for _ in range(args.steps):
+                    gl = gs(batch)
+                torch.cuda.synchronize()
+                tg = time.perf_counter() - tg
+                out["graph_step"] = {"ms_per_step": 1e3 * tg / args.steps, "value": B * D ** 3 * args.steps / tg, "unit": "voxels/s", "steps": args.steps,
+                                     "loss": float(gl), "note": "whole training step captured once in a hipGraph and replayed (Trainer.fit at N = 1)"}
+                hip_ops.SEED_STEP = None
+            except Exception as e:                          # never lose the eager line over the extra measurement
+                out["graph_step"] = {"error": repr(e)}
+                hip_ops.SEED_STEP = None
         if args.sample_steps:
             try:
                 vdm.eval()

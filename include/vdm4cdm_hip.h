@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define VDM_ABI_VERSION 7
+#define VDM_ABI_VERSION 8
 
 typedef enum { VDM_OK = 0, VDM_ERR_ARG = -1, VDM_ERR_HIP = -2, VDM_ERR_UNSUPPORTED = -3 } vdm_status;
 typedef enum { VDM_F32 = 0, VDM_BF16 = 1 } vdm_dtype;
@@ -149,17 +149,20 @@ int vdm_gn_stats(const void* x1, int c1, const void* x2, int c2, int n, int64_t 
 /* y[n][v][c1+c2] = dropout(silu(gn(concat(x1,x2)))) ; keep-mask from Philox(seed, element index).
  * linear != 0: no activation - the plain GroupNorm in front of the attention block's qkv projection (mid_attn=True).
  * keep_mask (may be NULL): with dropout_p > 0 the keep bits are also written, one byte per 16-byte piece of y
- * ([n][voxels][(c1+c2) / (4 fp32 | 8 bf16)], bit j = channel j of the piece), for vdm_conv_dgrad_gn. */
+ * ([n][voxels][(c1+c2) / (4 fp32 | 8 bf16)], bit j = channel j of the piece), for vdm_conv_dgrad_gn.
+ * seed_step (may be NULL; also vdm_gn_dyh, vdm_randn, vdm_train_scalars): DEVICE step counter mixed into the seed inside the kernel
+ * (seed + *seed_step * 0x9E3779B97F4A7C15) - a hipGraph of the training step bakes the host seed into its kernel arguments; the
+ * counter, bumped once per replay (vdm_step_inc), keeps dropout masks, noise fields and the time grid fresh. */
 int vdm_gn_silu_fwd(const void* x1, int c1, const void* x2, int c2, int n, int64_t voxels, int groups,
                     int dtype, const float* stats, const float* gamma, const float* beta, float eps,
-                    float dropout_p, uint64_t seed, void* y, uint8_t* keep_mask, int linear, void* stream);
+                    float dropout_p, uint64_t seed, void* y, uint8_t* keep_mask, int linear, const int32_t* seed_step, void* stream);
 /* Backward of the above for a GroupNorm whose gradient did not come out of vdm_conv_dgrad_gn, first of three steps:
  * dyh = dy * keep/(1-p) * silu'(yhat) (linear != 0: dyh = dy); dyh may alias dy.  Then vdm_channel_dot_sums(dyh, x) gives the
  * per-sample (sum dyh, sum dyh * x) = the one-tile-per-sample `partials` of vdm_gn_bwd_finalize, and vdm_gn_bwd_apply writes dx:
  * the same fixed-order (bit-reproducible) arithmetic as the folded path; no float atomics. */
 int vdm_gn_dyh(const void* x1, int c1, const void* x2, int c2, int n, int64_t voxels, int groups, int dtype, const float* stats,
                const float* gamma, const float* beta, float eps, float dropout_p, uint64_t seed, const void* dy, void* dyh, int linear,
-               void* stream);
+               const int32_t* seed_step, void* stream);
 
 /* Second half of the GroupNorm backward after vdm_conv_dgrad_gn (all in fixed summation order: bit-reproducible).
  * finalize: chan[n][c][2] = sum over tiles of the partials; red[n][g][2] = sum_c gamma_c chan[n][c];
@@ -267,12 +270,13 @@ int vdm_channel_dot_sums(const void* a, const void* b1, int c1, const void* b2, 
 /* ---- scalar glue of the training step [R7, R11; D9-D11] (replaces ~60 five-microsecond ATen launches on the critical path) --------
  * train_scalars: out[5][batch] = {t, alpha_t, sigma_t, coef = gamma'(t) bpd / batch, t_norm} of the fixed linear schedule; with u0
  *   (DEVICE pointer to one uniform draw) t_i = (u0 + (rank batch + i) / (world batch)) mod 1 - the antithetic time grid stratified over
- *   the global batch - else t_i = times[i].  [REF trainVDM3D128...py:128-132 -> LightVDM.training_step; NB vdm_model.py:320-324]
+ *   the global batch - else t_i = times[i]; with neither, u0 is drawn in the kernel from Philox(seed, *seed_step) (same on every rank).
+ *   [REF trainVDM3D128...py:128-132 -> LightVDM.training_step; NB vdm_model.py:320-324]
  * elbo_assemble: out[4] = {elbo, diffusion, latent, reconstruction} in bits/dim from the sums of vdm_loss_terms:
  *   diffusion = 0.5 sum_n coef_n S0_n, latent = mean_n (c_lat0 + c_lat1 S1_n), reconstruction = mean_n (c_rec0 S2_n + c_rec1).
  * clip_scale: x *= min(1, max_norm / (sqrt(*sumsq) + 1e-6)) - gradient_clip_val [REF trainVDM3D128...py:45] on the device. */
 int vdm_train_scalars(const float* u0, const float* times, int batch, int rank, int world, float gamma_min, float gamma_max,
-                      float bpd_over_batch, float* out, void* stream);
+                      float bpd_over_batch, float* out, uint64_t seed, const int32_t* seed_step, void* stream);
 int vdm_elbo_assemble(const float* sums, const float* coef, int batch, float c_lat0, float c_lat1, float c_rec0, float c_rec1,
                       float* out, void* stream);
 int vdm_clip_scale(float* x, int64_t n, const float* sumsq, float max_norm, void* stream);
@@ -289,7 +293,7 @@ int vdm_ancestral_step(float* z, const float* eps_hat, const float* noise, const
 int vdm_ancestral_step_cfg(float* z, const float* eps_cond, const float* eps_uncond, float w_cfg, const float* noise,
                            const float* coef, const int32_t* step_ptr, uint64_t seed, int64_t n, void* stream);
 /* standard-normal fill from Philox(seed, stream_id) (z_1 of the sampler; eps in training). */
-int vdm_randn(float* out, int64_t n, uint64_t seed, uint64_t stream_id, void* stream);
+int vdm_randn(float* out, int64_t n, uint64_t seed, uint64_t stream_id, const int32_t* seed_step, void* stream);
 /* *step_ptr += 1 (device-side step counter for the captured sampler graph). */
 int vdm_step_inc(int32_t* step_ptr, void* stream);
 

@@ -94,7 +94,7 @@ assert L.vdm_conv_dgrad_gn(d, 1, 1, 1, C.byref(f), None) == -1                  
 assert L.vdm_conv_dgrad_gn(desc(stride=2), 1, 1, 1, C.byref(f), None) == -1
 assert L.vdm_gn_stats(None, 32, None, 0, 2, 4096, 8, 1, None, None, None, 0, None, 0, None, None) == -1
 assert L.vdm_gn_stats(1, 30, None, 0, 2, 4096, 8, 1, 1, 1, None, 0, None, 0, None, None) == -1      # channels not a multiple of a piece
-assert L.vdm_gn_silu_fwd(1, 32, None, 0, 2, 4096, 8, 1, 1, 1, 1, 1e-5, 1.5, 0, 1, None, 0, None) == -1   # dropout_p out of range
+assert L.vdm_gn_silu_fwd(1, 32, None, 0, 2, 4096, 8, 1, 1, 1, 1, 1e-5, 1.5, 0, 1, None, 0, None, None) == -1   # dropout_p out of range
 assert L.vdm_gn_bwd_finalize(1, 0, 2, 32, 8, 4096, 1, 1, 1e-5, None, 1, 1, None, 0, None) == -1
 assert L.vdm_gn_bwd_finalize(1, 4, 2, 32, 8, 4096, 1, 1, 1e-5, None, 1, 1, 1, 32, None) == -1            # colsum without chsum
 assert L.vdm_pack_input(None, None, 10, 8, 1, None, None) == -1

@@ -754,6 +754,83 @@ def test_return_all_runs_the_captured_graph():
     assert torch.equal(a, b) and torch.isfinite(a).all()
 
 
+def test_graphed_training_step_matches_eager_and_trains():
+    """trainer.GraphedTrainStep (the whole training step as one hipGraph replay): (a) a captured fwd+bwd, replayed,
+    gives bit-identical loss and parameter gradients to the eager step with the same host seeds and device step counter (dropout on, side
+    streams, deferred weight gradients - everything that is scheduled differently under capture); (b) replays draw fresh noise (the device
+    counter is mixed into the seeds inside the kernels) but the sequence is reproducible; (c) 40 replays with AdamW fit a fixed batch."""
+    import vdm4cdm_amd.unet_hip as uh
+    from vdm4cdm_amd import hip_ops as ops
+    from vdm4cdm_amd import vdm_model as vm
+    from vdm4cdm_amd.trainer import GraphedTrainStep
+    try:
+        net = make_net(D=32, chs=(16, 32, 64), precision="bf16", dropout=0.1, seed=8)
+        vdm = make_vdm(net).to(DEV).train()
+        x, t, sc, v = inputs(net, 2, seed=5)
+        batch = {"x": x.to(DEV), "conditioning": sc.to(DEV), "conditioning_values": [a.to(DEV) for a in v]}
+        counter = torch.zeros(1, dtype=torch.int32, device=DEV)
+        ops.SEED_STEP = counter
+
+        def fb():
+            loss = vdm.training_step(batch, 0)
+            net.flat.grad = None
+            loss.backward()
+            return loss
+
+        def reseed():
+            torch.manual_seed(5)
+            uh._seed_counter[0] = 0
+            vm.reset_train_generators()
+            vdm.model._graph_seed = 1234
+            counter.fill_(7)
+
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            fb()
+            reseed()
+            le = fb()
+            ge = net.flat.grad.clone()
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        reseed()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            lg = fb()
+        g.replay()
+        torch.cuda.synchronize()
+        assert torch.isfinite(ge).all() and torch.equal(le, lg), (le.item(), lg.item())
+        diff = [n for n in net.spec.items if not torch.equal(net.view(n, ge), net.view(n, net.flat.grad))]
+        assert not diff, f"captured step differs from the eager step in {len(diff)} gradient tensors: {diff[:8]}"
+        counter.fill_(8)                                        # another step index: other dropout masks / noise / time grid
+        g.replay()
+        torch.cuda.synchronize()
+        assert not torch.equal(lg, le) and torch.isfinite(net.flat.grad).all()
+        del g
+        # (c) the full step: clip + capturable fused AdamW + weight re-packing inside the graph
+        ops.SEED_STEP = None
+        net2 = make_net(D=16, chs=(16, 32), precision="fp32", seed=21).to(DEV)
+        vdm2 = vm.LightVDM(score_model=net2, gamma_max=13.3, learning_rate=3e-3).to(DEV).train()
+        opt = vdm2.configure_optimizers(capturable=True)
+        x, t, sc, v = inputs(net2, 4, seed=5)
+        b2 = {"x": x.to(DEV), "conditioning": sc.to(DEV), "conditioning_values": [a.to(DEV) for a in v]}
+        gs = GraphedTrainStep(vdm2, opt, [p for p in vdm2.parameters() if p.requires_grad], 0.5, b2)
+        losses = []
+        for _ in range(60):
+            losses.append(gs(b2).detach().clone())
+        losses = [float(l) for l in losses]
+        assert all(math.isfinite(l) for l in losses) and len(set(losses)) > 50, "replays do not draw fresh noise"
+        assert sum(losses[-10:]) < 0.8 * sum(losses[:10]), f"graph-replayed training does not fit the batch: {losses[:3]} ... {losses[-3:]}"
+        assert gs.counter.item() == 63                          # 3 eager warm-up steps + 60 replays bumped the device counter
+        vdm2.eval()                                             # the packed weights follow the in-graph optimizer steps
+        with torch.no_grad():
+            out = hip_forward(net2, x, t, sc, v)
+        ref = oracle_forward(net2, x, t, sc, v)
+        assert (out.cpu() - ref).abs().max().item() <= 2e-4 * max(ref.abs().max().item(), 1e-3) + 1e-5
+    finally:
+        ops.SEED_STEP = None
+
+
 def test_dropout_follows_module_mode_not_autograd():
     """The dropout probability follows net.training (nn.Dropout semantics of the reference stack); whether autograd records only
     decides if activations are saved.  eval + grad enabled: no dropout, deterministic, equal to the no_grad result, and the

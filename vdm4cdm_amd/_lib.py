@@ -64,7 +64,7 @@ class AugmentSample(C.Structure):
 PACK_CHUNK = 16384                   # VDM_PACK_CHUNK
 _p, _i, _i64, _u64, _f, _sz = C.c_void_p, C.c_int, C.c_int64, C.c_uint64, C.c_float, C.c_size_t
 _D = C.POINTER(ConvDesc)
-ABI_VERSION = 7                      # VDM_ABI_VERSION of include/vdm4cdm_hip.h this binding was written for
+ABI_VERSION = 8                      # VDM_ABI_VERSION of include/vdm4cdm_hip.h this binding was written for
 
 # name -> (restype, argtypes); mirrors include/vdm4cdm_hip.h one to one
 SIGNATURES = {
@@ -84,8 +84,8 @@ SIGNATURES = {
     "vdm_conv_wgrad_workspace_bytes": (_sz, [_D]),
     "vdm_conv_wgrad": (_i, [_D, _p, _p, _p, _p, _i, _p, _sz, _p]),
     "vdm_gn_stats": (_i, [_p, _i, _p, _i, _i, _i64, _i, _i, _p, _p, _p, _i, _p, _i, _p, _p]),
-    "vdm_gn_silu_fwd": (_i, [_p, _i, _p, _i, _i, _i64, _i, _i, _p, _p, _p, _f, _f, _u64, _p, _p, _i, _p]),
-    "vdm_gn_dyh": (_i, [_p, _i, _p, _i, _i, _i64, _i, _i, _p, _p, _p, _f, _f, _u64, _p, _p, _i, _p]),
+    "vdm_gn_silu_fwd": (_i, [_p, _i, _p, _i, _i, _i64, _i, _i, _p, _p, _p, _f, _f, _u64, _p, _p, _i, _p, _p]),
+    "vdm_gn_dyh": (_i, [_p, _i, _p, _i, _i, _i64, _i, _i, _p, _p, _p, _f, _f, _u64, _p, _p, _i, _p, _p]),
     "vdm_gn_bwd_finalize": (_i, [_p, _i, _i, _i, _i, _i64, _p, _p, _f, _p, _p, _p, _p, _i64, _p]),
     "vdm_gn_bwd_apply": (_i, [_p, _i, _p, _i, _i, _i64, _i, _i, _p, _p, _f, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p]),
     "vdm_pack_input": (_i, [_p, _p, _i64, _i, _i, _p, _p]),
@@ -107,10 +107,10 @@ SIGNATURES = {
     "vdm_loss_terms": (_i, [_p, _p, _p, _p, _f, _p, _i, _i64, _p, _p, _p, _p]),
     "vdm_ancestral_step": (_i, [_p, _p, _p, _p, _p, _u64, _i64, _p]),
     "vdm_ancestral_step_cfg": (_i, [_p, _p, _p, _f, _p, _p, _p, _u64, _i64, _p]),
-    "vdm_randn": (_i, [_p, _i64, _u64, _u64, _p]),
+    "vdm_randn": (_i, [_p, _i64, _u64, _u64, _p, _p]),
     "vdm_step_inc": (_i, [_p, _p]),
     "vdm_sumsq": (_i, [_p, _i64, _p, _p, _p]),
-    "vdm_train_scalars": (_i, [_p, _p, _i, _i, _i, _f, _f, _f, _p, _p]),
+    "vdm_train_scalars": (_i, [_p, _p, _i, _i, _i, _f, _f, _f, _p, _u64, _p, _p]),
     "vdm_elbo_assemble": (_i, [_p, _p, _i, _f, _f, _f, _f, _p, _p]),
     "vdm_clip_scale": (_i, [_p, _i64, _p, _f, _p]),
 }

@@ -54,6 +54,9 @@ class KernelProfiler:
 
 
 PROFILER = None        # set to a KernelProfiler by bench.py
+# Device step counter (int32 tensor) mixed into every RNG seed inside the kernels (dropout masks, noise fields, time grid); set by
+# vdm_model.GraphedTrainStep: a captured graph bakes the host seeds into its kernel arguments, the counter keeps the draws fresh.
+SEED_STEP = None
 
 
 def _pb(tag="other"):
@@ -371,7 +374,7 @@ def gn_silu_fwd(x1, x2, groups, stats, gamma, beta, dropout_p=0.0, seed=0, out=N
         return out
     ev = _pb()
     check(L.vdm_gn_silu_fwd(_p(x1), c1, _p(x2), c2, n, v, groups, dt_id(x1.dtype), _p(stats), _p(gamma), _p(beta), GN_EPS,
-                            float(dropout_p), int(seed), _p(out), _p(mask), int(bool(linear)), _s()), "vdm_gn_silu_fwd")
+                            float(dropout_p), int(seed), _p(out), _p(mask), int(bool(linear)), _p(SEED_STEP), _s()), "vdm_gn_silu_fwd")
     out.keep_mask = mask
     _pe(ev, "gn_silu_fwd", 0.0, 2.0 * out.numel() * out.element_size())
     return out
@@ -391,7 +394,7 @@ def gn_silu_bwd(x1, x2, groups, stats, gamma, beta, dy, dgamma, dbeta, add1=None
     ev = _pb()
     dyh = dy if (dx1 is not None and dx1.data_ptr() == dy.data_ptr()) else torch.empty_like(dy)      # in place when the caller gave dy away
     check(L.vdm_gn_dyh(_p(x1), c1, _p(x2), c2, n, v, groups, dt_id(x1.dtype), _p(stats), _p(gamma), _p(beta), GN_EPS, float(dropout_p),
-                       int(seed), _p(dy), _p(dyh), int(bool(linear)), _s()), "vdm_gn_dyh")
+                       int(seed), _p(dy), _p(dyh), int(bool(linear)), _p(SEED_STEP), _s()), "vdm_gn_dyh")
     dyh.gnb_partials = channel_dot_sums(dyh, x1, x2)
     if colsum is not None and getattr(stats, "chsum", None) is None:      # the analytic column sums need sum_v x per channel
         cs = [channel_dot_sums(t, t)[:, 0, :, 0] for t in (x1, x2) if t is not None]
@@ -652,7 +655,7 @@ def randn(out, seed, stream_id=0):
     L = _lib.lib()
     _contig(out)
     assert out.dtype == torch.float32
-    check(L.vdm_randn(_p(out), out.numel(), int(seed), int(stream_id), _s()), "vdm_randn")
+    check(L.vdm_randn(_p(out), out.numel(), int(seed), int(stream_id), _p(SEED_STEP), _s()), "vdm_randn")
     return out
 
 
@@ -668,12 +671,13 @@ def sumsq(x, out):
     return out
 
 
-def train_scalars(B, device, rank, world, gamma_min, gamma_max, bpd_over_B, u0=None, times=None):
-    """[5, B] fp32 = {t, alpha_t, sigma_t, coef, t_norm} (vdm_train_scalars); u0: device tensor with one uniform draw, or times [B]."""
+def train_scalars(B, device, rank, world, gamma_min, gamma_max, bpd_over_B, u0=None, times=None, seed=0):
+    """[5, B] fp32 = {t, alpha_t, sigma_t, coef, t_norm} (vdm_train_scalars); u0: device tensor with one uniform draw, or times [B];
+    neither: u0 is drawn inside the kernel from (seed, SEED_STEP) - the graph-captured training step."""
     out = torch.empty((5, B), dtype=torch.float32, device=device)
     _contig(u0, times)
-    check(_lib.lib().vdm_train_scalars(_p(u0), _p(times), B, rank, world, float(gamma_min), float(gamma_max), float(bpd_over_B), _p(out), _s()),
-          "vdm_train_scalars")
+    check(_lib.lib().vdm_train_scalars(_p(u0), _p(times), B, rank, world, float(gamma_min), float(gamma_max), float(bpd_over_B), _p(out),
+                                       int(seed), _p(SEED_STEP), _s()), "vdm_train_scalars")
     return out
 
 

@@ -73,10 +73,64 @@ def clip_grad_norm_flat_(params, max_norm, use_hip, want_norm=True):
     return total
 
 
+class GraphedTrainStep:
+    """The whole training step - forward diffusion, UNet forward, ELBO, UNet backward, global-norm clip, fused AdamW, weight re-packing -
+    captured ONCE in a hipGraph and replayed.  Why: the host needs ~25 us per C-ABI call; in the deep UNet
+    levels the kernels are shorter than that, and the main queue idles ~1 ms per step waiting for launches (profiles/r03_step_timeline.txt).
+    What makes the step capturable: static shapes (one configuration per run), no host sync on the path, RNG seeds that are kernel
+    arguments PLUS a device-side step counter mixed in by the kernels (hip_ops.SEED_STEP: dropout masks, noise fields and the time grid
+    change from replay to replay although the host seeds are baked into the graph), AdamW with capturable state.  Single process only:
+    with world > 1 the step stays eager (the RCCL buckets are issued from Python).  The caller must not hold the loss tensor of an
+    earlier EAGER step when it builds this object: its autograd graph keeps an AccumulateGrad node bound to the default stream alive,
+    which would run inside the capture (torch warns; the capture then fails)."""
+
+    def __init__(self, model, opt, params, clip_val, batch, warmup=3):
+        from . import hip_ops as ops
+        assert ops.PROFILER is None, "per-launch events cannot be recorded inside a captured graph"
+        self.model, self.opt, self.params, self.clip = model, opt, params, clip_val
+        dev = params[0].device
+        self.static = {k: ([t.clone() for t in v] if isinstance(v, (list, tuple)) else (None if v is None else v.clone())) for k, v in batch.items()}
+        self.counter = torch.zeros(1, dtype=torch.int32, device=dev)
+        ops.SEED_STEP = self.counter                            # from now on every seed is (host seed, device step counter)
+        cur = torch.cuda.current_stream(dev)
+        side = torch.cuda.Stream(device=dev)
+        side.wait_stream(cur)
+        with torch.cuda.stream(side):                           # eager warm-up: allocator pools, workspaces, packed weights, optimizer state
+            for _ in range(warmup):
+                self._step()
+        cur.wait_stream(side)
+        torch.cuda.synchronize(dev)
+        self.graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.graph):
+            self.loss, self.gnorm = self._step()
+        self.replays = 0
+
+    def _step(self):
+        from . import hip_ops as ops
+        loss = self.model.training_step(self.static, 0)
+        self.opt.zero_grad(set_to_none=True)
+        loss.backward()
+        gnorm = clip_grad_norm_flat_(self.params, self.clip, True, want_norm=True) if self.clip else None
+        self.opt.step()
+        ops.step_inc(self.counter)
+        return loss, gnorm
+
+    def __call__(self, batch):
+        for k, v in batch.items():
+            if isinstance(v, (list, tuple)):
+                for dst, src in zip(self.static[k], v):
+                    dst.copy_(src, non_blocking=True)
+            elif v is not None:
+                self.static[k].copy_(v, non_blocking=True)
+        self.graph.replay()
+        self.replays += 1
+        return self.loss
+
+
 class Trainer:
     def __init__(self, max_steps=1_000_000, val_check_interval=1000, gradient_clip_val=0.5, every_n_train_steps=10_000,
                  default_root_dir="./data/logs", experiment_name="run", limit_val_batches=4, log_every_n_steps=50,
-                 n_val_sampling_steps=250, device=None, enable_progress=True):
+                 n_val_sampling_steps=250, device=None, enable_progress=True, graph_step=None):
         self.max_steps, self.val_check_interval, self.gradient_clip_val = max_steps, val_check_interval, gradient_clip_val
         self.every_n_train_steps = every_n_train_steps
         self.root = os.path.join(default_root_dir, experiment_name)
@@ -84,6 +138,9 @@ class Trainer:
         self.n_val_sampling_steps = n_val_sampling_steps
         self.device = device
         self.enable_progress = enable_progress
+        # capture the training step in a hipGraph (single-process HIP runs); None: $VDM4CDM_GRAPH_STEP (default off: measured 1.9 vs 5.2 ms
+        # per step at 32^3 where the host is the limiter, but 15.0 vs 14.7 ms at 128^3 and 23.0 vs 21.7 ms at 64^3 fp32 - bench.py --graph)
+        self.graph_step = (os.environ.get("VDM4CDM_GRAPH_STEP", "0") != "0") if graph_step is None else bool(graph_step)
         self.global_step = 0
         self.history = []
 
@@ -121,27 +178,38 @@ class Trainer:
         sm = model.model.score_model
         if hasattr(sm, "enable_ddp") and dev_type == "cuda":     # HIP backend: bucketed all-reduce inside the backward pass
             sm.enable_ddp(self.world)
-        opt = model.configure_optimizers()
         use_hip = dev_type == "cuda" and getattr(model.model.score_model, "backend", "") == "hip"
+        graphed = self.graph_step and use_hip and self.world == 1 and getattr(model.model, "noise_schedule", "") == "fixed_linear"
+        try:
+            opt = model.configure_optimizers(capturable=graphed)
+        except TypeError:                                    # (a user model with the reference's zero-argument signature)
+            opt, graphed = model.configure_optimizers(), False
+        gstep = None
         epoch, t0 = 0, time.time()
         model.train()
         while self.global_step < self.max_steps:
             n_batches = 0
             for batch in datamodule.train_dataloader(self.rank, self.world):
                 n_batches += 1
-                loss = model.training_step(batch, self.global_step)
-                opt.zero_grad(set_to_none=True)
-                loss.backward()
-                synced = getattr(sm, "grad_synced", False)     # the HIP backward already averaged the flat UNet gradient (in buckets)
-                sm.grad_synced = False
-                for p in params:                              # one collective per remaining parameter tensor (<= 2 schedule scalars)
-                    if p.grad is not None and not (synced and p is getattr(sm, "flat", None)):
-                        allreduce_mean_(p.grad, self.world)
-                gnorm = None
-                will_log = (self.global_step + 1) % self.log_every_n_steps == 0 or self.global_step == 0
-                if self.gradient_clip_val:
-                    gnorm = clip_grad_norm_flat_(params, self.gradient_clip_val, use_hip, want_norm=will_log)
-                opt.step()
+                if graphed and gstep is None and self.max_steps - self.global_step >= 8:
+                    gstep = GraphedTrainStep(model, opt, params, self.gradient_clip_val, batch)      # captured at the first batch
+                    self.global_step += 3                     # (its eager warm-up steps were real optimizer steps on this batch)
+                if gstep is not None and gstep.static["x"].shape == batch["x"].shape:
+                    loss, gnorm = gstep(batch), gstep.gnorm   # one hipGraph replay = the whole step
+                else:                                         # eager step (N > 1 ranks, short runs, a ragged last batch, the torch backend)
+                    loss = model.training_step(batch, self.global_step)
+                    opt.zero_grad(set_to_none=True)
+                    loss.backward()
+                    synced = getattr(sm, "grad_synced", False)     # the HIP backward already averaged the flat UNet gradient (in buckets)
+                    sm.grad_synced = False
+                    for p in params:                              # one collective per remaining parameter tensor (<= 2 schedule scalars)
+                        if p.grad is not None and not (synced and p is getattr(sm, "flat", None)):
+                            allreduce_mean_(p.grad, self.world)
+                    gnorm = None
+                    will_log = (self.global_step + 1) % self.log_every_n_steps == 0 or self.global_step == 0
+                    if self.gradient_clip_val:
+                        gnorm = clip_grad_norm_flat_(params, self.gradient_clip_val, use_hip, want_norm=will_log)
+                    opt.step()
                 self.global_step += 1
                 if self.global_step % self.log_every_n_steps == 0 or self.global_step == 1:
                     rec = {"step": self.global_step, "epoch": epoch, "lr": opt.param_groups[0]["lr"], "time": time.time() - t0,

@@ -67,9 +67,17 @@ class DeferredSide:
         self.ss.join()
 
     def flush(self):
-        for fn, tensors in self.pending:
-            self.ss.run(fn, *tensors)
-        self.pending = []
+        """ONE fork of the side stream for all held-back launches.  (Flushing them with one wait_stream each - four event records at the
+        same point of the main stream - was fine eagerly but produced a wrong hipGraph under stream capture: kernels issued on the main
+        stream right after the flush saw stale inputs.  Found by comparing a replayed step with the eager one tensor by tensor.)"""
+        pend, self.pending = self.pending, []
+        if not pend:
+            return
+
+        def all_():
+            for fn, _ in pend:
+                fn()
+        self.ss.run(all_, *[t for _, ts in pend for t in ts])
 
 
 # weight gradients of the up path's first N levels are deferred until the main stream starts the next level (0: launch immediately)

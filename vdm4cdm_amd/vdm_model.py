@@ -182,7 +182,12 @@ class VDM(nn.Module):
                 eps0 = ops.randn(torch.empty_like(x), noise_seed(), 2 * rank + 2)
             # the scalar side of the step in ONE launch: time grid (stratified over the global batch), alpha_t, sigma_t, the per-sample
             # loss weight 2 w_n = gamma'(t) bpd / B and the network's normalised time - no ATen launch between the noise draw and K7
-            if times is None and self.antithetic_time_sampling:
+            if times is None and self.antithetic_time_sampling and ops.SEED_STEP is not None:
+                # graph-captured step (trainer.GraphedTrainStep): u0 comes out of the kernel, from a fixed seed and the device step counter
+                if getattr(self, "_graph_seed", None) is None:
+                    self._graph_seed = noise_seed()
+                sc = ops.train_scalars(B, x.device, rank, world, self.gamma_min, self.gamma_max, bpd / B, seed=self._graph_seed)
+            elif times is None and self.antithetic_time_sampling:
                 u0 = torch.rand(1, device=x.device, generator=train_generator(x.device))
                 sc = ops.train_scalars(B, x.device, rank, world, self.gamma_min, self.gamma_max, bpd / B, u0=u0)
             else:
@@ -493,9 +498,11 @@ class LightVDM(nn.Module):
         self.log_dict({f"val/{k}": v for k, v in metrics.items()})
         return loss
 
-    def configure_optimizers(self):
+    def configure_optimizers(self, capturable=False):
+        """capturable: the optimizer state (step count) lives on the device, so that the step can be captured in a hipGraph
+        (trainer.GraphedTrainStep)."""
         fused = all(p.is_cuda for p in self.parameters())                       # one fused kernel over the flat vector
-        opt = torch.optim.AdamW(self.parameters(), lr=self.learning_rate, fused=fused)       # D11
+        opt = torch.optim.AdamW(self.parameters(), lr=self.learning_rate, fused=fused, capturable=bool(capturable and fused))       # D11
         sm = self.model.score_model
         if hasattr(sm, "mark_weights_dirty"):      # fused steps do not bump Tensor._version: tell the HIP executor to re-pack
             def _after_step(*_):
