@@ -176,8 +176,10 @@ class AstroDataModule:
         cv = sel["set_name"] == "CV"
         self.fields = []
         for c in self.channel_names:
-            f = np.load(field_path(root, sel["dataset_name"], sel["suite_name"], sel["set_name"], sel["z_name"], c),
-                        mmap_mode="r" if mmap else None)
+            # always memory-mapped, whatever `mmap` says (the reference's scripts pass mmap=False and hold the whole set - 67 GB per field at
+            # 256^3 - in host RAM, once per rank): here the cubes live in HBM after _resident() uploaded them slab by slab, the host only
+            # ever touches one slab
+            f = np.load(field_path(root, sel["dataset_name"], sel["suite_name"], sel["set_name"], sel["z_name"], c), mmap_mode="r")
             self.fields.append(f[_cv_keep(len(f))] if cv else f)
         self.params = np.atleast_2d(np.loadtxt(params_path(root, sel["suite_name"], sel["set_name"]))).astype(np.float32)
         if cv:
