@@ -1,8 +1,8 @@
 // elementwise.hip - HBM-bound kernels of the VDM denoising path (K2, K7-K10 of DESIGN.md):
 // GroupNorm statistics, fused GroupNorm-apply+SiLU(+dropout) forward/backward, VDM forward
 // diffusion, ELBO reductions, ancestral update with Philox normals, gradient-norm reduction and
-// the small layout helpers.  All are 16-byte-vectorised NDHWC streams with wave64 shuffle
-// reductions and one float atomic per workgroup per output.
+// the small layout helpers, and the scalar glue of the training step (time grid / ELBO assembly / clip scale).  All are
+// 16-byte-vectorised NDHWC streams with wave64 shuffle reductions and fixed-order two-stage folds (no float atomics).
 #include "common.h"
 
 namespace vdm {
