@@ -248,8 +248,7 @@ int vdm_augment_batch(const vdm_augment_channel* host_channels, int n_channels, 
  *   fwd:   q, k row-major, vt transposed -> out [n][v][heads*hd] (the layout the projection conv reads), lse [n][h][v] (may be NULL).
  *   rowdot: out[n][h][v] = sum_d a[n][v][h*hd+d] b[n][v][h*hd+d]   (dsum = rowsum(dOut * out) of the backward).
  *   bwd:   -> dqkv [n][v][3][heads*hd]; dQ in its own pass over the keys: no float atomics, bit-reproducible.
- * voxels % 4 == 0; head_dim in {16, 32, 64, 96, 128}.
- * (vdm_softmax_rows / _bwd: the row softmax of a materialised score matrix - kept for callers that hold one; off the network path.) */
+ * voxels % 4 == 0; head_dim in {16, 32, 64, 96, 128}. */
 int vdm_attn_split_heads(const void* src, int64_t src_stride, int64_t src_offset, int n, int64_t voxels, int heads, int head_dim,
                          int dtype, void* rowmajor, void* transposed, void* stream);
 int vdm_attn_fwd(const void* q, const void* k, const void* vt, int n, int64_t voxels, int heads, int head_dim, int dtype, float scale,
@@ -258,8 +257,6 @@ int vdm_attn_rowdot(const void* a, const void* b, int n, int64_t voxels, int hea
 int vdm_attn_bwd(const void* q, const void* k, const void* v, const void* qt, const void* kt, const void* do_rowmajor,
                  const void* do_transposed, const float* lse, const float* dsum, int n, int64_t voxels, int heads, int head_dim,
                  int dtype, float scale, void* dqkv, void* stream);
-int vdm_softmax_rows(float* scores, int64_t rows, int cols, float scale, void* stream);
-int vdm_softmax_rows_bwd(const float* probs, float* dprobs, int64_t rows, int cols, float scale, void* stream);
 /* out[c] = sum over rows of x[row][c] (x: [rows][c] in `dtype`): bias gradients of the block's two 1x1x1 projections. */
 int vdm_channel_sums(const void* x, int64_t rows, int c, int dtype, float* out, void* stream);
 /* out[n][c1+c2][2] = (sum_rows a, sum_rows a * b) per sample, a: [n][rows][c1+c2], b = concat(b1 [n][rows][c1], b2 [n][rows][c2] or

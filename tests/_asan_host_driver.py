@@ -100,7 +100,7 @@ assert L.vdm_gn_bwd_finalize(1, 4, 2, 32, 8, 4096, 1, 1, 1e-5, None, 1, 1, 1, 32
 assert L.vdm_pack_input(None, None, 10, 8, 1, None, None) == -1
 assert L.vdm_diffuse(1, 1, 1, 1, 2, 7, 1, None) == -1                                 # per % 4 != 0
 assert L.vdm_sumsq(3, 100, 1, 1, None) == -1                                          # misaligned
-assert L.vdm_softmax_rows(None, 1, 1, 1.0, None) == -1 and L.vdm_channel_sums(1, 4, 7, 1, 1, None) == -1
+assert L.vdm_channel_sums(1, 4, 7, 1, 1, None) == -1 and L.vdm_attn_fwd(1, 1, 1, 1, 30, 2, 16, 1, 1.0, 1, None, None) == -1      # voxels % 4
 assert L.vdm_augment_batch(None, 0, 16, 8, None, 0, None) == -1
 calls += 20
 

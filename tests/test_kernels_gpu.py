@@ -728,20 +728,10 @@ def test_pack_many_equals_per_conv_packing(dtype):
         assert torch.equal(a.wd, b.wd), f"dgrad packing differs for {shp}"
 
 
-def test_softmax_rows_and_channel_sums():
-    """Row softmax (+ backward) and channel sums of the attention block vs torch (fp32: 1e-6 relative)."""
+def test_channel_sums():
+    """Channel sums (bias gradients of the attention block's 1x1x1 projections) vs torch."""
     from vdm4cdm_amd import hip_ops as ops
     g = torch.Generator().manual_seed(3)
-    for rows, cols, scale in ((7, 64, 0.25), (33, 4096, 0.125), (3, 13824, 1.0)):
-        s = torch.randn(rows, cols, generator=g) * 4
-        dp = torch.randn(rows, cols, generator=g)
-        sr = s.clone().requires_grad_(True)
-        pr = torch.softmax(sr * scale, dim=-1)
-        (pr * dp).sum().backward()
-        p = ops.softmax_rows_(s.to(DEV), scale)
-        assert (p.cpu() - pr.detach()).abs().max().item() <= 1e-6
-        ds = ops.softmax_rows_bwd_(p, dp.to(DEV), scale)
-        assert (ds.cpu() - sr.grad).abs().max().item() <= 2e-6 * max(1.0, sr.grad.abs().max().item())
     for dtype in DTYPES:
         x = torch.randn(2, 5, 3, 7, 32, generator=g)
         xd = x.to(DEV).to(dtype)

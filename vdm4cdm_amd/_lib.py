@@ -99,8 +99,6 @@ SIGNATURES = {
     "vdm_attn_fwd": (_i, [_p, _p, _p, _i, _i64, _i, _i, _i, _f, _p, _p, _p]),
     "vdm_attn_rowdot": (_i, [_p, _p, _i, _i64, _i, _i, _i, _p, _p]),
     "vdm_attn_bwd": (_i, [_p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i64, _i, _i, _i, _f, _p, _p]),
-    "vdm_softmax_rows": (_i, [_p, _i64, _i, _f, _p]),
-    "vdm_softmax_rows_bwd": (_i, [_p, _p, _i64, _i, _f, _p]),
     "vdm_channel_sums": (_i, [_p, _i64, _i, _i, _p, _p]),
     "vdm_channel_dot_sums": (_i, [_p, _p, _i, _p, _i, _i, _i64, _i, _p, _p]),
     "vdm_diffuse": (_i, [_p, _p, _p, _p, _i, _i64, _p, _p]),

@@ -598,51 +598,6 @@ __global__ void __launch_bounds__(256) ancestral_kernel(float* __restrict__ z, c
     }
 }
 
-// ---------------------------------------------------------------------------------------------
-// attention block (mid_attn=True): row softmax of the fp32 score matrix and its backward, in place.  The two batched GEMMs around
-// them (Q K^T, P V and their transposes in the backward) are plain library GEMMs (rocBLAS through torch.matmul).
-// One workgroup per row; a row (<= 13 824 voxels at 192^3 / 8) stays in L2 between the passes.
-// ---------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(256) softmax_rows_kernel(float* __restrict__ s, int cols, float scale) {
-    __shared__ float sm[8];
-    float* row = s + (size_t)blockIdx.x * cols;
-    float m[1] = {-3.0e38f};
-    for (int i = threadIdx.x; i < cols; i += 256) m[0] = fmaxf(m[0], row[i] * scale);
-    // block max through the sum helper's scratch: wave max, then fold the 4 waves
-    float w = m[0];
-    for (int off = 32; off > 0; off >>= 1) w = fmaxf(w, __shfl_xor(w, off));
-    if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = w;
-    __syncthreads();
-    const float mx = fmaxf(fmaxf(sm[0], sm[1]), fmaxf(sm[2], sm[3]));
-    float acc[1] = {0.f};
-    for (int i = threadIdx.x; i < cols; i += 256) {
-        const float e = __expf(row[i] * scale - mx);
-        row[i] = e;
-        acc[0] += e;
-    }
-    block_sum<1>(acc, sm + 4);
-    __syncthreads();
-    if (threadIdx.x == 0) sm[4] = 1.f / acc[0];
-    __syncthreads();
-    const float inv = sm[4];
-    for (int i = threadIdx.x; i < cols; i += 256) row[i] *= inv;
-}
-
-// dp <- scale * p * (dp - sum_j dp_j p_j)   (gradient w.r.t. the un-scaled scores)
-__global__ void __launch_bounds__(256) softmax_rows_bwd_kernel(const float* __restrict__ p, float* __restrict__ dp, int cols, float scale) {
-    __shared__ float sm[8];
-    const float* pr = p + (size_t)blockIdx.x * cols;
-    float* dr = dp + (size_t)blockIdx.x * cols;
-    float acc[1] = {0.f};
-    for (int i = threadIdx.x; i < cols; i += 256) acc[0] += pr[i] * dr[i];
-    block_sum<1>(acc, sm);
-    __syncthreads();
-    if (threadIdx.x == 0) sm[4] = acc[0];
-    __syncthreads();
-    const float dot = sm[4];
-    for (int i = threadIdx.x; i < cols; i += 256) dr[i] = scale * pr[i] * (dr[i] - dot);
-}
-
 // out[c] = sum over rows of x[row][c] (bias gradients of the attention block's 1x1 projections); one workgroup per 16-byte piece
 // column, fixed summation order
 template <typename T>
@@ -984,20 +939,6 @@ extern "C" int vdm_ancestral_step_cfg(float* z, const float* eps_cond, const flo
     hipLaunchKernelGGL(ancestral_kernel, dim3(grid_for(n, 256 * 8)), dim3(256), 0, (hipStream_t)stream, z, eps_cond, eps_uncond, w_cfg,
                        noise, coef, step_ptr, seed, n);
     VDM_LAUNCH_CHECK("ancestral_kernel(cfg)");
-    return VDM_OK;
-}
-
-extern "C" int vdm_softmax_rows(float* scores, int64_t rows, int cols, float scale, void* stream) {
-    VDM_REQUIRE(scores && rows > 0 && rows < (1ll << 31) && cols > 0, "softmax_rows: bad arguments");
-    hipLaunchKernelGGL(softmax_rows_kernel, dim3((unsigned)rows), dim3(256), 0, (hipStream_t)stream, scores, cols, scale);
-    VDM_LAUNCH_CHECK("softmax_rows_kernel");
-    return VDM_OK;
-}
-
-extern "C" int vdm_softmax_rows_bwd(const float* probs, float* dprobs, int64_t rows, int cols, float scale, void* stream) {
-    VDM_REQUIRE(probs && dprobs && rows > 0 && rows < (1ll << 31) && cols > 0, "softmax_rows_bwd: bad arguments");
-    hipLaunchKernelGGL(softmax_rows_bwd_kernel, dim3((unsigned)rows), dim3(256), 0, (hipStream_t)stream, probs, dprobs, cols, scale);
-    VDM_LAUNCH_CHECK("softmax_rows_bwd_kernel");
     return VDM_OK;
 }
 

@@ -590,24 +590,6 @@ def attn_bwd(q, k, v, qt, kt, dout, out, lse, scale):
     return dqkv
 
 
-def softmax_rows_(scores, scale):
-    """In-place row softmax of scale * scores (fp32, last dim = row)."""
-    _contig(scores)
-    assert scores.dtype == torch.float32 and scores.is_cuda
-    cols = scores.shape[-1]
-    check(_lib.lib().vdm_softmax_rows(_p(scores), scores.numel() // cols, cols, float(scale), _s()), "vdm_softmax_rows")
-    return scores
-
-
-def softmax_rows_bwd_(probs, dprobs, scale):
-    """In place on dprobs: gradient w.r.t. the un-scaled scores, scale * p * (dp - sum_j dp_j p_j)."""
-    _contig(probs, dprobs)
-    assert probs.dtype == dprobs.dtype == torch.float32 and probs.shape == dprobs.shape
-    cols = probs.shape[-1]
-    check(_lib.lib().vdm_softmax_rows_bwd(_p(probs), _p(dprobs), probs.numel() // cols, cols, float(scale), _s()), "vdm_softmax_rows_bwd")
-    return dprobs
-
-
 def diffuse(x, eps, alpha, sigma, out=None):
     L = _lib.lib()
     _contig(x, eps, alpha, sigma)
