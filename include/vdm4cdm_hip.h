@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define VDM_ABI_VERSION 8
+#define VDM_ABI_VERSION 9
 
 typedef enum { VDM_OK = 0, VDM_ERR_ARG = -1, VDM_ERR_HIP = -2, VDM_ERR_UNSUPPORTED = -3 } vdm_status;
 typedef enum { VDM_F32 = 0, VDM_BF16 = 1 } vdm_dtype;
@@ -176,6 +176,29 @@ int vdm_gn_bwd_finalize(const float* partials, int tiles, int n, int c, int grou
 int vdm_gn_bwd_apply(const void* x1, int c1, const void* x2, int c2, int n, int64_t voxels, int groups, int dtype,
                      const float* stats, const float* gamma, float eps, const void* dyh, const float* red, const float* chan,
                      const void* add1, const void* add2, void* dx1, void* dx2, float* dgamma, float* dbeta, void* stream);
+
+/* ---- ResNetBlock skip path folded into the GroupNorm passes (bf16 storage) ------------------------------------------------
+ * [NB blocks.py ResNetBlock: out = net2(net1(x) + cond) + skip(x), skip = Conv3d(cin, cout, 1) when cin != cout; call chain
+ * trainVDM3D128_c_c_from_field_name_thick_lowbatch.py:116-127.]  norm1 and the 1x1x1 skip conv read the same block input, and the
+ * skip conv's input gradient is added to the result of norm1's backward: one pass each instead of a conv launch of their own.
+ *   vdm_gn_skip_supported: bit 0 = the forward kernel, bit 1 = the backward kernel exist for (c1 + c2 -> cout) in `dtype`
+ *     (host only; 0 for fp32 storage and for wide layers, which keep vdm_conv_fwd / vdm_conv_dgrad / vdm_conv_wgrad with ksize 1).
+ *   vdm_gn_silu_skip_fwd: y = silu(gn(concat(x1, x2)))  [n][voxels][c1+c2]  (vdm_gn_silu_fwd without dropout) AND
+ *     skip_out[n][voxels][cout] = w1 x1 + w2 x2 + bias, w1 [cout][c1], w2 [cout][c2] = the fp32 MASTER weights of the two column
+ *     blocks of the skip conv (rounded to bf16 in the kernel like vdm_conv_pack_weights does), bias [cout] or NULL.
+ *   vdm_gn_bwd_apply_skip: vdm_gn_bwd_apply with add = W^T dout computed in the pass (dout [n][voxels][cout] = the gradient of the
+ *     block output), plus the skip weight gradients dw1 [cout][c1], dw2 [cout][c2] = sum_{n,v} dout x (written, not accumulated;
+ *     per-workgroup slabs in `workspace` (vdm_gn_skip_ws_floats floats) + a fixed-order reduce: bit-reproducible).  The skip bias
+ *     gradient is the column sum of dout, which vdm_conv_wgrad of the block's second conv already returns. */
+int vdm_gn_skip_supported(int c1, int c2, int cout, int dtype);
+size_t vdm_gn_skip_ws_floats(int c1, int c2, int cout, int n, int64_t voxels);
+int vdm_gn_silu_skip_fwd(const void* x1, int c1, const void* x2, int c2, int n, int64_t voxels, int groups, int dtype,
+                         const float* stats, const float* gamma, const float* beta, float eps, const float* w1, const float* w2,
+                         const float* bias, int cout, void* y, void* skip_out, void* stream);
+int vdm_gn_bwd_apply_skip(const void* x1, int c1, const void* x2, int c2, int n, int64_t voxels, int groups, int dtype,
+                          const float* stats, const float* gamma, float eps, const void* dyh, const float* red, const float* chan,
+                          const void* dout, const float* w1, const float* w2, int cout, void* dx1, void* dx2, float* dgamma,
+                          float* dbeta, float* dw1, float* dw2, float* workspace, size_t workspace_floats, void* stream);
 
 /* ---- small tensor ops on the path ------------------------------------------------------------ */
 /* out[n][v][cpad] <- channels {a[n][v], b[n][v] (b may be NULL)} zero-padded to cpad; a,b fp32. */

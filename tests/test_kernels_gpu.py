@@ -764,3 +764,83 @@ def test_gn_stats_from_many_tile_partials():
         gs2 = 2 * c // G                                       # concat(out, out) in G groups of 2c / G channels
         ref2 = torch.cat([part, part], dim=2).double().sum(dim=1).reshape(N, G, gs2, 2).sum(dim=2)
         assert ((two.double() - ref2).abs() <= 2e-6 * ref2.abs() + 1e-3).all()
+
+
+SKIP_CASES = [  # (N, spatial, c1, c2, cout, groups)
+    (2, (8, 8, 16), 32, 32, 32, 8),      # level-0 up block of the 128^3 config
+    (1, (5, 6, 7), 32, 0, 64, 8),        # level-1 down block; ragged voxel count (210: partial 16- and 32-voxel groups)
+    (2, (4, 6, 6), 64, 0, 128, 8),       # level-2 down block (forward kernel only)
+    (1, (6, 6, 6), 64, 64, 64, 8),       # level-1 up block (forward kernel only)
+    (1, (8, 8, 8), 16, 16, 16, 8),       # level 0 of the 256^3 config (chs 16..128): two sources inside one 32-channel K-step
+    (3, (3, 5, 5), 16, 0, 32, 8),        # half-empty K-step
+    (1, (4, 4, 5), 8, 0, 16, 4),         # one piece per voxel
+    (1, (16, 16, 16), 32, 32, 64, 8),    # many chunks per wave
+]
+
+
+@pytest.mark.parametrize("case", SKIP_CASES, ids=[f"{c[2]}+{c[3]}to{c[4]}" for c in SKIP_CASES])
+def test_gn_skip_fused_passes(case):
+    """norm1 + the 1x1x1 skip conv in one pass (csrc/gn_skip.hip), forward and backward, against fp32 torch on the CPU:
+    y = silu(gn(x)), s = W x + b;  dx = GroupNorm backward of dyh (the gradient at the GroupNorm output) + W^T dout,
+    dW = dout^T x, dgamma, dbeta.  bf16 storage: outputs within 2^-7 of max|ref| (one rounding), weight gradients 2e-3."""
+    ops = _ops()
+    dtype = torch.bfloat16
+    N, sp, c1, c2, cout, G = case
+    C = c1 + c2
+    V = math.prod(sp)
+    fwd_ok, bwd_ok = ops.gn_skip_supported(c1, c2, cout, dtype)
+    assert fwd_ok
+    assert ops.gn_skip_supported(c1, c2, cout, torch.float32) == (False, False)
+    x1 = (rnd((N,) + sp + (c1,), 11) * 1.5 + 0.3).to(dtype).float()
+    x2 = rnd((N,) + sp + (c2,), 12, dtype) if c2 else None
+    gamma = 1.0 + 0.3 * rnd((C,), 13)
+    beta = 0.2 * rnd((C,), 14)
+    w = rnd((cout, C), 15, scale=C ** -0.5)
+    bias = 0.1 * rnd((cout,), 16)
+    dyh = rnd((N,) + sp + (C,), 17, dtype)
+    dout = rnd((N,) + sp + (cout,), 18, dtype)
+    wb = w.to(dtype).float()                     # the kernel multiplies bf16-rounded weights
+    xc = (x1 if x2 is None else torch.cat([x1, x2], -1)).clone().requires_grad_(True)
+    gr, br, wr = gamma.clone().requires_grad_(True), beta.clone().requires_grad_(True), wb.clone().requires_grad_(True)
+    z = F.group_norm(xc.permute(0, 4, 1, 2, 3), G, gr, br, 1e-5).permute(0, 2, 3, 4, 1)
+    y_ref = F.silu(z).detach()
+    s_ref_t = xc @ wr.t() + bias
+    ((z * dyh).sum() + (s_ref_t * dout).sum()).backward()
+
+    d1, d2 = to_dev(x1, dtype), (to_dev(x2, dtype) if c2 else None)
+    w1, w2 = w[:, :c1].contiguous().to(DEV), (w[:, c1:].contiguous().to(DEV) if c2 else None)
+    st = ops.gn_stats(d1, d2, G)
+    y, s = ops.gn_silu_skip_fwd(d1, d2, G, st, gamma.to(DEV), beta.to(DEV), w1, w2, bias.to(DEV))
+    assert y.shape == (N,) + sp + (C,) and s.shape == (N,) + sp + (cout,)
+    e = (y.float().cpu() - y_ref).abs().max().item()
+    assert e <= ew_tol(dtype, y_ref) * 4, f"y err {e}"
+    # the activation half is the plain kernel's arithmetic
+    assert torch.equal(y, ops.gn_silu_fwd(d1, d2, G, st, gamma.to(DEV), beta.to(DEV)))
+    s_ref = s_ref_t.detach()
+    e = (s.float().cpu() - s_ref).abs().max().item()
+    assert e <= conv_tol(dtype, s_ref), f"skip out err {e} > {conv_tol(dtype, s_ref)}"
+    if not bwd_ok:
+        return
+    ddyh, ddout = to_dev(dyh, dtype), to_dev(dout, dtype)
+    ddyh.gnb_partials = ops.channel_dot_sums(ddyh, d1, d2)
+    dgam, dbet = torch.zeros(C, device=DEV), torch.zeros(C, device=DEV)
+    dw1, dw2 = torch.full((cout, c1), 7.0, device=DEV), (torch.full((cout, c2), 7.0, device=DEV) if c2 else None)
+    dx1, dx2 = ops.gn_bwd_fused(d1, d2, G, st, gamma.to(DEV), ddyh, dgam, dbet, skip=(ddout, w1, w2, dw1, dw2))   # (c2 == 0: in place)
+    gx = xc.grad
+    tol = ew_tol(dtype, gx) * 8
+    e1 = (dx1.float().cpu() - gx[..., :c1]).abs().max().item()
+    assert e1 <= tol, f"dx1 err {e1} > {tol}"
+    if c2:
+        e2 = (dx2.float().cpu() - gx[..., c1:]).abs().max().item()
+        assert e2 <= tol, f"dx2 err {e2} > {tol}"
+    dw = dw1 if not c2 else torch.cat([dw1, dw2], 1)
+    e = (dw.cpu() - wr.grad).abs().max().item()
+    assert e <= 2e-3 * wr.grad.abs().max().item(), f"dW err {e} vs max {wr.grad.abs().max().item()}"
+    assert torch.allclose(dgam.cpu(), gr.grad, rtol=2e-2, atol=2e-2 * gr.grad.abs().max().item())
+    assert torch.allclose(dbet.cpu(), br.grad, rtol=2e-2, atol=2e-2 * br.grad.abs().max().item())
+    # bit-reproducible (per-workgroup slabs folded in a fixed order)
+    dw1b, dw2b = torch.zeros_like(dw1), (torch.zeros_like(dw2) if c2 else None)
+    ddyh2 = to_dev(dyh, dtype)
+    ddyh2.gnb_partials = ddyh.gnb_partials
+    dx1b, _ = ops.gn_bwd_fused(d1, d2, G, st, gamma.to(DEV), ddyh2, dgam, dbet, skip=(ddout, w1, w2, dw1b, dw2b))
+    assert torch.equal(dw1, dw1b) and torch.equal(dx1, dx1b)

@@ -27,12 +27,67 @@ def timed(fn, iters):
     return (time.perf_counter() - t0) / iters
 
 
+SKIP_SHAPES = [("L0up", 2, 128, 32, 32, 32), ("L0up_b1", 1, 128, 32, 32, 32), ("L1down", 2, 64, 32, 0, 64), ("L1up", 2, 64, 64, 64, 64),
+               ("L2down", 2, 32, 64, 0, 128), ("c256_L0up", 1, 256, 16, 16, 16)]
+
+
+def skip_bench(args):
+    """ms per call, alone on the device: (gn_silu_fwd + the 1x1x1 convs) vs gn_silu_skip_fwd; (1x1x1 dgrad + wgrads + finalize/apply) vs
+    the fused apply."""
+    dt, dev, G = torch.bfloat16, "cuda:0", 8
+    for name, N, D, c1, c2, cout in SKIP_SHAPES:
+        x1 = torch.randn(N, D, D, D, c1, device=dev).to(dt)
+        x2 = torch.randn(N, D, D, D, c2, device=dev).to(dt) if c2 else None
+        C = c1 + c2
+        gamma, beta = torch.randn(C, device=dev), torch.randn(C, device=dev)
+        w1, w2 = torch.randn(cout, c1, device=dev) / C ** 0.5, (torch.randn(cout, c2, device=dev) / C ** 0.5 if c2 else None)
+        bias = torch.randn(cout, device=dev)
+        k1, k2 = ops.Conv(c1, cout, 1), (ops.Conv(c2, cout, 1) if c2 else None)
+        k1.pack(w1.view(1, cout, c1), dt, True)
+        if k2:
+            k2.pack(w2.view(1, cout, c2), dt, True)
+        st = ops.gn_stats(x1, x2, G)
+        dyh = torch.randn(N, D, D, D, C, device=dev).to(dt)
+        dout = torch.randn(N, D, D, D, cout, device=dev).to(dt)
+        part = ops.channel_dot_sums(dyh, x1, x2)
+        dg, db = torch.zeros(C, device=dev), torch.zeros(C, device=dev)
+        dw1, dw2 = torch.zeros(cout, c1, device=dev), (torch.zeros(cout, c2, device=dev) if c2 else None)
+        dx1, dx2 = torch.empty_like(x1), (torch.empty_like(x2) if c2 else None)
+        dyh.gnb_partials = part
+
+        def sep_f():
+            ops.gn_silu_fwd(x1, x2, G, st, gamma, beta)
+            s = k1.fwd(x1, bias)
+            if k2:
+                k2.fwd(x2, None, None, s)
+
+        def sep_b():
+            a1 = k1.dgrad(dout)
+            a2 = k2.dgrad(dout) if k2 else None
+            k1.wgrad(x1, dout, dw1.view(1, cout, c1))
+            if k2:
+                k2.wgrad(x2, dout, dw2.view(1, cout, c2))
+            ops.gn_bwd_fused(x1, x2, G, st, gamma, dyh, dg, db, add1=a1, add2=a2, dx1=dx1, dx2=dx2)
+
+        okf, okb = ops.gn_skip_supported(c1, c2, cout, dt)
+        t = [timed(sep_f, args.iters), timed(lambda: ops.gn_silu_skip_fwd(x1, x2, G, st, gamma, beta, w1, w2, bias), args.iters) if okf else float("nan"),
+             timed(sep_b, args.iters),
+             timed(lambda: ops.gn_bwd_fused(x1, x2, G, st, gamma, dyh, dg, db, dx1=dx1, dx2=dx2, skip=(dout, w1, w2, dw1, dw2)), args.iters) if okb else float("nan")]
+        fb = (2 * x1.numel() * C / c1 + dout.numel()) * 2            # x read, y + s written
+        bb = (3 * x1.numel() * C / c1 + dout.numel()) * 2            # dyh, x, dout read, dx written
+        print(f"{name:10s} fwd separate {t[0] * 1e3:6.3f} ms  fused {t[1] * 1e3:6.3f} ms ({fb / t[1] / 1e9:5.0f} GB/s) | "
+              f"bwd separate {t[2] * 1e3:6.3f} ms  fused {t[3] * 1e3:6.3f} ms ({bb / t[3] / 1e9:5.0f} GB/s)", flush=True)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--dtype", default="bf16")
     ap.add_argument("--iters", type=int, default=20)
     ap.add_argument("--dropout", type=float, default=0.0)
+    ap.add_argument("--skip", action="store_true", help="norm1 + 1x1x1 skip conv: the fused passes (csrc/gn_skip.hip) against the separate kernels")
     args = ap.parse_args()
+    if args.skip:
+        return skip_bench(args)
     dt = torch.bfloat16 if args.dtype == "bf16" else torch.float32
     dev = "cuda:0"
     G = 8

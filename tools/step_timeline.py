@@ -3,7 +3,9 @@
 start offset and duration - the launches of one template instantiation differ a lot between UNet levels, which the --stats
 averages hide.
     rocprofv3 --kernel-trace --output-format csv -d out -- python3 bench.py --steps 6 --warmup 2 --no-cpu-baseline --no-kernel-events --sample-steps 0
-    python tools/step_timeline.py out/*/*kernel_trace.csv [step_index_from_the_end=2] > profiles/rNN_step_timeline.txt"""
+    python tools/step_timeline.py out/*/*kernel_trace.csv [step_index_from_the_end=2] > profiles/rNN_step_timeline.txt
+A third argument names the kernel a step starts with (default randn_kernel; `pack_input_kernel` for the denoise step of the sampler:
+    rocprofv3 --kernel-trace ... -- python3 tools/sampler_profile.py --steps 30;  step_timeline.py trace.csv 5 pack_input_kernel)."""
 import csv
 import re
 import sys
@@ -11,8 +13,9 @@ import sys
 rows = list(csv.DictReader(open(sys.argv[1])))
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
 back = int(sys.argv[2]) if len(sys.argv) > 2 else 2
-# a step starts with the randn_kernel pair of the forward diffusion (two launches back to back): take the first of each pair
-starts = [i for i, r in enumerate(rows) if "randn_kernel" in r["Kernel_Name"] and (i == 0 or "randn_kernel" not in rows[i - 1]["Kernel_Name"])]
+# a training step starts with the randn_kernel pair of the forward diffusion (two launches back to back): take the first of each pair
+mark = sys.argv[3] if len(sys.argv) > 3 else "randn_kernel"
+starts = [i for i, r in enumerate(rows) if mark in r["Kernel_Name"] and (i == 0 or mark not in rows[i - 1]["Kernel_Name"])]
 assert len(starts) > back, f"only {len(starts)} steps in the trace"
 lo, hi = starts[-back - 1], starts[-back]
 step = rows[lo:hi]

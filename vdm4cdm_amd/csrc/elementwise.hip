@@ -139,22 +139,21 @@ __global__ void __launch_bounds__(256) gn_stats_finalize_kernel(const float* __r
     }
 }
 
-// Same, from the per-tile channel partials a conv epilogue wrote (conv_common.h, gn_partials_reduce): part[n][tile][C][2].
-// stats[n][g0 + g][k] = sum over tiles and over the gs channels of group g.  One block per (sample, group).  Thread t < S
-// (S = the largest multiple of gs <= 256) owns channel t % gs and takes the tiles t / gs, t / gs + S / gs, ...; the S partial
-// sums are folded per channel and then over the channels in a fixed order (deterministic).  chsum (optional): the per-channel
-// sums chsum[n][c0 + c] = sum_v x[n][v][c] (the analytic column sums of the GroupNorm backward need them).
-__global__ void __launch_bounds__(256) gn_stats_from_partials_kernel(const float* __restrict__ part, int tiles, int C, int gs, int G,
-                                                                     int g0, float* __restrict__ stats, float* __restrict__ chsum,
-                                                                     int chsum_stride, int c0) {
-    const int gc = C / gs;
-    const int n = blockIdx.x / gc, g = blockIdx.x % gc;
-    const float2* p2 = reinterpret_cast<const float2*>(part) + (size_t)n * tiles * C + (size_t)g * gs;
-    const int per = 256 / gs, S = per * gs;                 // tiles in flight per sweep, active threads
+// Sum of the per-tile channel partials a conv epilogue wrote (conv_common.h, gn_partials_reduce): p2[tile][C] (float2), channels
+// [0, gs) of it -> sm[k][c] = sum over the tiles of component k of channel c, for c < gs (valid after the trailing barrier).
+// Thread t owns channel t % gs and the tiles t / gs, t / gs + per, ...; U independent loads in flight per thread (the sweep is
+// pure latency: the partials come from beyond the L2 of this XCD; in the step these launches take 3-45 us for the same work -
+// their duration is the wait for free wave slots next to the other queues' kernels, which is why neither 16 or 32 loads in flight
+// nor 1024-thread blocks - slower: a 16-wave block waits for a whole free CU - changed their average).  Power-of-two gs <= 64: the lanes of a wave that own the same
+// channel are folded by an xor-butterfly, the waves through LDS in wave order; otherwise every thread parks its sums and gs
+// threads walk them.  Both orders are fixed: bit-reproducible.
+template <int NT>
+__device__ __forceinline__ void tile_partials_fold(const float2* __restrict__ p2, int tiles, int C, int gs, float (*sm)[NT]) {
+    const int per = NT / gs, S = per * gs;                  // tiles in flight per sweep, active threads
     const int t = threadIdx.x, c = t % gs, b0 = t / gs;
     float s0 = 0.f, s1 = 0.f;
     if (t < S) {
-        constexpr int U = 8;                                // independent loads in flight per thread (the kernel is pure latency)
+        constexpr int U = 16;
         for (int b = b0; b < tiles; b += per * U) {
             float2 v[U];
 #pragma unroll
@@ -166,16 +165,45 @@ __global__ void __launch_bounds__(256) gn_stats_from_partials_kernel(const float
             for (int u = 0; u < U; ++u) { s0 += v[u].x; s1 += v[u].y; }
         }
     }
-    __shared__ float sm[2][256];
-    sm[0][t] = s0; sm[1][t] = s1;
-    __syncthreads();
-    if (t < gs) {                                           // per-channel totals, fixed order
+    if (gs <= 64 && (gs & (gs - 1)) == 0) {                 // (uniform)
+        for (int off = 32; off >= gs; off >>= 1) {
+            s0 += __shfl_xor(s0, off, 64);
+            s1 += __shfl_xor(s1, off, 64);
+        }
+        const int lane = t & 63, wave = t >> 6;
+        if (lane < gs) { sm[0][wave * gs + lane] = s0; sm[1][wave * gs + lane] = s1; }
+        __syncthreads();
         float a0 = 0.f, a1 = 0.f;
-        for (int j = 0; j < per; ++j) { a0 += sm[0][t + j * gs]; a1 += sm[1][t + j * gs]; }
-        if (chsum) chsum[(size_t)n * chsum_stride + c0 + g * gs + t] = a0;
-        sm[0][t] = a0; sm[1][t] = a1;                       // (slot t < gs is only read by this thread above)
+        if (t < gs)
+            for (int w = 0; w < NT / 64; ++w) { a0 += sm[0][w * gs + t]; a1 += sm[1][w * gs + t]; }
+        __syncthreads();
+        if (t < gs) { sm[0][t] = a0; sm[1][t] = a1; }
+    } else {
+        sm[0][t] = s0; sm[1][t] = s1;
+        __syncthreads();
+        if (t < gs) {                                       // (slot t < gs is only read by this thread)
+            float a0 = 0.f, a1 = 0.f;
+            for (int j = 0; j < per; ++j) { a0 += sm[0][t + j * gs]; a1 += sm[1][t + j * gs]; }
+            sm[0][t] = a0; sm[1][t] = a1;
+        }
     }
     __syncthreads();
+}
+
+// GroupNorm statistics from those partials: part[n][tile][C][2] -> stats[n][g0 + g][k] = sum over tiles and over the gs channels of
+// group g.  One block per (sample, group).  chsum (optional): the per-channel sums chsum[n][c0 + c] = sum_v x[n][v][c] (the analytic
+// column sums of the GroupNorm backward need them).
+template <int NT>
+__global__ void __launch_bounds__(NT) gn_stats_from_partials_kernel(const float* __restrict__ part, int tiles, int C, int gs, int G,
+                                                                    int g0, float* __restrict__ stats, float* __restrict__ chsum,
+                                                                    int chsum_stride, int c0) {
+    const int gc = C / gs;
+    const int n = blockIdx.x / gc, g = blockIdx.x % gc;
+    const float2* p2 = reinterpret_cast<const float2*>(part) + (size_t)n * tiles * C + (size_t)g * gs;
+    __shared__ float sm[2][NT];
+    tile_partials_fold<NT>(p2, tiles, C, gs, sm);
+    const int t = threadIdx.x;
+    if (chsum && t < gs) chsum[(size_t)n * chsum_stride + c0 + g * gs + t] = sm[0][t];
     if (t < 2) {
         float tot = 0.f;
         for (int j = 0; j < gs; ++j) tot += sm[t][j];
@@ -345,41 +373,26 @@ __device__ __forceinline__ bool pc_is_first(const GnArgs& a, int epl, int bid, i
 // apply: dx = rstd * (gamma * dyh - m1 - xhat * m2) (+ add), m = red / cnt; block 0 also writes dgamma / dbeta = sum_n chan.
 // No float atomics anywhere: the backward pass is bit-reproducible.
 // ---------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(256) gn_bwd_finalize_kernel(const float* __restrict__ part, int tiles, int C, int gs, int64_t V,
-                                                              const float* __restrict__ stats, const float* __restrict__ gamma,
-                                                              float eps, const float* __restrict__ chsum, float* __restrict__ red,
-                                                              float* __restrict__ chan, float* __restrict__ colsum,
-                                                              long long colsum_stride) {
+template <int NT>
+__global__ void __launch_bounds__(NT) gn_bwd_finalize_kernel(const float* __restrict__ part, int tiles, int C, int gs, int64_t V,
+                                                             const float* __restrict__ stats, const float* __restrict__ gamma,
+                                                             float eps, const float* __restrict__ chsum, float* __restrict__ red,
+                                                             float* __restrict__ chan, float* __restrict__ colsum,
+                                                             long long colsum_stride) {
     const int G = C / gs;
     const int n = blockIdx.x / G, g = blockIdx.x % G;
     const float2* p2 = reinterpret_cast<const float2*>(part) + (size_t)n * tiles * C + (size_t)g * gs;
-    const int per = 256 / gs, S = per * gs;
-    const int t = threadIdx.x, c = t % gs, b0 = t / gs;
-    float s0 = 0.f, s1 = 0.f;
-    if (t < S) {
-        constexpr int U = 8;
-        for (int b = b0; b < tiles; b += per * U) {
-            float2 v[U];
-#pragma unroll
-            for (int u = 0; u < U; ++u) {
-                const int bb = b + u * per;
-                v[u] = bb < tiles ? p2[(size_t)bb * C + c] : make_float2(0.f, 0.f);
-            }
-#pragma unroll
-            for (int u = 0; u < U; ++u) { s0 += v[u].x; s1 += v[u].y; }
-        }
-    }
-    __shared__ float sm[2][256];
+    const int t = threadIdx.x;
+    __shared__ float sm[2][NT];
     __shared__ float gr[2];
-    sm[0][t] = s0; sm[1][t] = s1;
-    __syncthreads();
+    tile_partials_fold<NT>(p2, tiles, C, gs, sm);
     const float cnt = (float)V * gs;
     const float gsum = stats[((size_t)n * G + g) * 2], gsq = stats[((size_t)n * G + g) * 2 + 1];
     const float mean = gsum / cnt;
     const float rstd = rsqrtf(fmaxf(gsq / cnt - mean * mean, 0.f) + eps);
     float T1 = 0.f, T2 = 0.f, gam = 0.f;
     if (t < gs) {
-        for (int j = 0; j < per; ++j) { T1 += sm[0][t + j * gs]; T2 += sm[1][t + j * gs]; }
+        T1 = sm[0][t]; T2 = sm[1][t];
         T2 = rstd * (T2 - mean * T1);                       // the epilogues sum dyh * x (raw): -> sum dyh * xhat
         gam = gamma[g * gs + t];
         chan[((size_t)n * C + g * gs + t) * 2] = T1;
@@ -782,8 +795,8 @@ extern "C" int vdm_gn_stats(const void* x1, int c1, const void* x2, int c2, int 
     for (int k = 0; k < 2; ++k) {
         if (cs[k] == 0) continue;
         if (parts[k]) {                                   // statistics already reduced per tile by the producing conv
-            hipLaunchKernelGGL(gn_stats_from_partials_kernel, dim3(n * (cs[k] / gs)), dim3(256), 0, s, parts[k], tiles[k], cs[k], gs, groups, g0, stats,
-                               chsum, c1 + c2, g0 * gs);
+            hipLaunchKernelGGL(gn_stats_from_partials_kernel<256>, dim3(n * (cs[k] / gs)), dim3(256), 0, s, parts[k], tiles[k], cs[k], gs, groups, g0,
+                               stats, chsum, c1 + c2, g0 * gs);
             VDM_LAUNCH_CHECK("gn_stats_from_partials_kernel");
             g0 += cs[k] / gs;
             continue;
@@ -860,7 +873,7 @@ extern "C" int vdm_gn_bwd_finalize(const float* partials, int tiles, int n, int 
     VDM_REQUIRE(tiles > 0 && n > 0 && groups > 0 && c > 0 && c % groups == 0 && voxels > 0, "gn_bwd_finalize: bad sizes");
     VDM_REQUIRE(c / groups <= 256, "gn_bwd_finalize: more than 256 channels per group");
     VDM_REQUIRE(!colsum || chsum, "gn_bwd_finalize: the analytic column sums need the per-channel sums of the GroupNorm input");
-    hipLaunchKernelGGL(gn_bwd_finalize_kernel, dim3(n * groups), dim3(256), 0, (hipStream_t)stream, partials, tiles, c, c / groups, voxels,
+    hipLaunchKernelGGL(gn_bwd_finalize_kernel<256>, dim3(n * groups), dim3(256), 0, (hipStream_t)stream, partials, tiles, c, c / groups, voxels,
                        stats, gamma, eps, chsum, red, chan, colsum, (long long)colsum_stride);
     VDM_LAUNCH_CHECK("gn_bwd_finalize_kernel");
     return VDM_OK;

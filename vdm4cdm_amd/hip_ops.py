@@ -380,6 +380,39 @@ def gn_silu_fwd(x1, x2, groups, stats, gamma, beta, dropout_p=0.0, seed=0, out=N
     return out
 
 
+def gn_skip_supported(c1, c2, cout, dtype):
+    """(forward, backward): whether the 1x1x1 skip conv (c1 + c2 -> cout) can ride along with norm1's GroupNorm passes
+    (csrc/gn_skip.hip: bf16 storage, narrow layers)."""
+    if dtype != torch.bfloat16:
+        return False, False
+    m = _lib.lib().vdm_gn_skip_supported(int(c1), int(c2), int(cout), dt_id(dtype))
+    return bool(m & 1), bool(m & 2)
+
+
+def gn_silu_skip_fwd(x1, x2, groups, stats, gamma, beta, w1, w2, bias):
+    """(silu(gn(concat(x1, x2))), w1 x1 + w2 x2 + bias) in one pass over the block input: norm1 + the 1x1x1 skip conv of a ResNetBlock.
+    w1 / w2: fp32 master weights [cout, c1(, 1, 1, 1)] / [cout, c2(, 1, 1, 1)] (w2 None without a second source)."""
+    L = _lib.lib()
+    _contig(x1, x2, gamma, beta, stats, w1, w2, bias)
+    n, v = _nv(x1)
+    c1 = x1.shape[-1]
+    c2 = 0 if x2 is None else x2.shape[-1]
+    cout = w1.shape[0]
+    y = torch.empty(x1.shape[:-1] + (c1 + c2,), dtype=x1.dtype, device=x1.device)
+    sk = torch.empty(x1.shape[:-1] + (cout,), dtype=x1.dtype, device=x1.device)
+    y.keep_mask = None
+    if "gn_fwd" in ABLATE:
+        return y, sk
+    ev = _pb()
+    check(L.vdm_gn_silu_skip_fwd(_p(x1), c1, _p(x2), c2, n, v, groups, dt_id(x1.dtype), _p(stats), _p(gamma), _p(beta), GN_EPS,
+                                 _p(w1), _p(w2), _p(bias), cout, _p(y), _p(sk), _s()), "vdm_gn_silu_skip_fwd")
+    _pe(ev, "gn_silu_fwd", 2.0 * n * v * (c1 + c2) * cout, (2.0 * y.numel() + sk.numel()) * y.element_size())
+    return y, sk
+
+
+_skip_ws = {}
+
+
 def gn_silu_bwd(x1, x2, groups, stats, gamma, beta, dy, dgamma, dbeta, add1=None, add2=None, colsum=None,
                 dropout_p=0.0, seed=0, dx1=None, dx2=None, linear=False):
     """GroupNorm(+SiLU+dropout) backward for a gradient `dy` that did NOT come out of Conv.dgrad_gn: dyh = dy * keep * silu'(yhat) as
@@ -409,9 +442,11 @@ def gn_silu_bwd(x1, x2, groups, stats, gamma, beta, dy, dgamma, dbeta, add1=None
     return out
 
 
-def gn_bwd_fused(x1, x2, groups, stats, gamma, dyh, dgamma, dbeta, add1=None, add2=None, colsum=None, dx1=None, dx2=None):
+def gn_bwd_fused(x1, x2, groups, stats, gamma, dyh, dgamma, dbeta, add1=None, add2=None, colsum=None, dx1=None, dx2=None, skip=None):
     """Second half of the GroupNorm+SiLU backward after Conv.dgrad_gn (dyh carries `.gnb_partials`).  Writes dgamma / dbeta,
-    colsum (optional [N, >=C] fp32 view, row stride honoured; needs stats.chsum) and returns (dx1, dx2).  No float atomics."""
+    colsum (optional [N, >=C] fp32 view, row stride honoured; needs stats.chsum) and returns (dx1, dx2).  No float atomics.
+    skip = (dout, w1, w2, dw1, dw2): the block's 1x1x1 skip conv rides along (gn_skip_supported(...)[1]): W^T dout is added to dx and
+    the skip weight gradients dw1 / dw2 are written in the same pass (instead of add1 / add2 from a separate dgrad conv)."""
     L = _lib.lib()
     _contig(x1, x2, dyh, add1, add2, gamma, dgamma, dbeta, stats)
     n, v = _nv(x1)
@@ -434,6 +469,21 @@ def gn_bwd_fused(x1, x2, groups, stats, gamma, dyh, dgamma, dbeta, add1=None, ad
     ev = _pb()
     check(L.vdm_gn_bwd_finalize(_p(part), part.shape[1], n, C_, groups, v, _p(stats), _p(gamma), GN_EPS, _p(chsum), _p(red), _p(chan),
                                 _p(colsum), cstride, _s()), "vdm_gn_bwd_finalize")
+    if skip is not None:
+        assert add1 is None and add2 is None
+        dout, w1, w2, dw1, dw2 = skip
+        _contig(dout, w1, w2, dw1, dw2)
+        cout = w1.shape[0]
+        nws = L.vdm_gn_skip_ws_floats(c1, c2, cout, n, v)
+        ws = _skip_ws.get((x1.device, _s()))
+        if ws is None or ws.numel() < nws:
+            ws = _skip_ws[(x1.device, _s())] = torch.empty(nws, dtype=torch.float32, device=x1.device)
+        if "gn_apply" not in ABLATE:
+            check(L.vdm_gn_bwd_apply_skip(_p(x1), c1, _p(x2), c2, n, v, groups, dt_id(x1.dtype), _p(stats), _p(gamma), GN_EPS, _p(dyh), _p(red),
+                                          _p(chan), _p(dout), _p(w1), _p(w2), cout, _p(dx1), _p(dx2), _p(dgamma), _p(dbeta), _p(dw1), _p(dw2),
+                                          _p(ws), ws.numel(), _s()), "vdm_gn_bwd_apply_skip")
+        _pe(ev, "gn_bwd(finalize+apply)", 4.0 * n * v * C_ * cout, (3.0 * dyh.numel() + dout.numel()) * dyh.element_size())
+        return dx1, dx2
     if "gn_apply" not in ABLATE:
       check(L.vdm_gn_bwd_apply(_p(x1), c1, _p(x2), c2, n, v, groups, dt_id(x1.dtype), _p(stats), _p(gamma), GN_EPS, _p(dyh), _p(red), _p(chan),
                              _p(add1), _p(add2), _p(dx1), _p(dx2), _p(dgamma), _p(dbeta), _s()), "vdm_gn_bwd_apply")

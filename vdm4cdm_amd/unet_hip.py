@@ -20,6 +20,8 @@ FUSED_GN = os.environ.get("VDM4CDM_FUSED_GN", "1") != "0"
 # float atomics, for A/B timing).  Needs the forward partials (FUSED_GN) for the analytic conditioning-table gradient.
 FUSED_GNB = FUSED_GN and os.environ.get("VDM4CDM_FUSED_GNB", "1") != "0"
 GNB_MIN_K = int(os.environ.get("VDM4CDM_GNB_MIN_K", "0"))      # fold only into dgrad convs with at least this many reduction channels
+# the 1x1x1 skip conv of a ResNetBlock rides along with norm1's GroupNorm passes where csrc/gn_skip.hip has a kernel (bf16, narrow layers)
+FUSED_SKIP = os.environ.get("VDM4CDM_FUSED_SKIP", "1") != "0"
 
 
 class SideStream:
@@ -106,10 +108,22 @@ class _Res:
             out.append((self.skip2, n + ".skip2.weight"))
         return out
 
+    def skip_rides(self, dtype):
+        """(forward, backward): the skip conv is computed inside norm1's GroupNorm passes."""
+        if self.skip1 is None or not FUSED_SKIP:
+            return False, False
+        return ops.gn_skip_supported(self.i.c1, self.i.c2, self.i.cout, dtype)
+
+    def skip_weights(self, P):
+        """The fp32 master weights of the two column blocks of the skip conv as [cout, c] matrices (views of the flat vector)."""
+        i, n = self.i, self.i.name
+        return P(n + ".skip.weight").view(i.cout, i.c1), (P(n + ".skip2.weight").view(i.cout, i.c2) if self.skip2 is not None else None)
+
     def fwd(self, P, x1, x2, table, save, p, seed, ss):
         i, G, n = self.i, self.net.norm_groups, self.i.name
         skip_out = []
-        if self.skip1 is not None:               # the 1x1 skip convs (HBM-bound) overlap with conv1 on the side stream
+        ride = self.skip_rides(x1.dtype)[0]      # norm1 and the skip conv read the same tensor: one pass (csrc/gn_skip.hip)
+        if self.skip1 is not None and not ride:  # the 1x1 skip convs (HBM-bound) overlap with conv1 on the side stream
             def side_skip():
                 s = self.skip1.fwd(x1, P(n + ".skip.bias"))
                 if self.skip2 is not None:
@@ -117,11 +131,16 @@ class _Res:
                 skip_out.append(s)
             ss.run(side_skip, x1, x2)
         st1 = ops.gn_stats(x1, x2, G)
-        a1 = ops.gn_silu_fwd(x1, x2, G, st1, P(n + ".norm1.weight"), P(n + ".norm1.bias"))
+        if ride:
+            a1, s = ops.gn_silu_skip_fwd(x1, x2, G, st1, P(n + ".norm1.weight"), P(n + ".norm1.bias"), *self.skip_weights(P), P(n + ".skip.bias"))
+        else:
+            a1 = ops.gn_silu_fwd(x1, x2, G, st1, P(n + ".norm1.weight"), P(n + ".norm1.bias"))
         h = self.conv1.fwd(a1, P(n + ".conv1.bias"), table[:, i.table_off:i.table_off + i.cout], gn=FUSED_GN)
         st2 = ops.gn_stats(h, None, G, chsum=save and FUSED_GNB)
         a2 = ops.gn_silu_fwd(h, None, G, st2, P(n + ".norm2.weight"), P(n + ".norm2.bias"), p, seed, want_mask=save and FUSED_GNB)
-        if self.skip1 is not None:
+        if ride:
+            pass
+        elif self.skip1 is not None:
             ss.join()
             s = skip_out[0]
             if ss.enabled:
@@ -143,7 +162,8 @@ class _Res:
                  and self.conv2.gn_fold_ok(i.cout, 0, h.dtype) and self.conv1.gn_fold_ok(i.c1, i.c2, h.dtype))
 
         skip_grads = []
-        if self.skip1 is not None:             # input gradients of the 1x1 skip convs: independent of the main chain until norm1
+        ride = fused and self.skip_rides(h.dtype)[1]      # skip dgrad + wgrad inside norm1's apply pass (csrc/gn_skip.hip)
+        if self.skip1 is not None and not ride:  # input gradients of the 1x1 skip convs: independent of the main chain until norm1
             def side_skip_dgrad():
                 skip_grads.append(self.skip1.dgrad(dout))
                 skip_grads.append(self.skip2.dgrad(dout) if self.skip2 is not None else None)
@@ -152,10 +172,11 @@ class _Res:
         def side_conv2(a2=a2, dout=dout, x1=x1, x2=x2):      # conv2 (+ the 1x1 skip convs share dout); tensors bound now: may run deferred
             self.conv2.wgrad(a2, dout, GP(n + ".conv2.weight"), GP(n + ".conv2.bias"))      # bias grad fused (column sums of dout)
             if self.skip1 is not None:
-                self.skip1.wgrad(x1, dout, GP(n + ".skip.weight"))
                 GP(n + ".skip.bias").copy_(GP(n + ".conv2.bias"))          # same column sums of dout
-                if self.skip2 is not None:
-                    self.skip2.wgrad(x2, dout, GP(n + ".skip2.weight"))
+                if not ride:
+                    self.skip1.wgrad(x1, dout, GP(n + ".skip.weight"))
+                    if self.skip2 is not None:
+                        self.skip2.wgrad(x2, dout, GP(n + ".skip2.weight"))
         ss.run(side_conv2, a2, dout, x1, x2)
         tcols = dtable[:, i.table_off:i.table_off + i.cout]
         if fused:      # dgrad epilogue: dyh = da2 * keep * silu'(.) + per-tile sums; then one finalize + one apply pass (no atomics)
@@ -176,6 +197,9 @@ class _Res:
         del a1, dh
         # skip path
         add1 = add2 = None
+        if ride:
+            return ops.gn_bwd_fused(x1, x2, G, st1, P(n + ".norm1.weight"), dyh1, GP(n + ".norm1.weight"), GP(n + ".norm1.bias"),
+                                    skip=(dout,) + self.skip_weights(P) + self.skip_weights(GP))
         if self.skip1 is not None:
             ss.second.join()
             add1, add2 = skip_grads
