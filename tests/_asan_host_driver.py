@@ -128,7 +128,7 @@ assert L.vdm_cond_table_bwd(mlps, 2, 2, 1312, 1, 1312, 1, 1, None, None) == -1  
 assert L.vdm_cond_table_step(None, None, None, 2, 8, None, None) == -1
 calls += 14
 # 5. skip conv folded into the GroupNorm passes: shape table, workspace size, argument checks
-for c1, c2, cout, want in [(32, 32, 32, 3), (32, 0, 64, 3), (64, 64, 64, 1), (64, 0, 128, 1), (128, 128, 128, 0), (16, 16, 16, 3), (8, 0, 16, 3),
+for c1, c2, cout, want in [(32, 32, 32, 3), (32, 0, 64, 3), (64, 64, 64, 3), (64, 0, 128, 1), (128, 128, 128, 0), (16, 16, 16, 3), (8, 0, 16, 3),
                            (12, 0, 16, 0), (32, 0, 24, 0), (0, 0, 16, 0), (-8, 8, 16, 0), (32, -8, 16, 0), (2 ** 30, 2 ** 30, 16, 0)]:
     assert L.vdm_gn_skip_supported(c1, c2, cout, 1) == want, (c1, c2, cout)
     assert L.vdm_gn_skip_supported(c1, c2, cout, 0) == 0
@@ -140,8 +140,8 @@ assert L.vdm_gn_silu_skip_fwd(16, 32, 16, 32, 2, 512, 8, 0, 16, 16, 16, 1e-5, 16
 assert L.vdm_gn_silu_skip_fwd(16, 32, None, 32, 2, 512, 8, 1, 16, 16, 16, 1e-5, 16, 16, 16, 32, 16, 16, None) == -1     # x2 NULL with c2 > 0
 assert L.vdm_gn_silu_skip_fwd(16, 128, 16, 128, 2, 512, 8, 1, 16, 16, 16, 1e-5, 16, 16, 16, 128, 16, 16, None) == -1 and b"not supported" in L.vdm_last_error()
 assert L.vdm_gn_silu_skip_fwd(16, 32, 16, 32, 2, 512, 7, 1, 16, 16, 16, 1e-5, 16, 16, 16, 32, 16, 16, None) == -1       # 64 channels, 7 groups
-assert L.vdm_gn_bwd_apply_skip(16, 64, 16, 64, 1, 512, 8, 1, 16, 16, 1e-5, 16, 16, 16, 16, 16, 16, 64, 16, 16, 16, 16, 16, 16, 16, 1 << 30,
-                               None) == -1 and b"not supported" in L.vdm_last_error()                                   # forward-only shape
+assert L.vdm_gn_bwd_apply_skip(16, 128, 16, 128, 1, 512, 8, 1, 16, 16, 1e-5, 16, 16, 16, 16, 16, 16, 128, 16, 16, 16, 16, 16, 16, 16, 1 << 30,
+                               None) == -1 and b"not supported" in L.vdm_last_error()                                   # too wide for the kernels
 assert L.vdm_gn_bwd_apply_skip(16, 32, 16, 32, 1, 512, 8, 1, 16, 16, 1e-5, 16, 16, 16, 16, 16, 16, 32, 16, 16, 16, 16, 16, 16, 16, 10,
                                None) == -1 and b"workspace" in L.vdm_last_error()
 calls += 10

@@ -245,24 +245,28 @@ __global__ void __launch_bounds__(256) gn_bwd_apply_skip_kernel(const GnSkipArgs
     char* tx = lds + Geo::PRO_BYTES + wave * Geo::WAVE_BYTES;
     char* td = tx + 32 * PX;
     // W^T fragments: tile (cb, m2) row r <-> channel cb * 32 + (r >> 2) * 8 + m2 * 4 + (r & 3): D rows 4g + e of the two tiles are the
-    // channels 8g + 4 m2 + e = the piece q = g of K-step cb that this lane streams
-    bf16x8 wt[KS][2][KD];
+    // channels 8g + 4 m2 + e = the piece q = g of K-step cb that this lane streams.  Small shapes hold the fragments and the
+    // constants in registers; wide ones (BIG) read them from LDS where they are used - their registers go to the dW accumulators.
+    constexpr bool BIG = KS * MT > 8;
+    constexpr int KSR = BIG ? 1 : KS;
+    const int crow = (v16 >> 2) * 8 + (v16 & 3);
+    bf16x8 wt[KSR][2][KD];
+    float Pc[KSR][8], Qc[KSR][8], Rc[KSR][8];
+    if constexpr (!BIG) {
 #pragma unroll
-    for (int cb = 0; cb < KS; ++cb)
+        for (int cb = 0; cb < KS; ++cb)
 #pragma unroll
-        for (int m2 = 0; m2 < 2; ++m2) {
-            const int c = cb * 32 + (v16 >> 2) * 8 + m2 * 4 + (v16 & 3);
+            for (int m2 = 0; m2 < 2; ++m2)
 #pragma unroll
-            for (int kd = 0; kd < KD; ++kd) wt[cb][m2][kd] = *reinterpret_cast<const bf16x8*>(&wtl[c * KW + kd * 32 + q * 8]);
-        }
-    float Pc[KS][8], Qc[KS][8], Rc[KS][8];
+                for (int kd = 0; kd < KD; ++kd) wt[cb][m2][kd] = *reinterpret_cast<const bf16x8*>(&wtl[(cb * 32 + crow + m2 * 4) * KW + kd * 32 + q * 8]);
 #pragma unroll
-    for (int ks = 0; ks < KS; ++ks)
+        for (int ks = 0; ks < KS; ++ks)
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            const int c = ks * 32 + q * 8 + j;
-            Pc[ks][j] = pqr[c]; Qc[ks][j] = pqr[CW + c]; Rc[ks][j] = pqr[2 * CW + c];
-        }
+            for (int j = 0; j < 8; ++j) {
+                const int c = ks * 32 + q * 8 + j;
+                Pc[ks][j] = pqr[c]; Qc[ks][j] = pqr[CW + c]; Rc[ks][j] = pqr[2 * CW + c];
+            }
+    }
     f32x4 dw[MT][CT];
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt)
@@ -316,8 +320,16 @@ __global__ void __launch_bounds__(256) gn_bwd_apply_skip_kernel(const GnSkipArgs
                 f32x4 t0 = f32x4{0.f, 0.f, 0.f, 0.f}, t1 = t0;
 #pragma unroll
                 for (int kd = 0; kd < KD; ++kd) {
-                    t0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wt[ks][0][kd], __builtin_bit_cast(bf16x8, ro[h][kd]), t0, 0, 0, 0);
-                    t1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wt[ks][1][kd], __builtin_bit_cast(bf16x8, ro[h][kd]), t1, 0, 0, 0);
+                    bf16x8 w0, w1;
+                    if constexpr (BIG) {
+                        w0 = *reinterpret_cast<const bf16x8*>(&wtl[(ks * 32 + crow) * KW + kd * 32 + q * 8]);
+                        w1 = *reinterpret_cast<const bf16x8*>(&wtl[(ks * 32 + crow + 4) * KW + kd * 32 + q * 8]);
+                    } else {
+                        w0 = wt[ks][0][kd];
+                        w1 = wt[ks][1][kd];
+                    }
+                    t0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w0, __builtin_bit_cast(bf16x8, ro[h][kd]), t0, 0, 0, 0);
+                    t1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w1, __builtin_bit_cast(bf16x8, ro[h][kd]), t1, 0, 0, 0);
                 }
                 const int p = ks * 4 + q;
                 if (ok && p < PPV) {
@@ -326,8 +338,14 @@ __global__ void __launch_bounds__(256) gn_bwd_apply_skip_kernel(const GnSkipArgs
                     pd.load(ry[h][ks]);
                     const float d0 = t0[0], d1 = t0[1], d2 = t0[2], d3 = t0[3], d4 = t1[0], d5 = t1[1], d6 = t1[2], d7 = t1[3];
                     const float ds[8] = {d0, d1, d2, d3, d4, d5, d6, d7};
+                    if constexpr (BIG) {
+                        const float* c0 = pqr + p * 8;
 #pragma unroll
-                    for (int j = 0; j < 8; ++j) px.f[j] = fmaf(pd.f[j], Pc[ks][j], fmaf(px.f[j], Qc[ks][j], Rc[ks][j])) + ds[j];
+                        for (int j = 0; j < 8; ++j) px.f[j] = fmaf(pd.f[j], c0[j], fmaf(px.f[j], c0[CW + j], c0[2 * CW + j])) + ds[j];
+                    } else {
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) px.f[j] = fmaf(pd.f[j], Pc[ks][j], fmaf(px.f[j], Qc[ks][j], Rc[ks][j])) + ds[j];
+                    }
                     if (p < P1)
                         *reinterpret_cast<uint4*>(dx1 + v * a.c1 + p * 8) = px.store();
                     else
@@ -411,7 +429,12 @@ static bool skip_shape(int c1, int c2, int cout, int& ks, int& mt) {
 static bool fwd_supported(int ks, int mt) {
     return (ks == 1 && (mt == 1 || mt == 2 || mt == 4)) || (ks == 2 && (mt == 2 || mt == 4 || mt == 8)) || (ks == 4 && mt == 4);
 }
-static bool bwd_supported(int ks, int mt) { return (ks == 1 && (mt == 1 || mt == 2 || mt == 4)) || (ks == 2 && (mt == 2 || mt == 4)); }
+static bool bwd_supported(int ks, int mt) {
+    return (ks == 1 && (mt == 1 || mt == 2 || mt == 4)) || (ks == 2 && (mt == 2 || mt == 4)) || (ks == 4 && mt == 4);
+}
+
+// wide shapes run one wave per SIMD (their dW accumulators fill the register file): one workgroup per CU, half the slabs to reduce
+static int bwd_wgs_per_cu(int ks, int mt) { return ks * mt > 8 ? 1 : 2; }
 
 static int skip_grid_x(int64_t units, int n, int per_cu) {      // workgroups per sample: 4 waves, one unit per wave and iteration
     int64_t want = (units + 3) / 4, cap = (256 * per_cu + n - 1) / n;
@@ -432,7 +455,7 @@ extern "C" int vdm_gn_skip_supported(int c1, int c2, int cout, int dtype) {
 extern "C" size_t vdm_gn_skip_ws_floats(int c1, int c2, int cout, int n, int64_t voxels) {
     int ks, mt;
     if (!skip_shape(c1, c2, cout, ks, mt) || n <= 0 || voxels <= 0) return 0;
-    return (size_t)skip_grid_x((voxels + 31) / 32, n, 2) * n * cout * 32 * ks;
+    return (size_t)skip_grid_x((voxels + 31) / 32, n, bwd_wgs_per_cu(ks, mt)) * n * cout * 32 * ks;
 }
 
 static int skip_common_check(int c1, int c2, int n, int64_t voxels, int groups, int cout, int dtype, const char* who) {
@@ -497,10 +520,10 @@ extern "C" int vdm_gn_bwd_apply_skip(const void* x1, int c1, const void* x2, int
     a.stats = stats; a.gamma = gamma; a.eps = eps; a.w1 = w1; a.w2 = w2;
     a.dyh = (const bf16_t*)dyh; a.dout = (const bf16_t*)dout; a.red = red; a.chan = chan;
     a.dx1 = (bf16_t*)dx1; a.dx2 = (bf16_t*)dx2; a.dgamma = dgamma; a.dbeta = dbeta; a.slabs = workspace;
-    const dim3 grid(skip_grid_x((voxels + 31) / 32, n, 2), n);
+    const dim3 grid(skip_grid_x((voxels + 31) / 32, n, bwd_wgs_per_cu(ks, mt)), n);
     hipStream_t s = (hipStream_t)stream;
     bool launched = false;
-    SKIP_BWD_CASE(1, 1) SKIP_BWD_CASE(1, 2) SKIP_BWD_CASE(1, 4) SKIP_BWD_CASE(2, 2) SKIP_BWD_CASE(2, 4)
+    SKIP_BWD_CASE(1, 1) SKIP_BWD_CASE(1, 2) SKIP_BWD_CASE(1, 4) SKIP_BWD_CASE(2, 2) SKIP_BWD_CASE(2, 4) SKIP_BWD_CASE(4, 4)
     VDM_REQUIRE(launched, "gn_bwd_apply_skip: no kernel for KS=%d MT=%d", ks, mt);
     VDM_LAUNCH_CHECK("gn_bwd_apply_skip_kernel");
     const int CW = 32 * ks;
