@@ -24,6 +24,9 @@ echo "pmc done"
 rocprofv3 --kernel-trace --stats --output-format csv -d "$out/${tag}_samp_stats" -- python3 tools/sampler_profile.py --steps 100 > "$out/${tag}_sampler_profile.json" 2> "$out/${tag}_samp.err"
 cp "$(ls "$out/${tag}_samp_stats"/*/*kernel_stats.csv | head -1)" "$out/${tag}_rocprofv3_kernel_stats_sampler_c5.csv"
 rm -rf "$out/${tag}_samp_stats"
+rocprofv3 --kernel-trace --output-format csv -d "$out/${tag}_samp_tr" -- python3 tools/sampler_profile.py --steps 40 > /dev/null 2> "$out/${tag}_samp_tr.err"
+python tools/step_timeline.py "$(ls "$out"/${tag}_samp_tr/*/*kernel_trace.csv | head -1)" 5 pack_input_kernel > "$out/${tag}_sampler_step_timeline.txt"
+rm -rf "$out/${tag}_samp_tr"
 python tools/sampler_profile.py --steps 200 > "$out/${tag}_sampler_plain.json" 2>/dev/null
 cat "$out/${tag}_sampler_plain.json"
 echo done
