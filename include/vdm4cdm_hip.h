@@ -89,6 +89,15 @@ int vdm_conv_pack_many(const vdm_pack_item* items_device, const vdm_pack_chunk* 
 int vdm_conv_gn_tiles(const vdm_conv_desc* d);
 int vdm_conv_fwd(const vdm_conv_desc* d, const void* x, const void* w_packed_fwd, const float* bias,
                  const float* nbias, int64_t nbias_stride, const void* residual, void* out, float* gn_partials, void* stream);
+/* The same forward conv for an input that is y = silu(groupnorm(x)) of the raw tensor x [NB blocks.py:129-132: net1 / net2 =
+ * Sequential(GroupNorm, SiLU, (Dropout,) Conv)] in INFERENCE (no dropout, nobody else needs y): GroupNorm + SiLU are applied to the
+ * staged halo image in LDS - vdm_gn_silu_fwd's arithmetic, bit-identical results - instead of by a pass of their own (one read and
+ * one write of the tensor per GroupNorm).  stats [n][groups][2] from vdm_gn_stats; gamma / beta [cin].  bf16 3x3x3 stride-1 convs
+ * on the generic kernel only: ask vdm_conv_fwd_gn_supported (host only) first. */
+int vdm_conv_fwd_gn_supported(const vdm_conv_desc* d);
+int vdm_conv_fwd_gn(const vdm_conv_desc* d, const void* x, const void* w_packed_fwd, const float* bias, const float* nbias,
+                    int64_t nbias_stride, const void* residual, void* out, float* gn_partials, const float* stats,
+                    const float* gamma, const float* beta, int groups, float eps, void* stream);
 /* dx = gradient w.r.t. the conv INPUT: the descriptor is the FORWARD conv's; dout has cout channels and the output
  * dims (od,oh,ow); dx gets cin channels and the input dims (stride 1: same; stride 2: 2x; up-sampling conv: the
  * coarse source grid od/2...).  Stride-2 and up-sampling convs run as per-parity-class convs (no dilated /

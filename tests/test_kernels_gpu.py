@@ -845,3 +845,47 @@ def test_gn_skip_fused_passes(case):
     ddyh2.gnb_partials = ddyh.gnb_partials
     dx1b, _ = ops.gn_bwd_fused(d1, d2, G, st, gamma.to(DEV), ddyh2, dgam, dbet, skip=(ddout, w1, w2, dw1b, dw2b))
     assert torch.equal(dw1, dw1b) and torch.equal(dx1, dx1b)
+
+
+GNP_CASES = [  # (N, spatial, cin, cout, circular, out_f32)
+    (2, (8, 8, 16), 32, 32, False, False),       # level 0 (NC2, 4x8x16 tiles)
+    (1, (5, 9, 20), 32, 32, False, False),       # ragged: partial tiles, zero padding inside the staged image
+    (1, (6, 6, 6), 32, 32, True, False),         # circular: every halo voxel is a real one
+    (1, (8, 8, 16), 64, 64, False, False),       # two K-blocks, NC4
+    (1, (4, 4, 16), 128, 128, False, False),     # deep level: small-grid tiles / half-chunk workgroups
+    (2, (8, 8, 16), 32, 1, False, True),         # conv_out: fp32 result
+    (1, (8, 8, 16), 96, 32, False, False),       # 3 K-blocks, 12 channels per group
+]
+
+
+@pytest.mark.parametrize("case", GNP_CASES, ids=[f"{c[2]}to{c[3]}{'c' if c[4] else ''}{'f' if c[5] else ''}_{'x'.join(map(str, c[1]))}" for c in GNP_CASES])
+def test_conv_fwd_with_groupnorm_prologue(case):
+    """Inference: conv(silu(gn(x))) with GroupNorm + SiLU applied to the staged image inside the conv kernel (vdm_conv_fwd_gn)
+    == gn_silu_fwd followed by the plain conv, BIT FOR BIT (same arithmetic on the same bf16 operands), and within the conv tolerance of
+    the CPU fp32 reference."""
+    ops = _ops()
+    dtype = torch.bfloat16
+    N, sp, cin, cout, circ, f32 = case
+    G = 8
+    x = (rnd((N,) + sp + (cin,), 21) * 1.3 + 0.2).to(dtype).float()
+    gamma, beta = 1.0 + 0.3 * rnd((cin,), 22), 0.2 * rnd((cin,), 23)
+    w = rnd((27, cout, cin), 24, scale=(27 * cin) ** -0.5)
+    bias = 0.1 * rnd((cout,), 25)
+    conv = ops.Conv(cin, cout, 3, circular=circ, out_f32=f32)
+    conv.pack(w.to(DEV), dtype, need_dgrad=False)
+    dx = to_dev(x, dtype)
+    if not conv.gn_in_ok(dx):
+        pytest.skip("this shape runs a kernel without the prologue")
+    st = ops.gn_stats(dx, None, G)
+    a = ops.gn_silu_fwd(dx, None, G, st, gamma.to(DEV), beta.to(DEV))
+    ref_dev = conv.fwd(a, bias.to(DEV), gn=not f32)
+    out = conv.fwd(dx, bias.to(DEV), gn=not f32, gn_in=(G, st, gamma.to(DEV), beta.to(DEV)))
+    assert torch.equal(out, ref_dev), f"max diff {(out.float() - ref_dev.float()).abs().max().item()}"
+    if not f32:
+        assert torch.equal(out.gn_partials, ref_dev.gn_partials)
+    y = F.silu(F.group_norm(x.permute(0, 4, 1, 2, 3), G, gamma, beta, 1e-5)).to(dtype).float()
+    wt = w.to(dtype).float().reshape(3, 3, 3, cout, cin).permute(3, 4, 0, 1, 2)
+    yp = F.pad(y, (1, 1, 1, 1, 1, 1), mode="circular") if circ else y
+    ref = F.conv3d(yp, wt, bias, padding=0 if circ else 1).permute(0, 2, 3, 4, 1)
+    e = (out.float().cpu()[..., :cout] - ref).abs().max().item()
+    assert e <= 2 * conv_tol(dtype, ref), f"err {e} > {2 * conv_tol(dtype, ref)}"

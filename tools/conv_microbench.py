@@ -66,7 +66,14 @@ def main():
                 st = ops.gn_stats(x, None, G)
                 gam, bet = torch.ones(cin, device=dev), torch.zeros(cin, device=dev)
                 mask = torch.full((N, D * D * D, cin // ops.epl(dt)), 0xFF, dtype=torch.uint8, device=dev)
+            if op in ("fwd_gnp", "gn_silu"):               # inference: GroupNorm + SiLU in the conv's prologue / as the separate pass it replaces
+                if ks != 3 or stride != 1 or ups or not conv.gn_in_ok(x):
+                    continue
+                G = 8
+                st = ops.gn_stats(x, None, G)
+                gam, bet = torch.ones(cin, device=dev), torch.zeros(cin, device=dev)
             fn = {"fwd": lambda: conv.fwd(x), "fwd_gn": lambda: conv.fwd(x, gn=True), "dgrad": lambda: conv.dgrad(dout),
+                  "fwd_gnp": lambda: conv.fwd(x, gn=True, gn_in=(G, st, gam, bet)), "gn_silu": lambda: ops.gn_silu_fwd(x, None, G, st, gam, bet),
                   "wgrad": lambda: conv.wgrad(x, dout, dw),
                   "dgrad_gn": lambda: conv.dgrad_gn(dout, x, None, G, st, gam, bet, keep_mask=mask, dropout_p=0.1)}[op]
             for _ in range(3):

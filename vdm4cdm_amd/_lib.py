@@ -77,6 +77,8 @@ SIGNATURES = {
     "vdm_conv_pack_many": (_i, [_p, _p, _i, _i, _p]),
     "vdm_conv_gn_tiles": (_i, [_D]),
     "vdm_conv_fwd": (_i, [_D, _p, _p, _p, _p, _i64, _p, _p, _p, _p]),
+    "vdm_conv_fwd_gn_supported": (_i, [_D]),
+    "vdm_conv_fwd_gn": (_i, [_D, _p, _p, _p, _p, _i64, _p, _p, _p, _p, _p, _p, _i, _f, _p]),
     "vdm_conv_dgrad": (_i, [_D, _p, _p, _p, _p, _p]),
     "vdm_conv_dgrad_gn_tiles": (_i, [_D]),
     "vdm_conv_dgrad_gn": (_i, [_D, _p, _p, _p, C.POINTER(GnFold), _p]),

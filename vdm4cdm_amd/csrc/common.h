@@ -81,7 +81,8 @@ __device__ __forceinline__ float wave_sum(float v) {
     return v;
 }
 
-__device__ __forceinline__ float silu_f(float y) { return y / (1.0f + __expf(-y)); }
+// (v_rcp_f32 instead of the correctly rounded division: the activation is stored as bf16; every forward path uses this one form)
+__device__ __forceinline__ float silu_f(float y) { return y * __builtin_amdgcn_rcpf(1.0f + __expf(-y)); }
 __device__ __forceinline__ float sigmoid_f(float y) { return 1.0f / (1.0f + __expf(-y)); }
 
 // ---- Philox4x32-10 counter RNG (dropout masks, sampler noise) ---------------------------------

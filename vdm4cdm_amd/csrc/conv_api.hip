@@ -281,6 +281,31 @@ extern "C" int vdm_conv_fwd(const vdm_conv_desc* d, const void* x, const void* w
     return launch_fwd(a, d->dtype, d->out_f32, d->ksize, d->stride, d->upsample, p.nc, (hipStream_t)stream);
 }
 
+// host only: can vdm_conv_fwd_gn run this conv (the generic bf16 3x3x3 stride-1 kernel, not the tap-packed / K-split / class kernels)?
+extern "C" int vdm_conv_fwd_gn_supported(const vdm_conv_desc* d) {
+    if (validate(d) != VDM_OK) return 0;
+    if (d->dtype != VDM_BF16 || d->ksize != 3 || d->stride != 1 || d->upsample || d->cin > 512 || d->cin % 8) return 0;
+    return vdm_conv_kernel_variant(d, 0) == VDM_CONV_VARIANT_GENERIC || vdm_conv_kernel_variant(d, 0) == VDM_CONV_VARIANT_SPLIT;
+}
+
+extern "C" int vdm_conv_fwd_gn(const vdm_conv_desc* d, const void* x, const void* w_packed, const float* bias, const float* nbias,
+                               int64_t nbias_stride, const void* residual, void* out, float* gn_partials, const float* stats,
+                               const float* gamma, const float* beta, int groups, float eps, void* stream) {
+    int e = validate(d);
+    if (e) return e;
+    VDM_REQUIRE(x && w_packed && out && stats && gamma && beta, "conv_fwd_gn: NULL pointer");
+    VDM_REQUIRE(vdm_conv_fwd_gn_supported(d), "conv_fwd_gn: this conv has no GroupNorm prologue (vdm_conv_fwd_gn_supported)");
+    VDM_REQUIRE(groups > 0 && groups <= 64 && d->cin % groups == 0, "conv_fwd_gn: %d channels / %d groups", d->cin, groups);
+    const Plan p = plan_of(d, 0);
+    ConvArgs a{};
+    a.x = x; a.w = w_packed; a.bias = bias; a.nbias = nbias; a.nbias_stride = nbias_stride; a.res = residual; a.out = out;
+    a.gnp = gn_partials;
+    fwd_args(a, d);
+    a.gstats = stats; a.ggamma = gamma; a.gbeta = beta; a.gG = groups; a.geps = eps;
+    a.gcnt = (float)((double)d->od * d->oh * d->ow * (d->cin / groups));
+    return launch_fwd_gnp(a, d->out_f32, p.nc, (hipStream_t)stream);
+}
+
 extern "C" int vdm_conv_dgrad(const vdm_conv_desc* d, const void* dout, const void* w_packed_dgrad, const void* residual, void* dx,
                               void* stream) {
     int e = validate(d);

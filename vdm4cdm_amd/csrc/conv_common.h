@@ -26,6 +26,7 @@
 namespace vdm {
 
 static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
+static constexpr int GNP_TABLE_BYTES = 512 * 2 * 4;          // GroupNorm prologue: (A, B) of up to 512 input channels
 static constexpr int GN_SCRATCH_BYTES = 4 * 64 * 2 * 4;      // 4 waves x (NC <= 4) * 16 channels x (sum, sumsq) floats
 
 // ---------------------------------------------------------------------------------------------
@@ -154,6 +155,58 @@ __device__ __forceinline__ void stage_halo_dma_gen(char* lds, const T* __restric
         hx += DX; hy += DY; hz += DZ;
         if (hx >= G::HX) { hx -= G::HX; hy += 1; }
         if (hy >= G::HY) { hy -= G::HY; hz += 1; }
+    }
+}
+
+// GroupNorm + SiLU applied to the staged halo image in place (inference: the conv input is silu(gn(x)) of a tensor nobody else
+// needs activated - the separate gn_silu_fwd pass, one read + one write of the tensor, disappears).  Every wave transforms exactly
+// the chunks it staged itself (same chunk / lane walk as stage_halo_dma_gen), so its own `s_waitcnt vmcnt(0)` is all the
+// synchronisation needed before the workgroup barrier in front of the taps.  Voxels outside the volume came from the zero page and
+// stay zero (the conv pads the ACTIVATED tensor).  tab: LDS, [0, Cin) = A = rstd * gamma, [Cin, 2 Cin) = B = beta - mean * A of
+// this sample.  The arithmetic is gn_silu_fwd's: the conv sees bit-identical operands.
+template <typename T, typename G, int NWAVES = 4>
+__device__ __forceinline__ void gn_prologue_inplace(char* lds, const float* tab, const ConvArgs& a, int oz0, int oy0, int ox0, int kb,
+                                                    int wave, int lane) {
+    static_assert(G::STRIDE == 1, "prologue: stride-1 convs only");
+    constexpr int EPL = DT<T>::EPL, KB = DT<T>::KB;
+    constexpr int NCHUNK = (G::HVOX + 15) / 16;
+    constexpr int STEP = 16 * NWAVES;
+    constexpr int DX = STEP % G::HX, DY = (STEP / G::HX) % G::HY, DZ = STEP / (G::HX * G::HY);
+    const int iz0 = oz0 - G::PAD, iy0 = oy0 - G::PAD, ix0 = ox0 - G::PAD;
+    const int k = lane >> 2, j = lane & 3;
+    const int hv0 = wave * 16 + k;
+    int hx = hv0 % G::HX, hy = (hv0 / G::HX) % G::HY, hz = hv0 / (G::HX * G::HY);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // this wave's LDS-DMA chunks have landed
+    for (int c = wave; c < NCHUNK; c += NWAVES) {
+        const int pc = j ^ ((hx >> 1) & 3);
+        const int ci = kb * KB + pc * EPL;
+        const int iz = iz0 + hz, iy = iy0 + hy, ix = ix0 + hx;
+        bool ok = ci < a.Cin && hz < G::HZ;
+        if (!a.circular) ok = ok && (unsigned)iz < (unsigned)a.Iz && (unsigned)iy < (unsigned)a.Iy && (unsigned)ix < (unsigned)a.Ix;
+        if (ok) {
+            uint4* q = reinterpret_cast<uint4*>(lds + c * 1024 + lane * 16);
+            Piece<T> px;
+            px.load(*q);
+#pragma unroll
+            for (int e = 0; e < EPL; ++e) px.f[e] = silu_f(px.f[e] * tab[ci + e] + tab[a.Cin + ci + e]);
+            *q = px.store();
+        }
+        hx += DX; hy += DY; hz += DZ;
+        if (hx >= G::HX) { hx -= G::HX; hy += 1; }
+        if (hy >= G::HY) { hy -= G::HY; hz += 1; }
+    }
+}
+
+// the per-channel affines of sample n for gn_prologue_inplace (all threads of the workgroup; a barrier must follow)
+__device__ __forceinline__ void gn_prologue_table(float* tab, const ConvArgs& a, int n, int tid, int nthreads) {
+    const int gs = a.Cin / a.gG;
+    for (int c = tid; c < a.Cin; c += nthreads) {
+        const float sum = a.gstats[((size_t)n * a.gG + c / gs) * 2], sq = a.gstats[((size_t)n * a.gG + c / gs) * 2 + 1];
+        const float mean = sum / a.gcnt;
+        const float rstd = rsqrtf(fmaxf(sq / a.gcnt - mean * mean, 0.f) + a.geps);
+        const float A = rstd * a.ggamma[c];
+        tab[c] = A;
+        tab[a.Cin + c] = a.gbeta[c] - mean * A;
     }
 }
 
@@ -952,6 +1005,7 @@ static void fwd_tile_shape(const ConvArgs& a, int dtype, int out_f32, int ks, in
 // launchers (defined in conv_fwd.hip / conv_cls.hip / conv_wgrad.hip)
 int launch_fwd(const ConvArgs& a, int dtype, int out_f32, int ks, int stride, int ups, int nc, hipStream_t s);
 int launch_fwd_gnb(const ConvArgs& a, int dtype, int nc, hipStream_t s);
+int launch_fwd_gnp(const ConvArgs& a, int out_f32, int nc, hipStream_t s);
 int run_cls(const vdm_conv_desc* d, int kind, const void* x, const void* w, const float* bias, const void* res, void* out,
             int cd, int ch, int cw, hipStream_t s, float* gn_partials = nullptr);
 int launch_wgrad_any(const WgradArgs& w, float* dw, float* db, int acc, int cout, int cin, int ks, int stride, int ups, size_t ws,

@@ -10,9 +10,12 @@ namespace vdm {
 // 2h+1 = couts 16q + 8h .. +7 of every lane group q): twice the workgroups for the small grids of the deep levels, where a
 // workgroup's K-blocks run strictly one after the other and only co-resident workgroups overlap staging with MFMAs.
 // GNB: the GroupNorm+SiLU backward reduction is folded into the epilogue (dgrad launches that feed a GroupNorm: conv_epilogue_gnb).
-template <typename T, typename TO, int KS, int STRIDE, int UPS, int NC, int TZ, int TY, bool SPLIT = false, bool GNB = false>
+// GNP: the conv input is silu(gn(x)) of the raw tensor x (inference): GroupNorm + SiLU are applied to the staged image in LDS
+// (gn_prologue_inplace) instead of by a pass of their own.
+template <typename T, typename TO, int KS, int STRIDE, int UPS, int NC, int TZ, int TY, bool SPLIT = false, bool GNB = false, bool GNP = false>
 __global__ void __launch_bounds__(256, (TZ * TY <= 16 && NC <= 2) ? 3 : 2) conv_fwd_kernel(const ConvArgs a) {
     static_assert(!SPLIT || NC == 2, "half-chunk mode is the NC=2 kernel on NC=4 weights");
+    static_assert(!(GNB && GNP), "the prologue belongs to forward convs, the folded backward to dgrad convs");
     constexpr int NCW = SPLIT ? 4 : NC;
     using G = Geo<KS, STRIDE, TZ, TY>;
     constexpr int NV = G::NV, TAPS = G::TAPS;
@@ -58,6 +61,14 @@ __global__ void __launch_bounds__(256, (TZ * TY <= 16 && NC <= 2) ? 3 : 2) conv_
         if (kb) __syncthreads();
         stage_halo_dma<T, G, UPS>(lds, x, a, n, oz0, oy0, ox0, kb, wave, lane);
         if (kb == 0) VDM_STAMP(6);
+        constexpr int IMG_ = ((G::HVOX + 15) / 16) * 1024;
+        float* gn_tab = reinterpret_cast<float*>(lds + IMG_ + GN_SCRATCH_BYTES);
+        if constexpr (GNP) {
+            if (kb == 0) {                                  // (behind the first DMA issue: the table is built while the halo is in flight)
+                gn_prologue_table(gn_tab, a, n, tid, 256);
+                __syncthreads();
+            }
+        }
         const uint4* wk = wbase + (size_t)kb * TAPS * NCW * 64;
         if constexpr (sizeof(T) == 2) {
             constexpr int WPD = WPipe<NC>::WPD;
@@ -66,11 +77,13 @@ __global__ void __launch_bounds__(256, (TZ * TY <= 16 && NC <= 2) ? 3 : 2) conv_
             if constexpr (RR) rr_prefetch_weights<NC, WPD, NCW>(wf, wk);
             else taps_prefetch_weights<TAPS, NC, WPD, NCW>(wf, wk);
             if (kb == 0) VDM_STAMP(1);
+            if constexpr (GNP) gn_prologue_inplace<T, G>(lds, gn_tab, a, oz0, oy0, ox0, kb, wave, lane);
             __syncthreads();
             if (kb == 0) VDM_STAMP(2);
             if constexpr (RR) taps_rowreuse<T, G, NC, NV, WPD, NCW>(acc, lds, wk, wf, lanex);
             else taps_pipelined<T, G, NC, NV, WPD, NCW>(acc, lds, wk, wf, lanex);
         } else {
+            if constexpr (GNP) gn_prologue_inplace<T, G>(lds, gn_tab, a, oz0, oy0, ox0, kb, wave, lane);
             __syncthreads();
             taps_rolled<T, G, NC, NV>(acc, lds, wk, lanex);
         }
@@ -293,14 +306,14 @@ __global__ void __launch_bounds__(256, GNB ? 2 : 4) conv_kpack_kernel(const Conv
                                         (tz * a.nty + ty) * a.ntx + tx, chunk * NC * 16, NC * 4);
 }
 
-template <typename T, typename TO, int KS, int STRIDE, int UPS, int NC, int TZ, int TY, bool SPLIT = false, bool GNB = false>
+template <typename T, typename TO, int KS, int STRIDE, int UPS, int NC, int TZ, int TY, bool SPLIT = false, bool GNB = false, bool GNP = false>
 static int launch_fwd_cfg(const ConvArgs& a0, hipStream_t s) {
     using G = Geo<KS, STRIDE, TZ, TY>;
     ConvArgs a = a0;
     if (SPLIT) a.nchunks *= 2;
     a.ntz = cdiv(a.Dz, TZ); a.nty = cdiv(a.Dy, TY); a.ntx = cdiv(a.Dx, 16);
-    const size_t lds = (size_t)((G::HVOX + 15) / 16) * 1024 + GN_SCRATCH_BYTES;
-    auto kern = conv_fwd_kernel<T, TO, KS, STRIDE, UPS, NC, TZ, TY, SPLIT, GNB>;
+    const size_t lds = (size_t)((G::HVOX + 15) / 16) * 1024 + GN_SCRATCH_BYTES + (GNP ? GNP_TABLE_BYTES : 0);
+    auto kern = conv_fwd_kernel<T, TO, KS, STRIDE, UPS, NC, TZ, TY, SPLIT, GNB, GNP>;
     static unsigned long long lds_done = 0;
     {
         int e = set_lds(kern, lds, lds_done);
@@ -335,7 +348,7 @@ static int launch_ksplit(const ConvArgs& a0, hipStream_t s) {
     return VDM_OK;
 }
 
-template <typename T, typename TO, int KS, int STRIDE, int UPS, int NC, bool GNB = false>
+template <typename T, typename TO, int KS, int STRIDE, int UPS, int NC, bool GNB = false, bool GNP = false>
 static int launch_fwd_geo(const ConvArgs& a, hipStream_t s) {
     if constexpr (STRIDE == 2)
         return s2_tile_z() == 1 ? launch_fwd_cfg<T, TO, KS, STRIDE, UPS, NC, 1, 4>(a, s) : launch_fwd_cfg<T, TO, KS, STRIDE, UPS, NC, 2, 4>(a, s);
@@ -343,25 +356,28 @@ static int launch_fwd_geo(const ConvArgs& a, hipStream_t s) {
         int tz, ty;
         small_grid_tile(a, tz, ty);
         if constexpr (NC == 4 && UPS == 0 && sizeof(TO) == 2) {
-            if (ksplit_tile(a, tz, ty)) return ty == 4 ? launch_ksplit<T, TO, 4, 4, GNB>(a, s) : launch_ksplit<T, TO, 4, 8, GNB>(a, s);
+            if (ksplit_tile(a, tz, ty)) {
+                if constexpr (GNP) { set_error("conv_fwd_gn: the K-split kernel has no GroupNorm prologue (vdm_conv_fwd_gn_supported)"); return VDM_ERR_UNSUPPORTED; }
+                else return ty == 4 ? launch_ksplit<T, TO, 4, 4, GNB>(a, s) : launch_ksplit<T, TO, 4, 8, GNB>(a, s);
+            }
             if (uses_split(a, tz, ty)) {
-                if (tz == 1) return ty == 4 ? launch_fwd_cfg<T, TO, KS, STRIDE, UPS, 2, 1, 4, true, GNB>(a, s) : launch_fwd_cfg<T, TO, KS, STRIDE, UPS, 2, 1, 8, true, GNB>(a, s);
-                return launch_fwd_cfg<T, TO, KS, STRIDE, UPS, 2, 2, 8, true, GNB>(a, s);
+                if (tz == 1) return ty == 4 ? launch_fwd_cfg<T, TO, KS, STRIDE, UPS, 2, 1, 4, true, GNB, GNP>(a, s) : launch_fwd_cfg<T, TO, KS, STRIDE, UPS, 2, 1, 8, true, GNB, GNP>(a, s);
+                return launch_fwd_cfg<T, TO, KS, STRIDE, UPS, 2, 2, 8, true, GNB, GNP>(a, s);
             }
         }
-        if (tz == 1) return ty == 4 ? launch_fwd_cfg<T, TO, KS, STRIDE, UPS, NC, 1, 4, false, GNB>(a, s) : launch_fwd_cfg<T, TO, KS, STRIDE, UPS, NC, 1, 8, false, GNB>(a, s);
-        if (tz == 2) return launch_fwd_cfg<T, TO, KS, STRIDE, UPS, NC, 2, 8, false, GNB>(a, s);
-        return launch_fwd_cfg<T, TO, KS, STRIDE, UPS, NC, 4, 8, false, GNB>(a, s);
+        if (tz == 1) return ty == 4 ? launch_fwd_cfg<T, TO, KS, STRIDE, UPS, NC, 1, 4, false, GNB, GNP>(a, s) : launch_fwd_cfg<T, TO, KS, STRIDE, UPS, NC, 1, 8, false, GNB, GNP>(a, s);
+        if (tz == 2) return launch_fwd_cfg<T, TO, KS, STRIDE, UPS, NC, 2, 8, false, GNB, GNP>(a, s);
+        return launch_fwd_cfg<T, TO, KS, STRIDE, UPS, NC, 4, 8, false, GNB, GNP>(a, s);
     } else
-        return launch_fwd_cfg<T, TO, KS, STRIDE, UPS, NC, 4, 8, false, GNB>(a, s);
+        return launch_fwd_cfg<T, TO, KS, STRIDE, UPS, NC, 4, 8, false, GNB, GNP>(a, s);
 }
 
-template <typename T, typename TO, int KS, int STRIDE, int UPS, bool GNB = false>
+template <typename T, typename TO, int KS, int STRIDE, int UPS, bool GNB = false, bool GNP = false>
 static int launch_fwd_nc(const ConvArgs& a, int nc, hipStream_t s) {
     switch (nc) {
-        case 1: return launch_fwd_geo<T, TO, KS, STRIDE, UPS, 1, GNB>(a, s);
-        case 2: return launch_fwd_geo<T, TO, KS, STRIDE, UPS, 2, GNB>(a, s);
-        default: return launch_fwd_geo<T, TO, KS, STRIDE, UPS, 4, GNB>(a, s);
+        case 1: return launch_fwd_geo<T, TO, KS, STRIDE, UPS, 1, GNB, GNP>(a, s);
+        case 2: return launch_fwd_geo<T, TO, KS, STRIDE, UPS, 2, GNB, GNP>(a, s);
+        default: return launch_fwd_geo<T, TO, KS, STRIDE, UPS, 4, GNB, GNP>(a, s);
     }
 }
 
@@ -405,6 +421,12 @@ int launch_fwd_gnb(const ConvArgs& a, int dtype, int nc, hipStream_t s) {
     if (uses_kpack(dtype, 3, 1, 0, a.Cin, a.Cout, 0)) return nc == 1 ? launch_kpack<1, true>(a, s) : launch_kpack<2, true>(a, s);
     if (dtype == VDM_F32) return launch_fwd_nc<float, float, 3, 1, 0, true>(a, nc, s);
     return launch_fwd_nc<bf16_t, bf16_t, 3, 1, 0, true>(a, nc, s);
+}
+
+// forward 3x3x3 stride-1 conv of y = silu(gn(x)) with GroupNorm + SiLU applied to the staged image (ConvArgs::gstats ... set; bf16)
+int launch_fwd_gnp(const ConvArgs& a, int out_f32, int nc, hipStream_t s) {
+    if (out_f32) return launch_fwd_geo<bf16_t, float, 3, 1, 0, 1, false, true>(a, s);
+    return launch_fwd_nc<bf16_t, bf16_t, 3, 1, 0, false, true>(a, nc, s);
 }
 
 }  // namespace vdm

@@ -172,8 +172,15 @@ class Conv:
             return (n, 2 * d, 2 * h, 2 * w, self.cout)
         return (n, d, h, w, self.cout)
 
-    def fwd(self, x, bias=None, nbias=None, residual=None, out=None, gn=False):
-        """out = conv(x) + bias + nbias[n] + residual.  nbias: fp32 [N, >=cout] view (row stride honoured)."""
+    def gn_in_ok(self, x):
+        """Can fwd(..., gn_in=...) apply GroupNorm + SiLU to the staged input (bf16, the generic 3x3x3 stride-1 kernel)?"""
+        shp = self.out_shape(x)
+        return x.dtype == torch.bfloat16 and bool(_lib.lib().vdm_conv_fwd_gn_supported(self.desc(shp[0], shp[1], shp[2], shp[3], x.dtype)))
+
+    def fwd(self, x, bias=None, nbias=None, residual=None, out=None, gn=False, gn_in=None):
+        """out = conv(x) + bias + nbias[n] + residual.  nbias: fp32 [N, >=cout] view (row stride honoured).
+        gn_in = (groups, stats, gamma, beta) (inference, gn_in_ok): the conv input is silu(groupnorm(x)) and the kernel applies it to the
+        staged image itself - no gn_silu_fwd pass, bit-identical result."""
         L = _lib.lib()
         _contig(x, bias, residual)
         assert x.shape[-1] == cpad(self.cin, x.dtype), f"conv input must have {cpad(self.cin, x.dtype)} channels, got {x.shape[-1]}"
@@ -197,7 +204,13 @@ class Conv:
             out.gn_partials = None
             return out
         ev = _pb("conv3" if self.ksize == 3 else "other")
-        check(L.vdm_conv_fwd(d, _p(x), _p(self.wf), _p(bias), _p(nbias), nstride, _p(residual), _p(out), _p(part), _s()), "vdm_conv_fwd")
+        if gn_in is not None:
+            G_, st_, gam_, bet_ = gn_in
+            _contig(st_, gam_, bet_)
+            check(L.vdm_conv_fwd_gn(d, _p(x), _p(self.wf), _p(bias), _p(nbias), nstride, _p(residual), _p(out), _p(part), _p(st_), _p(gam_),
+                                    _p(bet_), int(G_), GN_EPS, _s()), "vdm_conv_fwd_gn")
+        else:
+            check(L.vdm_conv_fwd(d, _p(x), _p(self.wf), _p(bias), _p(nbias), nstride, _p(residual), _p(out), _p(part), _s()), "vdm_conv_fwd")
         out.gn_partials = part
         if ev is not None:
             nvox = shp[0] * shp[1] * shp[2] * shp[3]

@@ -22,6 +22,9 @@ FUSED_GNB = FUSED_GN and os.environ.get("VDM4CDM_FUSED_GNB", "1") != "0"
 GNB_MIN_K = int(os.environ.get("VDM4CDM_GNB_MIN_K", "0"))      # fold only into dgrad convs with at least this many reduction channels
 # the 1x1x1 skip conv of a ResNetBlock rides along with norm1's GroupNorm passes where csrc/gn_skip.hip has a kernel (bf16, narrow layers)
 FUSED_SKIP = os.environ.get("VDM4CDM_FUSED_SKIP", "1") != "0"
+# inference: norm2's GroupNorm + SiLU applied inside conv2 (to the staged halo image) instead of by a pass of its own.  Measured: the
+# VALU work on the 2.1x halo costs the conv what the 5 TB/s pass cost - off by default
+GN_PROLOGUE = os.environ.get("VDM4CDM_GN_PROLOGUE", "0") == "1"
 
 
 class SideStream:
@@ -137,7 +140,8 @@ class _Res:
             a1 = ops.gn_silu_fwd(x1, x2, G, st1, P(n + ".norm1.weight"), P(n + ".norm1.bias"))
         h = self.conv1.fwd(a1, P(n + ".conv1.bias"), table[:, i.table_off:i.table_off + i.cout], gn=FUSED_GN)
         st2 = ops.gn_stats(h, None, G, chsum=save and FUSED_GNB)
-        a2 = ops.gn_silu_fwd(h, None, G, st2, P(n + ".norm2.weight"), P(n + ".norm2.bias"), p, seed, want_mask=save and FUSED_GNB)
+        inside = GN_PROLOGUE and not save and p == 0.0 and self.conv2.gn_in_ok(h)
+        a2 = None if inside else ops.gn_silu_fwd(h, None, G, st2, P(n + ".norm2.weight"), P(n + ".norm2.bias"), p, seed, want_mask=save and FUSED_GNB)
         if ride:
             pass
         elif self.skip1 is not None:
@@ -147,7 +151,10 @@ class _Res:
                 s.record_stream(torch.cuda.current_stream())
         else:
             s = x1
-        out = self.conv2.fwd(a2, P(n + ".conv2.bias"), None, s, gn=FUSED_GN)     # (every block output feeds a GroupNorm)
+        if inside:
+            out = self.conv2.fwd(h, P(n + ".conv2.bias"), None, s, gn=FUSED_GN, gn_in=(G, st2, P(n + ".norm2.weight"), P(n + ".norm2.bias")))
+        else:
+            out = self.conv2.fwd(a2, P(n + ".conv2.bias"), None, s, gn=FUSED_GN)     # (every block output feeds a GroupNorm)
         if save:
             self.saved = (x1, x2, st1, a1, h, st2, a2, p, seed, a2.keep_mask)
         return out
