@@ -889,3 +889,43 @@ def test_conv_fwd_with_groupnorm_prologue(case):
     ref = F.conv3d(yp, wt, bias, padding=0 if circ else 1).permute(0, 2, 3, 4, 1)
     e = (out.float().cpu()[..., :cout] - ref).abs().max().item()
     assert e <= 2 * conv_tol(dtype, ref), f"err {e} > {2 * conv_tol(dtype, ref)}"
+
+
+THIN_CASES = [
+    ("in_2_32", 2, (8, 8, 16), 2, 32, 3, 1, 0, False),
+    ("in_2_32_ragged", 1, (5, 7, 40), 2, 32, 3, 1, 0, False),        # x chunks of 32 + 8 voxels, zero padding
+    ("in_2_32_circ", 1, (4, 6, 20), 2, 32, 3, 1, 0, True),
+    ("in_1_16", 2, (6, 6, 33), 1, 16, 3, 1, 0, False),
+    ("in_2_64_circ", 1, (3, 5, 64), 2, 64, 3, 1, 0, True),
+    ("out_32_1", 2, (8, 8, 16), 32, 1, 3, 1, 0, False),
+    ("out_32_1_ragged_circ", 1, (5, 7, 40), 32, 1, 3, 1, 0, True),
+    ("out_16_1", 1, (6, 6, 33), 16, 1, 3, 1, 0, False),
+    ("out_64_1", 1, (4, 4, 70), 64, 1, 3, 1, 0, False),
+    ("in_2_32_big", 1, (32, 32, 32), 2, 32, 3, 1, 0, False),         # many chunks per wave, every workgroup busy
+]
+
+
+@pytest.mark.parametrize("case", THIN_CASES, ids=[c[0] for c in THIN_CASES])
+def test_wgrad_thin_side(case):
+    """Weight gradient of conv_in / conv_out shaped convs (one side <= 2 channels: csrc/wgrad_thin.hip) against torch.autograd of the
+    reference conv; bf16 storage: 2^-7 of max|dW|; bit-reproducible; the generic kernel (VDM4CDM_NO_THIN_WGRAD) agrees."""
+    dtype = torch.bfloat16
+    ops, conv, x, w, xd = _conv_setup(case, dtype, seed=30)
+    name, N, (D, H, W), cin, cout, ks, stride, ups, circ = case
+    dout = rnd((N, D, H, W, cout), 31, dtype)
+    wr = w.clone().requires_grad_(True)
+    ref_conv(x, wr, None, None, None, ks, stride, ups, circ).backward(dout)
+    dd = torch.zeros((N, D, H, W, ops.cpad(cout, dtype)), dtype=dtype, device=DEV)
+    dd[..., :cout] = dout.to(dtype).to(DEV)
+    dw = torch.full((27, cout, cin), float("nan"), device=DEV)
+    db = torch.full((cout,), float("nan"), device=DEV) if cout > 1 else None
+    conv.wgrad(xd, dd, dw, db)
+    tol = 2.0 ** -7 * max(wr.grad.abs().max().item(), 1e-6)
+    err = (dw.cpu() - wr.grad).abs().max().item()
+    assert err <= tol, f"{name}: wgrad err {err} > {tol}"
+    if db is not None:
+        bref = dout.reshape(-1, cout).sum(0)
+        assert (db.cpu() - bref).abs().max().item() <= 1e-3 * max(bref.abs().max().item(), 1.0) + 1e-3
+    dw2 = torch.zeros_like(dw)
+    conv.wgrad(xd, dd, dw2, torch.zeros_like(db) if db is not None else None)
+    assert torch.equal(dw, dw2)

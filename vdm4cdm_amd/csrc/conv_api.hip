@@ -395,7 +395,13 @@ extern "C" size_t vdm_conv_wgrad_workspace_bytes(const vdm_conv_desc* d) {
     int P = wgrad_wgs() / npairs;
     if (P < 1) P = 1;
     const int slots = d->upsample ? 8 : (taps > 1 ? 1 : 4) * taps;
-    return (size_t)npairs * P * slots * CL * CL * sizeof(float) + (size_t)cdiv(d->cout, CL) * cls * P * CL * sizeof(float);
+    size_t need = (size_t)npairs * P * slots * CL * CL * sizeof(float) + (size_t)cdiv(d->cout, CL) * cls * P * CL * sizeof(float);
+    const int thin = wgrad_thin_mode(d->dtype, d->ksize, d->stride, d->upsample, d->cin, d->cout, false, false);
+    if (thin >= 0) {
+        const size_t t = wgrad_thin_workspace_bytes(d->n, d->od, d->oh, d->ow, thin == 0 ? d->cout : d->cin);
+        need = need > t ? need : t;
+    }
+    return need;
 }
 
 extern "C" int vdm_conv_wgrad(const vdm_conv_desc* d, const void* x, const void* dout, float* dw, float* dbias, int accumulate,
@@ -403,6 +409,13 @@ extern "C" int vdm_conv_wgrad(const vdm_conv_desc* d, const void* x, const void*
     int e = validate(d);
     if (e) return e;
     VDM_REQUIRE(x && dout && dw && workspace, "conv_wgrad: NULL pointer");
+    {   // conv_in / conv_out: one side has <= 2 channels - the (tap, channel) pairs become the MFMA's N dimension (wgrad_thin.hip)
+        static const bool off = getenv("VDM4CDM_NO_THIN_WGRAD") != nullptr;
+        const int thin = off ? -1 : wgrad_thin_mode(d->dtype, d->ksize, d->stride, d->upsample, d->cin, d->cout, dbias != nullptr, accumulate != 0);
+        if (thin >= 0 && !(thin == 1 && dbias) && !(d->pad_mode == VDM_PAD_CIRCULAR && d->ow < 17))
+            return launch_wgrad_thin(thin, x, dout, d->n, d->od, d->oh, d->ow, d->cin, d->cout, d->pad_mode == VDM_PAD_CIRCULAR, dw, dbias, workspace,
+                                     workspace_bytes, (hipStream_t)stream);
+    }
     const int CL = d->dtype == VDM_F32 ? 16 : 32;
     WgradArgs w{};
     fill_dims(w.c, d);

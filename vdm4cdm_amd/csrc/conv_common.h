@@ -1006,6 +1006,11 @@ static void fwd_tile_shape(const ConvArgs& a, int dtype, int out_f32, int ks, in
 int launch_fwd(const ConvArgs& a, int dtype, int out_f32, int ks, int stride, int ups, int nc, hipStream_t s);
 int launch_fwd_gnb(const ConvArgs& a, int dtype, int nc, hipStream_t s);
 int launch_fwd_gnp(const ConvArgs& a, int out_f32, int nc, hipStream_t s);
+// wgrad_thin.hip: weight gradient of conv_in / conv_out (one thin side)
+int wgrad_thin_mode(int dtype, int ksize, int stride, int upsample, int cin, int cout, bool want_bias, bool accumulate);
+size_t wgrad_thin_workspace_bytes(int n, int od, int oh, int ow, int cdense);
+int launch_wgrad_thin(int mode, const void* x, const void* dout, int n, int od, int oh, int ow, int cin, int cout, int circular, float* dw,
+                      float* dbias, void* workspace, size_t workspace_bytes, hipStream_t s);
 int run_cls(const vdm_conv_desc* d, int kind, const void* x, const void* w, const float* bias, const void* res, void* out,
             int cd, int ch, int cw, hipStream_t s, float* gn_partials = nullptr);
 int launch_wgrad_any(const WgradArgs& w, float* dw, float* db, int acc, int cout, int cin, int ks, int stride, int ups, size_t ws,
