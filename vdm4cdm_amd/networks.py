@@ -232,7 +232,7 @@ class CUNet(nn.Module):
         from the optimizer post-step hook, the one launch then runs in the GPU-idle gap while the host prepares the next step."""
         ex = self._exec
         if self.backend == "hip" and ex is not None and ex._packed_key is not None and self.flat.is_cuda:
-            ex.pack_weights(self.flat.detach(), ex._packed_key[3], ex._packed_key[4])
+            ex.pack_weights(self.flat.detach(), ex._packed_key[3], ex._packed_key[4], overlap=True)
 
     def cond_matrix(self, k, flat=None):
         """[sum cout, dim_k] projection matrix of conditioning k for all blocks at once.  `flat` may be the flat vector or its head

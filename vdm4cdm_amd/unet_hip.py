@@ -25,6 +25,8 @@ FUSED_SKIP = os.environ.get("VDM4CDM_FUSED_SKIP", "1") != "0"
 # inference: norm2's GroupNorm + SiLU applied inside conv2 (to the staged halo image) instead of by a pass of its own.  Measured: the
 # VALU work on the 2.1x halo costs the conv what the 5 TB/s pass cost - off by default
 GN_PROLOGUE = os.environ.get("VDM4CDM_GN_PROLOGUE", "0") == "1"
+# the per-step weight re-packing runs on a stream of its own next to the head of the next step (off: on the main stream)
+PACK_OVERLAP = os.environ.get("VDM4CDM_PACK_OVERLAP", "1") != "0"
 
 
 class SideStream:
@@ -331,6 +333,7 @@ class HipUNet:
         self.attn = _Attn(net) if net.mid_attn else None
         self._packed_key = None
         self._pack_plan = None
+        self._pack_stream = self._pack_event = None
         self.saved = None
         self._ss = None
 
@@ -346,8 +349,11 @@ class HipUNet:
             out.extend(self.attn.convs())
         return out
 
-    def pack_weights(self, flat, dtype, need_dgrad):
-        """Re-pack master fp32 weights into MFMA fragment order when the parameters changed."""
+    def pack_weights(self, flat, dtype, need_dgrad, overlap=False):
+        """Re-pack master fp32 weights into MFMA fragment order when the parameters changed.
+        overlap (the optimizer post-step hook): the launch goes to a stream of its own, ordered behind the optimizer step; the next
+        forward waits for it only in front of its first conv, so the head of the next step (noise draws, forward diffusion, input
+        packing, conditioning table) runs next to it instead of behind it."""
         # flat._version alone is NOT enough: fused optimizers (torch._fused_adamw_) update the parameters without bumping the
         # version counter.  net.weights_epoch is bumped by every backward pass of this executor (an optimizer step follows) and by
         # CUNet.mark_weights_dirty() (the optimizer post-step hook LightVDM.configure_optimizers installs).
@@ -359,8 +365,24 @@ class HipUNet:
         pkey = (flat.data_ptr(), dtype, bool(need_dgrad))
         if self._pack_plan is None or self._pack_plan[0] != pkey:         # one launch for all ~120 (conv, form) packings
             self._pack_plan = (pkey, ops.PackPlan([(conv, self.net.view(name, flat)) for conv, name in self._all_convs()], dtype, need_dgrad))
-        self._pack_plan[1].run()
+        if overlap and PACK_OVERLAP and flat.is_cuda and not torch.cuda.is_current_stream_capturing():
+            if self._pack_stream is None or self._pack_stream.device != flat.device:
+                self._pack_stream = torch.cuda.Stream(device=flat.device)
+            self._pack_stream.wait_stream(torch.cuda.current_stream(flat.device))
+            with torch.cuda.stream(self._pack_stream):
+                self._pack_plan[1].run()
+                self._pack_event = torch.cuda.Event()
+                self._pack_event.record(self._pack_stream)
+        else:
+            self._wait_pack()                        # (never two packings in flight)
+            self._pack_plan[1].run()
         self._packed_key = key
+
+    def _wait_pack(self):
+        """The current stream waits for a re-packing that is still running on the pack stream."""
+        if self._pack_event is not None:
+            torch.cuda.current_stream().wait_event(self._pack_event)
+            self._pack_event = None
 
     def enable_ddp(self, world, group=None):
         """Average the gradient over `world` ranks inside backward(), bucket by bucket (see GradBuckets); CUNet.grad_synced tells
@@ -393,6 +415,7 @@ class HipUNet:
         L = len(net.chs)
         ss = self._side_stream(flat.device)
         xin = ops.pack_input(z, s_cond, dtype)
+        self._wait_pack()
         h = self.conv_in.fwd(xin, P("conv_in.bias"), gn=FUSED_GN)
         skips = []
         for i in range(L):
