@@ -381,7 +381,12 @@ class HipUNet:
     def _wait_pack(self):
         """The current stream waits for a re-packing that is still running on the pack stream."""
         if self._pack_event is not None:
-            torch.cuda.current_stream().wait_event(self._pack_event)
+            # Under stream capture the event must NOT be waited for: it was recorded outside the capture (the post-step hook of an
+            # eager step), and a captured wait on uncaptured work leaves a broken graph behind (seen as aborts / segfaults in later
+            # hipFree / rocFFT calls of the same process).  Nothing to wait for either: a capture begins with a device-wide
+            # synchronize, so a re-packing issued before it has finished.
+            if not torch.cuda.is_current_stream_capturing():
+                torch.cuda.current_stream().wait_event(self._pack_event)
             self._pack_event = None
 
     def enable_ddp(self, world, group=None):
