@@ -19,8 +19,8 @@ import sys
 
 def simplify(name):
     """rocprofv3 kernel name -> the key bench.py / hip_ops.py use for the same launch family."""
-    # conv_fwd_kernel<T, TO, KS, STRIDE, UPS, NC, TZ, TY, SPLIT, GNB>
-    m = re.search(r"conv_fwd_kernel<vdm::(\w+), (?:vdm::)?(\w+), (\d), (\d), (\d), (\d), \d+, \d+(?:, (true|false))?(?:, (true|false))?>", name)
+    # conv_fwd_kernel<T, TO, KS, STRIDE, UPS, NC, TZ, TY, SPLIT, GNB, GNP>
+    m = re.search(r"conv_fwd_kernel<vdm::(\w+), (?:vdm::)?(\w+), (\d), (\d), (\d), (\d), \d+, \d+(?:, (true|false))?(?:, (true|false))?(?:, (?:true|false))?>", name)
     if m:
         return (f"conv_fwd_kernel<{m.group(1)},k{m.group(3)},s{m.group(4)},NC{m.group(6)}{',split' if m.group(7) == 'true' else ''}>"
                 + ("+gnb" if m.group(8) == "true" else ""))
