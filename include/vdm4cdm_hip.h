@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define VDM_ABI_VERSION 9
+#define VDM_ABI_VERSION 10
 
 typedef enum { VDM_OK = 0, VDM_ERR_ARG = -1, VDM_ERR_HIP = -2, VDM_ERR_UNSUPPORTED = -3 } vdm_status;
 typedef enum { VDM_F32 = 0, VDM_BF16 = 1 } vdm_dtype;
@@ -199,6 +199,17 @@ int vdm_gn_bwd_apply(const void* x1, int c1, const void* x2, int c2, int n, int6
  *     block output), plus the skip weight gradients dw1 [cout][c1], dw2 [cout][c2] = sum_{n,v} dout x (written, not accumulated;
  *     per-workgroup slabs in `workspace` (vdm_gn_skip_ws_floats floats) + a fixed-order reduce: bit-reproducible).  The skip bias
  *     gradient is the column sum of dout, which vdm_conv_wgrad of the block's second conv already returns. */
+/* The LAST GroupNorm backward of the network (norm1 of the first block) and the weight gradient of conv_in in one pass (bf16): the
+ * tensor vdm_gn_bwd_apply would write there - the gradient at the output of conv_in - has no reader but that weight gradient, so it is
+ * formed in registers (dx = rstd (gamma dyh - m1 - xhat m2) + add, rounded to bf16 like the tensor it replaces) and fed straight into
+ * dw[27][c][thin_c] = sum_v dx[v] (x) thin_x[v + tap], dbias[c] = sum_v dx[v]; dgamma / dbeta as vdm_gn_bwd_apply.  x / dyh / add:
+ * [n][od][oh][ow][c] with c in {16, 32, 64}; thin_x: the conv_in input [n][od][oh][ow][8] (thin_c <= 2 real channels); workspace:
+ * vdm_conv_wgrad_workspace_bytes of conv_in.  Replaces a 3-tensor pass + a write and a read of dx on the exposed tail of the
+ * backward pass. */
+int vdm_gn_bwd_apply_wgrad_thin(const void* x, int c, int n, int od, int oh, int ow, int groups, const float* stats, const float* gamma,
+                                float eps, const void* dyh, const float* red, const float* chan, const void* add, const void* thin_x,
+                                int thin_c, int circular, float* dgamma, float* dbeta, float* dw, float* dbias, void* workspace,
+                                size_t workspace_bytes, void* stream);
 int vdm_gn_skip_supported(int c1, int c2, int cout, int dtype);
 size_t vdm_gn_skip_ws_floats(int c1, int c2, int cout, int n, int64_t voxels);
 int vdm_gn_silu_skip_fwd(const void* x1, int c1, const void* x2, int c2, int n, int64_t voxels, int groups, int dtype,

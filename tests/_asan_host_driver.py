@@ -144,7 +144,12 @@ assert L.vdm_gn_bwd_apply_skip(16, 128, 16, 128, 1, 512, 8, 1, 16, 16, 1e-5, 16,
                                None) == -1 and b"not supported" in L.vdm_last_error()                                   # too wide for the kernels
 assert L.vdm_gn_bwd_apply_skip(16, 32, 16, 32, 1, 512, 8, 1, 16, 16, 1e-5, 16, 16, 16, 16, 16, 16, 32, 16, 16, 16, 16, 16, 16, 16, 10,
                                None) == -1 and b"workspace" in L.vdm_last_error()
-calls += 10
+assert L.vdm_gn_bwd_apply_wgrad_thin(16, 48, 2, 8, 8, 16, 8, 16, 16, 1e-5, 16, 16, 16, None, 16, 2, 0, 16, 16, 16, 16, 16, 1 << 30, None) == -1   # 48 channels
+assert L.vdm_gn_bwd_apply_wgrad_thin(16, 32, 99, 8, 8, 16, 8, 16, 16, 1e-5, 16, 16, 16, None, 16, 2, 0, 16, 16, 16, 16, 16, 1 << 30, None) == -1  # batch > 16
+assert L.vdm_gn_bwd_apply_wgrad_thin(16, 32, 2, 8, 8, 16, 8, 16, 16, 1e-5, 16, 16, 16, None, 16, 2, 1, 16, 16, 16, 16, 16, 1 << 30, None) == -1   # circular, 16 wide
+assert L.vdm_gn_bwd_apply_wgrad_thin(16, 32, 2, 8, 8, 32, 8, 16, 16, 1e-5, 16, 16, 16, None, 16, 2, 0, 16, 16, 16, 16, 16, 64, None) == -1 and b"workspace" in L.vdm_last_error()
+assert L.vdm_gn_bwd_apply_wgrad_thin(None, 32, 2, 8, 8, 32, 8, 16, 16, 1e-5, 16, 16, 16, None, 16, 2, 0, 16, 16, 16, 16, 16, 1 << 30, None) == -1
+calls += 15
 name = (C.c_char * 256)()
 cus, lds = C.c_int(0), C.c_int(0)
 L.vdm_device_info(0, C.byref(cus), C.byref(lds), name)                                 # no GPU here: must fail cleanly

@@ -929,3 +929,44 @@ def test_wgrad_thin_side(case):
     dw2 = torch.zeros_like(dw)
     conv.wgrad(xd, dd, dw2, torch.zeros_like(db) if db is not None else None)
     assert torch.equal(dw, dw2)
+
+
+@pytest.mark.parametrize("case", [(2, (8, 8, 32), 32, 2, False, True), (1, (5, 7, 40), 32, 2, False, False), (1, (4, 6, 36), 16, 1, True, True),
+                                  (3, (3, 4, 70), 64, 2, True, True)], ids=["c32", "c32_ragged_noadd", "c16_circ", "c64_circ"])
+def test_last_groupnorm_backward_feeds_conv_in_wgrad(case):
+    """vdm_gn_bwd_apply_wgrad_thin: norm1's apply pass of the first block + conv_in's weight / bias gradient in one pass == the apply
+    pass followed by the weight-gradient kernel, BIT FOR BIT (dx is rounded to bf16 exactly like the tensor it replaces), and dgamma /
+    dbeta equal."""
+    ops = _ops()
+    dtype = torch.bfloat16
+    N, sp, C, cin, circ, with_add = case
+    G = 8
+    x = (rnd((N,) + sp + (C,), 41) * 1.2 + 0.1).to(dtype).float()
+    dyh = rnd((N,) + sp + (C,), 42, dtype)
+    add = rnd((N,) + sp + (C,), 43, dtype) if with_add else None
+    xin = torch.zeros((N,) + sp + (8,))
+    xin[..., :cin] = rnd((N,) + sp + (cin,), 44, dtype)
+    gamma = 1.0 + 0.3 * rnd((C,), 45)
+    conv_in = ops.Conv(cin, C, 3, circular=circ)
+    dx_, ddyh, dxin = to_dev(x, dtype), to_dev(dyh, dtype), to_dev(xin, dtype)
+    dadd = to_dev(add, dtype) if with_add else None
+    assert ops.gn_tail_ok(conv_in, dx_)
+    st = ops.gn_stats(dx_, None, G)
+    part = ops.channel_dot_sums(ddyh, dx_, None)
+    # reference: apply pass, then the weight gradient
+    d1 = ddyh.clone()
+    d1.gnb_partials = part
+    dg0, db0 = torch.zeros(C, device=DEV), torch.zeros(C, device=DEV)
+    dxr, _ = ops.gn_bwd_fused(dx_, None, G, st, gamma.to(DEV), d1, dg0, db0, add1=dadd)
+    dw0, dbias0 = torch.zeros(27, C, cin, device=DEV), torch.zeros(C, device=DEV)
+    conv_in.wgrad(dxin, dxr, dw0, dbias0)
+    # fused
+    d2 = ddyh.clone()
+    d2.gnb_partials = part
+    dg1, db1 = torch.zeros(C, device=DEV), torch.zeros(C, device=DEV)
+    dw1, dbias1 = torch.full((27, C, cin), 5.0, device=DEV), torch.full((C,), 5.0, device=DEV)
+    out = ops.gn_bwd_fused(dx_, None, G, st, gamma.to(DEV), d2, dg1, db1, add1=dadd, tail=(conv_in, dxin, dw1, dbias1))
+    assert out == (None, None)
+    assert torch.equal(dw0, dw1) and torch.equal(dbias0, dbias1), f"max diff {(dw0 - dw1).abs().max().item()}"
+    assert torch.equal(dg0, dg1) and torch.equal(db0, db1)
+    assert dw1.abs().max().item() > 0

@@ -64,7 +64,7 @@ class AugmentSample(C.Structure):
 PACK_CHUNK = 16384                   # VDM_PACK_CHUNK
 _p, _i, _i64, _u64, _f, _sz = C.c_void_p, C.c_int, C.c_int64, C.c_uint64, C.c_float, C.c_size_t
 _D = C.POINTER(ConvDesc)
-ABI_VERSION = 9                      # VDM_ABI_VERSION of include/vdm4cdm_hip.h this binding was written for
+ABI_VERSION = 10                      # VDM_ABI_VERSION of include/vdm4cdm_hip.h this binding was written for
 
 # name -> (restype, argtypes); mirrors include/vdm4cdm_hip.h one to one
 SIGNATURES = {
@@ -90,6 +90,7 @@ SIGNATURES = {
     "vdm_gn_dyh": (_i, [_p, _i, _p, _i, _i, _i64, _i, _i, _p, _p, _p, _f, _f, _u64, _p, _p, _i, _p, _p]),
     "vdm_gn_bwd_finalize": (_i, [_p, _i, _i, _i, _i, _i64, _p, _p, _f, _p, _p, _p, _p, _i64, _p]),
     "vdm_gn_bwd_apply": (_i, [_p, _i, _p, _i, _i, _i64, _i, _i, _p, _p, _f, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p]),
+    "vdm_gn_bwd_apply_wgrad_thin": (_i, [_p, _i, _i, _i, _i, _i, _i, _p, _p, _f, _p, _p, _p, _p, _p, _i, _i, _p, _p, _p, _p, _p, _sz, _p]),
     "vdm_gn_skip_supported": (_i, [_i, _i, _i, _i]),
     "vdm_gn_skip_ws_floats": (_sz, [_i, _i, _i, _i, _i64]),
     "vdm_gn_silu_skip_fwd": (_i, [_p, _i, _p, _i, _i, _i64, _i, _i, _p, _p, _p, _f, _p, _p, _p, _i, _p, _p, _p]),

@@ -21,6 +21,12 @@ struct ThinArgs {
     const uint32_t* thin;    // [N][Dz][Dy][Dx]: channels 0..1 of the thin tensor, compacted (thin_compact_kernel)
     int N, Dz, Dy, Dx, C, circular;
     float* slabs;            // [gridDim.x][C][80]
+    // GNA (the dense tensor is the RESULT of a GroupNorm backward apply pass that nobody else reads - the gradient at the output of
+    // conv_in): dense = dyh * P + x * Q + R (+ add) is formed in the kernel instead of being written and read back
+    const bf16_t* gx; const bf16_t* gdyh; const bf16_t* gadd;
+    const float* gstats; const float* ggamma; const float* gred; const float* gchan;
+    float* gdgamma; float* gdbeta;
+    int gG; float geps;
 };
 
 constexpr int THIN_COLS = 80;                               // 9 rows x 8 + the ones row (72..79)
@@ -41,7 +47,7 @@ __global__ void __launch_bounds__(256) thin_compact_kernel(const bf16_t* __restr
         out[i] = *reinterpret_cast<const uint32_t*>(t + i * 8);
 }
 
-template <int MT, bool CIRC>                                // MT: 16-channel tiles of the dense tensor; CIRC: circular padding
+template <int MT, bool CIRC, bool GNA = false>              // MT: 16-channel tiles of the dense tensor; CIRC: circular padding
 __global__ void __launch_bounds__(256) wgrad_thin_kernel(const ThinArgs a) {
     constexpr int C = 16 * MT, PD = C * 2 + 16;             // dense tile pitch (bytes)
     constexpr int LROWS = 10;                               // 9 neighbour rows + the ones row
@@ -63,6 +69,31 @@ __global__ void __launch_bounds__(256) wgrad_thin_kernel(const ThinArgs a) {
     for (int m = 0; m < MT; ++m)
 #pragma unroll
         for (int t = 0; t < 5; ++t) acc[m][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+    // GNA: per (sample, channel) constants of dx = dyh * P + x * Q + R (gn_bwd_apply's), <= 16 samples
+    __shared__ float pqr[GNA ? 16 * 16 * MT * 3 : 1];
+    if constexpr (GNA) {
+        const int gs = C / a.gG;
+        const float cnt = (float)a.Dz * a.Dy * a.Dx * gs;
+        for (int i = threadIdx.x; i < a.N * C; i += 256) {
+            const int n = i / C, c = i % C, g = c / gs;
+            const float sum = a.gstats[((size_t)n * a.gG + g) * 2], sq = a.gstats[((size_t)n * a.gG + g) * 2 + 1];
+            const float mean = sum / cnt;
+            const float rstd = rsqrtf(fmaxf(sq / cnt - mean * mean, 0.f) + a.geps);
+            const float m1 = a.gred[((size_t)n * a.gG + g) * 2] / cnt, m2 = a.gred[((size_t)n * a.gG + g) * 2 + 1] / cnt;
+            pqr[i * 3] = rstd * a.ggamma[c];
+            pqr[i * 3 + 1] = -rstd * rstd * m2;
+            pqr[i * 3 + 2] = rstd * (mean * rstd * m2 - m1);
+        }
+        if (blockIdx.x == 0) {                              // GroupNorm parameter gradients: sum over the samples, fixed order
+            for (int c = threadIdx.x; c < C; c += 256) {
+                float db = 0.f, dg = 0.f;
+                for (int k = 0; k < a.N; ++k) { db += a.gchan[((size_t)k * C + c) * 2]; dg += a.gchan[((size_t)k * C + c) * 2 + 1]; }
+                a.gdbeta[c] = db;
+                a.gdgamma[c] = dg;
+            }
+        }
+        __syncthreads();
+    }
 
     const int xch = (a.Dx + 31) / 32;
     const long long nchunks = (long long)a.N * a.Dz * a.Dy * xch;
@@ -85,7 +116,14 @@ __global__ void __launch_bounds__(256) wgrad_thin_kernel(const ThinArgs a) {
         tlive[k] = idx < 9 * 36 && tpp[k] < 34;
     }
     const unsigned uxch = (unsigned)xch, uDy = (unsigned)a.Dy, uDz = (unsigned)a.Dz;
-    auto fetch = [&](unsigned ch, uint4 (&dreg)[2][(MT + 1) / 2], uint32_t (&treg)[6]) {      // (32-bit index arithmetic: the loop is issue-bound)
+    constexpr int KP = (MT + 1) / 2;                        // 16-byte pieces per lane and half chunk
+    struct Regs {
+        uint4 d[2][KP];                                     // the dense chunk (GNA: x)
+        uint4 y[GNA ? 2 : 1][GNA ? KP : 1], ad[GNA ? 2 : 1][GNA ? KP : 1];      // GNA: dyh, residual-path gradient
+        uint32_t t[6];
+        int n;
+    };
+    auto fetch = [&](unsigned ch, Regs& R) {                // (32-bit index arithmetic: the loop is issue-bound)
         const bool live = ch < (unsigned)nchunks;
         unsigned r = live ? ch : 0u;
         const int xc = (int)(r % uxch); r /= uxch;
@@ -93,18 +131,26 @@ __global__ void __launch_bounds__(256) wgrad_thin_kernel(const ThinArgs a) {
         const int z = (int)(r % uDz);
         const int n = (int)(r / uDz);
         const int x0 = xc * 32;
+        R.n = n;
         // dense chunk: lane (v16, q) of half h -> voxel x0 + 16 h + v16, pieces q, q + 4, ...
-        const bf16_t* drow = a.dense + ((((size_t)n * a.Dz + z) * a.Dy + y) * a.Dx) * C;
+        const size_t rowo = ((((size_t)n * a.Dz + z) * a.Dy + y) * a.Dx) * C;
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
             const int x = x0 + 16 * h + v16;
 #pragma unroll
-            for (int k = 0; k < (MT + 1) / 2; ++k) {
+            for (int k = 0; k < KP; ++k) {
                 const int pc = k * 4 + q;
                 // (branch-free: a conditional load compiles to a branch with its own s_waitcnt - clamp the address, select the value)
                 const bool okd = live && x < a.Dx && pc < 2 * MT;
-                const uint4 val = *reinterpret_cast<const uint4*>(drow + (okd ? (size_t)x * C + pc * 8 : (size_t)0));
-                dreg[h][k] = make_uint4(okd ? val.x : 0u, okd ? val.y : 0u, okd ? val.z : 0u, okd ? val.w : 0u);
+                const size_t eo = rowo + (okd ? (size_t)x * C + pc * 8 : (size_t)0);
+                const uint4 val = *reinterpret_cast<const uint4*>((GNA ? a.gx : a.dense) + eo);
+                R.d[h][k] = make_uint4(okd ? val.x : 0u, okd ? val.y : 0u, okd ? val.z : 0u, okd ? val.w : 0u);
+                if constexpr (GNA) {
+                    const uint4 vy = *reinterpret_cast<const uint4*>(a.gdyh + eo);
+                    R.y[h][k] = make_uint4(okd ? vy.x : 0u, okd ? vy.y : 0u, okd ? vy.z : 0u, okd ? vy.w : 0u);
+                    const uint4 va = a.gadd ? *reinterpret_cast<const uint4*>(a.gadd + eo) : make_uint4(0u, 0u, 0u, 0u);
+                    R.ad[h][k] = make_uint4(okd ? va.x : 0u, okd ? va.y : 0u, okd ? va.z : 0u, okd ? va.w : 0u);
+                }
             }
         }
         // thin rows: entry (r9, p) = T[z + dz - 1][y + dy - 1][x0 - 1 + p][0..1], p < 36 (34 used)
@@ -123,30 +169,42 @@ __global__ void __launch_bounds__(256) wgrad_thin_kernel(const ThinArgs a) {
                 ok = ok && (unsigned)zz < (unsigned)a.Dz && (unsigned)yy < (unsigned)a.Dy && (unsigned)xx < (unsigned)a.Dx;
             }
             const uint32_t tv = tn[ok ? ((unsigned)zz * (unsigned)a.Dy + (unsigned)yy) * (unsigned)a.Dx + (unsigned)xx : 0u];
-            treg[k] = ok ? tv : 0u;
+            R.t[k] = ok ? tv : 0u;
         }
     };
     const unsigned cstep = gridDim.x * 4u;
-    uint4 dreg[2][(MT + 1) / 2], dnxt[2][(MT + 1) / 2];
-    uint32_t treg[6], tnxt[6];
+    Regs cur, nxt;
     unsigned ch = blockIdx.x * 4u + wave;
-    fetch(ch, dreg, treg);
+    fetch(ch, cur);
     for (; ch < (unsigned)nchunks; ch += cstep) {
-        fetch(ch + cstep, dnxt, tnxt);
+        fetch(ch + cstep, nxt);
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // (the previous chunk's transposed reads are done)
 #pragma unroll
         for (int h = 0; h < 2; ++h)
 #pragma unroll
             for (int k = 0; k < (MT + 1) / 2; ++k) {
                 const int pc = k * 4 + q;
-                if (pc < 2 * MT) *reinterpret_cast<uint4*>(td + (16 * h + v16) * PD + pc * 16) = dreg[h][k];
+                uint4 val = cur.d[h][k];
+                if constexpr (GNA) {                        // dx = dyh * P + x * Q + R (+ add), rounded to bf16 like the tensor it replaces
+                    const int xv = (int)((ch % uxch) * 32) + 16 * h + v16;
+                    const bool inside = xv < a.Dx && pc < 2 * MT;
+                    Piece<bf16_t> px, pd, pa;
+                    px.load(val);
+                    pd.load(cur.y[h][k]);
+                    pa.load(cur.ad[h][k]);
+                    const float* pq = pqr + ((size_t)cur.n * C + (pc < 2 * MT ? pc * 8 : 0)) * 3;
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) px.f[j] = inside ? fmaf(pd.f[j], pq[j * 3], fmaf(px.f[j], pq[j * 3 + 1], pq[j * 3 + 2])) + pa.f[j] : 0.f;
+                    val = px.store();
+                }
+                if (pc < 2 * MT) *reinterpret_cast<uint4*>(td + (16 * h + v16) * PD + pc * 16) = val;
             }
 #pragma unroll
         for (int k = 0; k < 6; ++k) {
             if (k * 64 + lane < 9 * 36) {
                 const int ro = ((tdz[k] + 1) * 3 + tdy[k] + 1) * THIN_ROWP + tpp[k] * 4;
-                *reinterpret_cast<uint32_t*>(la + ro) = treg[k];
-                if (tpp[k] >= 1) *reinterpret_cast<uint32_t*>(lb + ro - 4) = treg[k];
+                *reinterpret_cast<uint32_t*>(la + ro) = cur.t[k];
+                if (tpp[k] >= 1) *reinterpret_cast<uint32_t*>(lb + ro - 4) = cur.t[k];
             }
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -159,12 +217,7 @@ __global__ void __launch_bounds__(256) wgrad_thin_kernel(const ThinArgs a) {
 #pragma unroll
             for (int t = 0; t < 5; ++t) acc[m][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ad, bt[t], acc[m][t], 0, 0, 0);
         }
-#pragma unroll
-        for (int h = 0; h < 2; ++h)
-#pragma unroll
-            for (int k = 0; k < (MT + 1) / 2; ++k) dreg[h][k] = dnxt[h][k];
-#pragma unroll
-        for (int k = 0; k < 6; ++k) treg[k] = tnxt[k];
+        cur = nxt;
     }
     // workgroup slab [C][80]: the waves add their tiles in wave order through LDS (fixed order)
     float* f = reinterpret_cast<float*>(lds);
@@ -288,4 +341,59 @@ int launch_wgrad_thin(int mode, const void* x, const void* dout, int n, int od, 
     return VDM_OK;
 }
 
+// conv_in's weight gradient with the GroupNorm backward apply pass that produces its dense operand folded in (see ThinArgs)
+int launch_wgrad_thin_gna(const ThinArgs& g, const void* thin_x, int cin, float* dw, float* dbias, void* workspace, size_t workspace_bytes,
+                          hipStream_t s) {
+    ThinArgs a = g;
+    if (workspace_bytes < wgrad_thin_workspace_bytes(a.N, a.Dz, a.Dy, a.Dx, a.C)) {
+        set_error("gn_bwd_apply_wgrad_thin: workspace too small (vdm_conv_wgrad_workspace_bytes of conv_in)");
+        return VDM_ERR_ARG;
+    }
+    const long long nvox = (long long)a.N * a.Dz * a.Dy * a.Dx;
+    const long long nchunks = (long long)a.N * a.Dz * a.Dy * ((a.Dx + 31) / 32);
+    if (nchunks + 4 * 512 >= 0x7fffffffLL || nvox >= 0x7fffffffLL) { set_error("gn_bwd_apply_wgrad_thin: tensor too large"); return VDM_ERR_ARG; }
+    uint32_t* compact = reinterpret_cast<uint32_t*>((char*)workspace + thin_slab_bytes(a.N, a.Dz, a.Dy, a.Dx, a.C));
+    a.slabs = (float*)workspace;
+    a.thin = compact;
+    const int grid = thin_grid(nchunks);
+    const long long cb = (nvox + 256 * 8 - 1) / (256 * 8);
+    hipLaunchKernelGGL(thin_compact_kernel, dim3((unsigned)(cb > 4096 ? 4096 : cb)), dim3(256), 0, s, (const bf16_t*)thin_x, nvox, compact);
+    if (a.circular) {
+        switch (a.C) {
+            case 16: hipLaunchKernelGGL((wgrad_thin_kernel<1, true, true>), dim3(grid), dim3(256), 0, s, a); break;
+            case 32: hipLaunchKernelGGL((wgrad_thin_kernel<2, true, true>), dim3(grid), dim3(256), 0, s, a); break;
+            default: hipLaunchKernelGGL((wgrad_thin_kernel<4, true, true>), dim3(grid), dim3(256), 0, s, a); break;
+        }
+    } else {
+        switch (a.C) {
+            case 16: hipLaunchKernelGGL((wgrad_thin_kernel<1, false, true>), dim3(grid), dim3(256), 0, s, a); break;
+            case 32: hipLaunchKernelGGL((wgrad_thin_kernel<2, false, true>), dim3(grid), dim3(256), 0, s, a); break;
+            default: hipLaunchKernelGGL((wgrad_thin_kernel<4, false, true>), dim3(grid), dim3(256), 0, s, a); break;
+        }
+    }
+    VDM_LAUNCH_CHECK("wgrad_thin_kernel(gna)");
+    hipLaunchKernelGGL(wgrad_thin_reduce_kernel, dim3(a.C * THIN_COLS / 16), dim3(256), 0, s, (const float*)workspace, grid, a.C, 0, cin, dw, dbias);
+    VDM_LAUNCH_CHECK("wgrad_thin_reduce_kernel");
+    return VDM_OK;
+}
+
 }  // namespace vdm
+
+using namespace vdm;
+
+extern "C" int vdm_gn_bwd_apply_wgrad_thin(const void* x, int c, int n, int od, int oh, int ow, int groups, const float* stats,
+                                           const float* gamma, float eps, const void* dyh, const float* red, const float* chan,
+                                           const void* add, const void* thin_x, int thin_c, int circular, float* dgamma, float* dbeta,
+                                           float* dw, float* dbias, void* workspace, size_t workspace_bytes, void* stream) {
+    VDM_REQUIRE(x && stats && gamma && dyh && red && chan && thin_x && dgamma && dbeta && dw && workspace, "gn_bwd_apply_wgrad_thin: NULL pointer");
+    VDM_REQUIRE(c == 16 || c == 32 || c == 64, "gn_bwd_apply_wgrad_thin: 16, 32 or 64 dense channels (got %d)", c);
+    VDM_REQUIRE(n > 0 && n <= 16 && od > 0 && oh > 0 && ow > 0 && od <= 4096 && oh <= 4096 && ow <= 4096, "gn_bwd_apply_wgrad_thin: bad n / dims");
+    VDM_REQUIRE(groups > 0 && groups <= 64 && c % groups == 0, "gn_bwd_apply_wgrad_thin: %d channels / %d groups", c, groups);
+    VDM_REQUIRE(thin_c >= 1 && thin_c <= 2, "gn_bwd_apply_wgrad_thin: the thin side has 1 or 2 channels (got %d)", thin_c);
+    VDM_REQUIRE(!circular || ow >= 17, "gn_bwd_apply_wgrad_thin: circular padding needs at least 17 voxels along x");
+    ThinArgs a{};
+    a.N = n; a.Dz = od; a.Dy = oh; a.Dx = ow; a.C = c; a.circular = circular;
+    a.gx = (const bf16_t*)x; a.gdyh = (const bf16_t*)dyh; a.gadd = (const bf16_t*)add;
+    a.gstats = stats; a.ggamma = gamma; a.gred = red; a.gchan = chan; a.gdgamma = dgamma; a.gdbeta = dbeta; a.gG = groups; a.geps = eps;
+    return launch_wgrad_thin_gna(a, thin_x, thin_c, dw, dbias, workspace, workspace_bytes, (hipStream_t)stream);
+}

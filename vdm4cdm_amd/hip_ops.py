@@ -455,9 +455,19 @@ def gn_silu_bwd(x1, x2, groups, stats, gamma, beta, dy, dgamma, dbeta, add1=None
     return out
 
 
-def gn_bwd_fused(x1, x2, groups, stats, gamma, dyh, dgamma, dbeta, add1=None, add2=None, colsum=None, dx1=None, dx2=None, skip=None):
+def gn_tail_ok(conv_in, x):
+    """Can the last GroupNorm backward + conv_in's weight gradient run as one pass (gn_bwd_fused(..., tail=...))?  bf16, 16 / 32 / 64
+    channels, <= 2 input channels of conv_in, batch <= 16."""
+    return (x.dtype == torch.bfloat16 and x.shape[-1] in (16, 32, 64) and conv_in.ksize == 3 and conv_in.stride == 1 and not conv_in.upsample
+            and conv_in.cin <= 2 and conv_in.cout == x.shape[-1] and x.shape[0] <= 16 and (not conv_in.circular or x.shape[3] >= 17)
+            and "VDM4CDM_NO_THIN_WGRAD" not in _os.environ and _os.environ.get("VDM4CDM_FUSED_TAIL", "1") != "0")
+
+
+def gn_bwd_fused(x1, x2, groups, stats, gamma, dyh, dgamma, dbeta, add1=None, add2=None, colsum=None, dx1=None, dx2=None, skip=None, tail=None):
     """Second half of the GroupNorm+SiLU backward after Conv.dgrad_gn (dyh carries `.gnb_partials`).  Writes dgamma / dbeta,
     colsum (optional [N, >=C] fp32 view, row stride honoured; needs stats.chsum) and returns (dx1, dx2).  No float atomics.
+    tail = (conv_in, xin, dw, dbias) (gn_tail_ok): x1 is the output of conv_in - its gradient is not written but folded straight into
+    conv_in's weight / bias gradient (returns (None, None)).
     skip = (dout, w1, w2, dw1, dw2): the block's 1x1x1 skip conv rides along (gn_skip_supported(...)[1]): W^T dout is added to dx and
     the skip weight gradients dw1 / dw2 are written in the same pass (instead of add1 / add2 from a separate dgrad conv)."""
     L = _lib.lib()
@@ -475,13 +485,31 @@ def gn_bwd_fused(x1, x2, groups, stats, gamma, dyh, dgamma, dbeta, add1=None, ad
         assert colsum.dtype == torch.float32 and colsum.stride(1) == 1 and colsum.shape[0] == n
         cstride, chsum = colsum.stride(0), getattr(stats, "chsum", None)
         assert chsum is not None, "gn_bwd_fused: colsum needs the per-channel sums (gn_stats(..., chsum=True))"
-    if dx1 is None:
+    if dx1 is None and tail is None:
         dx1 = dyh if x2 is None else torch.empty_like(x1)
     if x2 is not None and dx2 is None:
         dx2 = torch.empty_like(x2)
     ev = _pb()
     check(L.vdm_gn_bwd_finalize(_p(part), part.shape[1], n, C_, groups, v, _p(stats), _p(gamma), GN_EPS, _p(chsum), _p(red), _p(chan),
                                 _p(colsum), cstride, _s()), "vdm_gn_bwd_finalize")
+    if tail is not None:           # the last GroupNorm of the backward pass: dx feeds only conv_in's weight gradient - never written
+        conv_in, xin, dw, dbias = tail
+        assert x2 is None and add2 is None and skip is None
+        _contig(xin, dw, dbias, add1)
+        n_, od, oh, ow, _ = x1.shape
+        d = conv_in.desc(n_, od, oh, ow, x1.dtype)
+        need = L.vdm_conv_wgrad_workspace_bytes(d)
+        wkey = (x1.device, _s())
+        ws = Conv._ws.get(wkey)
+        if ws is None or ws.numel() < need:
+            ws = torch.empty(max(need, 32 << 20), dtype=torch.uint8, device=x1.device)
+            Conv._ws[wkey] = ws
+        if "gn_apply" not in ABLATE and "wgrad" not in ABLATE:
+            check(L.vdm_gn_bwd_apply_wgrad_thin(_p(x1), c1, n, od, oh, ow, groups, _p(stats), _p(gamma), GN_EPS, _p(dyh), _p(red), _p(chan), _p(add1),
+                                                _p(xin), conv_in.cin, 1 if conv_in.circular else 0, _p(dgamma), _p(dbeta), _p(dw), _p(dbias), _p(ws),
+                                                ws.numel(), _s()), "vdm_gn_bwd_apply_wgrad_thin")
+        _pe(ev, "gn_bwd(finalize+apply)", 2.0 * n * v * 27 * conv_in.cin * c1, (2.0 + (1.0 if add1 is not None else 0.0)) * dyh.numel() * dyh.element_size())
+        return None, None
     if skip is not None:
         assert add1 is None and add2 is None
         dout, w1, w2, dw1, dw2 = skip

@@ -161,9 +161,10 @@ class _Res:
             self.saved = (x1, x2, st1, a1, h, st2, a2, p, seed, a2.keep_mask)
         return out
 
-    def bwd(self, P, GP, dout, dtable, ss):
+    def bwd(self, P, GP, dout, dtable, ss, tail=None):
         """dout: gradient of the block output.  Returns (dx1, dx2).  Fills parameter grads via GP(name).
-        ss: SideStream for the weight-gradient kernels."""
+        ss: SideStream for the weight-gradient kernels.  tail = (conv_in, xin, dw, dbias) (first block of the network, when
+        ops.gn_tail_ok): the block's input gradient is not materialised, conv_in's weight gradient comes out of norm1's apply pass."""
         i, G, n = self.i, self.net.norm_groups, self.i.name
         x1, x2, st1, a1, h, st2, a2, p, seed, mask2 = self.saved
         self.saved = None
@@ -220,7 +221,7 @@ class _Res:
             add1 = dout
         if fused:
             return ops.gn_bwd_fused(x1, x2, G, st1, P(n + ".norm1.weight"), dyh1, GP(n + ".norm1.weight"), GP(n + ".norm1.bias"),
-                                    add1=add1, add2=add2)
+                                    add1=add1, add2=add2, tail=tail if (tail is not None and x2 is None and add2 is None) else None)
         return ops.gn_silu_bwd(x1, x2, G, st1, P(n + ".norm1.weight"), P(n + ".norm1.bias"), da1,
                                GP(n + ".norm1.weight"), GP(n + ".norm1.bias"), add1=add1, add2=add2)
 
@@ -493,8 +494,12 @@ class HipUNet:
                 ss.run(lambda i=i, dh=dh: self.down[i].wgrad(skips[i], dh, GP(f"downs.{i}.down.weight"), GP(f"downs.{i}.down.bias")),
                        skips[i], dh)
                 dh = self.down[i].dgrad(dh, residual=dskips[i])      # per-parity-class conv: no zero-dilated intermediate
-            dh, _ = self.res[f"downs.{i}.block"].bwd(P, GP, dh, dtable, ss)
-        ss.run(lambda: self.conv_in.wgrad(xin, dh, GP("conv_in.weight"), GP("conv_in.bias")), xin, dh)
+            tail = None
+            if i == 0 and FUSED_GNB and self.res["downs.0.block"].skip1 is None and ops.gn_tail_ok(self.conv_in, self.res["downs.0.block"].saved[0]):
+                tail = (self.conv_in, xin, GP("conv_in.weight"), GP("conv_in.bias"))      # the last apply pass + conv_in's weight gradient: one pass
+            dh, _ = self.res[f"downs.{i}.block"].bwd(P, GP, dh, dtable, ss, tail=tail)
+        if dh is not None:
+            ss.run(lambda: self.conv_in.wgrad(xin, dh, GP("conv_in.weight"), GP("conv_in.bias")), xin, dh)
         # (the K6 backward only needs dtable - complete since the last block - and writes its own slice of gflat: it runs on the main
         # stream WHILE the side stream finishes the conv_in weight gradient, instead of behind the join)
         if cond is not None:      # K6 backward: conditioning MLPs + projections + the conv1 biases (column sums of dtable), 3 launches
