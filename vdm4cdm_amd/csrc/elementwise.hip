@@ -193,12 +193,20 @@ __device__ __forceinline__ void tile_partials_fold(const float2* __restrict__ p2
 // GroupNorm statistics from those partials: part[n][tile][C][2] -> stats[n][g0 + g][k] = sum over tiles and over the gs channels of
 // group g.  One block per (sample, group).  chsum (optional): the per-channel sums chsum[n][c0 + c] = sum_v x[n][v][c] (the analytic
 // column sums of the GroupNorm backward need them).
+// Two sources (a skip concat whose halves were produced by two convs) in ONE launch: blocks [0, C / gs) of a sample take source 1,
+// the following C2 / gs blocks source 2 (part2 == nullptr: one source).
 template <int NT>
 __global__ void __launch_bounds__(NT) gn_stats_from_partials_kernel(const float* __restrict__ part, int tiles, int C, int gs, int G,
                                                                     int g0, float* __restrict__ stats, float* __restrict__ chsum,
-                                                                    int chsum_stride, int c0) {
-    const int gc = C / gs;
-    const int n = blockIdx.x / gc, g = blockIdx.x % gc;
+                                                                    int chsum_stride, int c0, const float* __restrict__ part2, int tiles2,
+                                                                    int C2) {
+    const int gc1 = C / gs, gcs = gc1 + (part2 ? C2 / gs : 0);
+    const int n = blockIdx.x / gcs;
+    int g = blockIdx.x % gcs;
+    if (g >= gc1) {                                        // (uniform per block) second source: its groups follow the first one's
+        g -= gc1; g0 += gc1; c0 += C;
+        part = part2; tiles = tiles2; C = C2;
+    }
     const float2* p2 = reinterpret_cast<const float2*>(part) + (size_t)n * tiles * C + (size_t)g * gs;
     __shared__ float sm[2][NT];
     tile_partials_fold<NT>(p2, tiles, C, gs, sm);
@@ -792,11 +800,17 @@ extern "C" int vdm_gn_stats(const void* x1, int c1, const void* x2, int c2, int 
     const float* parts[2] = {part1, part2};
     const int tiles[2] = {tiles1, tiles2};
     int g0 = 0;
+    if (parts[0] && c2 > 0 && parts[1]) {                  // both halves of a concat come with conv partials: one launch
+        hipLaunchKernelGGL(gn_stats_from_partials_kernel<256>, dim3(n * ((c1 + c2) / gs)), dim3(256), 0, s, parts[0], tiles[0], c1, gs, groups, 0, stats,
+                           chsum, c1 + c2, 0, parts[1], tiles[1], c2);
+        VDM_LAUNCH_CHECK("gn_stats_from_partials_kernel");
+        return VDM_OK;
+    }
     for (int k = 0; k < 2; ++k) {
         if (cs[k] == 0) continue;
         if (parts[k]) {                                   // statistics already reduced per tile by the producing conv
             hipLaunchKernelGGL(gn_stats_from_partials_kernel<256>, dim3(n * (cs[k] / gs)), dim3(256), 0, s, parts[k], tiles[k], cs[k], gs, groups, g0,
-                               stats, chsum, c1 + c2, g0 * gs);
+                               stats, chsum, c1 + c2, g0 * gs, (const float*)nullptr, 0, 0);
             VDM_LAUNCH_CHECK("gn_stats_from_partials_kernel");
             g0 += cs[k] / gs;
             continue;
