@@ -297,6 +297,30 @@ __global__ void __launch_bounds__(256) wgrad_reduce_kernel(const float* __restri
         dw[i] = accumulate ? dw[i] + tot : tot;
     }
 }
+// Few slabs per output (the deep levels: 8 - 32 persistent workgroups per channel-block pair, but millions of outputs): the grouped
+// form above launches 27 648 blocks of two loads per thread - 1.8 TB/s.  One thread per output walks all its slabs (8 loads in flight,
+// fixed order), 256 outputs per block.
+__global__ void __launch_bounds__(256) wgrad_reduce_direct_kernel(const float* __restrict__ slabs, float* __restrict__ dw, int taps,
+                                                                 int cout, int cin, int ncb, int nkb, int CL, int nslabs, int accumulate) {
+    const int total = taps * cout * cin;
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= total) return;
+    const int ci = i % cin, co = (i / cin) % cout, tap = i / (cin * cout);
+    const int pair = (co / CL) * nkb + ci / CL;
+    const size_t slab_elems = (size_t)taps * CL * CL;
+    const float* s = slabs + (size_t)pair * nslabs * slab_elems + ((size_t)tap * CL + co % CL) * CL + ci % CL;
+    float sum = 0.f;
+    int k = 0;
+    for (; k + 7 < nslabs; k += 8) {
+        float v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[u] = s[(size_t)(k + u) * slab_elems];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) sum += v[u];
+    }
+    for (; k < nslabs; ++k) sum += s[(size_t)k * slab_elems];
+    dw[i] = accumulate ? dw[i] + sum : sum;
+}
 __global__ void __launch_bounds__(256) wgrad_bias_reduce_kernel(const float* __restrict__ bslabs, float* __restrict__ dbias, int cout,
                                                                int CL, int P, int accumulate) {
     const int c = threadIdx.x & 15, gp = threadIdx.x >> 4;
@@ -377,8 +401,13 @@ static int launch_wgrad_cfg(WgradArgs w, float* dw, float* dbias, int accumulate
     static const bool no_reduce = getenv("VDM4CDM_ABLATE_REDUCE") != nullptr;      // timing ablation only (wrong results)
     if (no_reduce) return VDM_OK;
     const int total = G::TAPS * cout * cin;
-    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(cdiv(total, WRED_OUT)), dim3(256), 0, s,
-                       (const float*)w.slabs, dw, G::TAPS, cout, cin, w.ncb, w.nkb, CL, P * per_wg, accumulate);
+    static const bool grouped_only = getenv("VDM4CDM_GROUPED_REDUCE") != nullptr;
+    if (P * per_wg <= 32 && !grouped_only)
+        hipLaunchKernelGGL(wgrad_reduce_direct_kernel, dim3(cdiv(total, 256)), dim3(256), 0, s,
+                           (const float*)w.slabs, dw, G::TAPS, cout, cin, w.ncb, w.nkb, CL, P * per_wg, accumulate);
+    else
+        hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(cdiv(total, WRED_OUT)), dim3(256), 0, s,
+                           (const float*)w.slabs, dw, G::TAPS, cout, cin, w.ncb, w.nkb, CL, P * per_wg, accumulate);
     VDM_LAUNCH_CHECK("wgrad_reduce_kernel");
     if (dbias) {
         hipLaunchKernelGGL(wgrad_bias_reduce_kernel, dim3(cdiv(cout, 16)), dim3(256), 0, s, (const float*)w.bslabs, dbias, cout, CL, P, accumulate);
