@@ -336,7 +336,7 @@ class HipUNet:
         self.attn = _Attn(net) if net.mid_attn else None
         self._packed_key = None
         self._pack_plan = None
-        self._pack_stream = self._pack_event = None
+        self._pack_stream = self._pack_event = self._pack_event_obj = None
         self.saved = None
         self._ss = None
 
@@ -374,8 +374,10 @@ class HipUNet:
             self._pack_stream.wait_stream(torch.cuda.current_stream(flat.device))
             with torch.cuda.stream(self._pack_stream):
                 self._pack_plan[1].run()
-                self._pack_event = torch.cuda.Event()
-                self._pack_event.record(self._pack_stream)
+                if self._pack_event_obj is None:         # ONE event per executor, never destroyed while a stream may still wait on it
+                    self._pack_event_obj = torch.cuda.Event()
+                self._pack_event_obj.record(self._pack_stream)
+                self._pack_event = self._pack_event_obj
         else:
             self._wait_pack()                        # (never two packings in flight)
             self._pack_plan[1].run()
