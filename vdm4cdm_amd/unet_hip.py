@@ -27,7 +27,8 @@ FUSED_SKIP = os.environ.get("VDM4CDM_FUSED_SKIP", "1") != "0"
 GN_PROLOGUE = os.environ.get("VDM4CDM_GN_PROLOGUE", "0") == "1"
 # Opt-in experiment: the per-step weight re-packing on a stream of its own, next to the head of the next step (-0.05 ms per step).
 # OFF by default: with it, 3 of 5 runs of the whole GPU test suite in one process died in a later rocFFT / hipFree call (0 of 2
-# without it) - a captured wait on the hook's event was one cause (fixed in _wait_pack), a second one was not found.
+# without it) - a captured wait on the hook's event was one cause (fixed in _wait_pack); the buffers the launch touches were
+# not recorded on the pack stream (fixed below, see pack_weights); the default stays off.
 PACK_OVERLAP = os.environ.get("VDM4CDM_PACK_OVERLAP", "0") == "1"
 
 
@@ -372,6 +373,12 @@ class HipUNet:
             if self._pack_stream is None or self._pack_stream.device != flat.device:
                 self._pack_stream = torch.cuda.Stream(device=flat.device)
             self._pack_stream.wait_stream(torch.cuda.current_stream(flat.device))
+            # every tensor the launch touches is handed to the pack stream: without record_stream the caching allocator may give a
+            # freed buffer (a net deleted right after its last step) to a new owner on the main stream while the re-packing - queued
+            # behind the whole step - has not yet run: a write into somebody else's memory
+            plan = self._pack_plan[1]
+            for t in [flat, plan.items, plan.chunks] + [b for conv, _ in self._all_convs() for b in (conv.wf, conv.wd) if b is not None]:
+                t.record_stream(self._pack_stream)
             with torch.cuda.stream(self._pack_stream):
                 self._pack_plan[1].run()
                 if self._pack_event_obj is None:         # ONE event per executor, never destroyed while a stream may still wait on it
