@@ -26,7 +26,7 @@ FUSED_SKIP = os.environ.get("VDM4CDM_FUSED_SKIP", "1") != "0"
 # VALU work on the 2.1x halo costs the conv what the 5 TB/s pass cost - off by default
 GN_PROLOGUE = os.environ.get("VDM4CDM_GN_PROLOGUE", "0") == "1"
 # Opt-in experiment: the per-step weight re-packing on a stream of its own, next to the head of the next step (-0.05 ms per step).
-# OFF by default: with it, 3 of 5 runs of the whole GPU test suite in one process died in a later rocFFT / hipFree call (0 of 2
+# OFF by default: with it, 4 of 6 runs of the whole GPU test suite in one process died in a later rocFFT / hipFree call (0 of 4
 # without it) - a captured wait on the hook's event was one cause (fixed in _wait_pack); the buffers the launch touches were
 # not recorded on the pack stream (fixed below, see pack_weights); the default stays off.
 PACK_OVERLAP = os.environ.get("VDM4CDM_PACK_OVERLAP", "0") == "1"
