@@ -19,8 +19,9 @@ def main():
     out = sys.argv[1]
     rank = int(os.environ["RANK"])
     torch.manual_seed(42)
-    net = CUNet(shape=(1, 16, 16, 16), chs=[16, 32], s_conditioning_channels=1, v_conditioning_dims=[6], norm_groups=8,
-                dropout_prob=0.1, backend="hip", precision="fp32")
+    precision = os.environ.get("DDP_PRECISION", "fp32")     # bf16: the fused skip / tail kernels run under the gradient buckets too
+    net = CUNet(shape=(1, 16, 16, 16), chs=[16, 32] if precision == "fp32" else [32, 64], s_conditioning_channels=1, v_conditioning_dims=[6],
+                norm_groups=8, dropout_prob=0.1, backend="hip", precision=precision)
     # rank-dependent initial weights: the broadcast from rank 0 must make them identical
     net.reset_parameters(generator=torch.Generator().manual_seed(42 + rank), zero_init_std=0.02)
     vdm = LightVDM(score_model=net, gamma_max=13.3, learning_rate=1e-3)

@@ -183,19 +183,25 @@ def _spawn_ranks(cmd, world, port, tmp_path, extra_env=None, timeout=900):
     return outs
 
 
-def test_hip_training_two_ranks_share_one_gpu(tmp_path):
-    """SURVEY 8e with HIP kernels AND a world-2 process group in the same processes (two ranks on the one GPU of the box, gloo):
-    weights are broadcast from rank 0, each rank draws its own data shard / noise, the backward all-reduces the four gradient buckets
-    on the communication stream, and after 3 steps both ranks hold bit-identical parameters that differ from a single-rank run."""
+@pytest.mark.parametrize("world,precision", [(2, "fp32"), (3, "bf16")], ids=["world2_fp32", "world3_bf16"])
+def test_hip_training_two_ranks_share_one_gpu(tmp_path, world, precision, monkeypatch):
+    """SURVEY 8e with HIP kernels AND a process group in the same processes (2 / 3 ranks on the one GPU of the box, gloo): weights
+    are broadcast from rank 0, each rank draws its own data shard / noise (16 training cubes over 3 ranks: the wrap-around padding), the
+    backward all-reduces the four gradient buckets on the communication stream, and after 3 steps all ranks hold bit-identical
+    parameters.  world 3 runs bf16 storage: the skip convs folded into the GroupNorm passes and the fused tail write their gradients
+    from the main stream under the buckets."""
     import socket
     with socket.socket() as sk:
         sk.bind(("127.0.0.1", 0))
         port = sk.getsockname()[1]
-    _spawn_ranks([sys.executable, os.path.join(ROOT, "tests", "_ddp_gpu2_worker.py"), str(tmp_path)], 2, port, tmp_path)
-    o0, o1 = torch.load(tmp_path / "out0.pt"), torch.load(tmp_path / "out1.pt")
-    assert o0["world"] == o1["world"] == 2 and o0["bucketed"] and o1["bucketed"]
-    assert torch.isfinite(o0["flat"]).all() and torch.equal(o0["flat"], o1["flat"]), "ranks diverged"
-    assert o0["loss"] != o1["loss"], "both ranks saw the same batch / noise"
+    monkeypatch.setenv("DDP_PRECISION", precision)
+    _spawn_ranks([sys.executable, os.path.join(ROOT, "tests", "_ddp_gpu2_worker.py"), str(tmp_path)], world, port, tmp_path)
+    outs = [torch.load(tmp_path / f"out{r}.pt") for r in range(world)]
+    assert all(o["world"] == world and o["bucketed"] for o in outs)
+    assert torch.isfinite(outs[0]["flat"]).all()
+    for o in outs[1:]:
+        assert torch.equal(outs[0]["flat"], o["flat"]), "ranks diverged"
+    assert len({tuple(o["loss"]) for o in outs}) == world, "two ranks saw the same batch / noise"
 
 
 def test_bench_two_ranks_share_one_gpu(tmp_path):
