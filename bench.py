@@ -107,6 +107,60 @@ def cpu_baseline(chs):
                       f"{med(t128):.2f} s (warm-up {w128:.1f} s); C2 64^3 batch 2 {med(t64):.2f} s (warm-up {w64:.1f} s)"}
 
 
+def sample_leg(args, vdm, batch, D, device, rank, world):
+    """One `--sample-steps`-step chain of one 128^3 cube PER RANK (hipGraph-captured denoise step, in-kernel Philox noise).  Returns the
+    "sample" object on rank 0 (None elsewhere; every rank gets {"error": ...} if any chain failed).  N = 1: exactly the round-3 leg
+    (seed 1234, z_1 from the global generator); N > 1: chain id = rank, seed = entry.chain_seed(rank) for the chain AND its z_1."""
+    import torch.distributed as dist
+    from vdm4cdm_amd.entry import chain_seed
+    res, err = {}, None
+    try:
+        vdm.eval()
+        s = batch["conditioning"][:1]
+        v = [batch["conditioning_values"][0][:1]]
+        vdm.draw_samples(batch_size=1, n_sampling_steps=3, s_conditioning=s, v_conditionings=v)
+        seed = 1234 if world == 1 else chain_seed(rank)
+        if world == 1:
+            z1 = torch.randn(1, 1, D, D, D, device=device)          # z_1 ~ N(0, I), resident before the clock starts
+        else:
+            z1 = torch.randn(1, 1, D, D, D, device=device, generator=torch.Generator(device=device).manual_seed(seed))
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        t1 = time.perf_counter()
+        z = vdm.draw_samples(batch_size=1, n_sampling_steps=args.sample_steps, z=z1, s_conditioning=s, v_conditionings=v, seed=seed)
+        torch.cuda.synchronize()
+        secs = time.perf_counter() - t1
+        res = {"seconds": secs, "finite": bool(torch.isfinite(z).all()), "std": float(z.std()), "mean": float(z.mean()), "seed": seed}
+        if not res["finite"]:
+            raise RuntimeError(f"the {args.sample_steps}-step sample of rank {rank} is not finite")
+    except Exception as e:                                  # never lose the training line over the secondary measurement
+        err = repr(e)
+    per = [dict(res, error=err) if err else res]
+    if world > 1:
+        per = [None] * world
+        dist.all_gather_object(per, dict(res, error=err) if err else res)
+    if rank != 0:
+        return {"error": "a chain failed"} if any("error" in p for p in per) else None
+    out = {"steps": args.sample_steps, "cube": D, "batch": 1, "chains": world}
+    bad = [(r, p["error"]) for r, p in enumerate(per) if "error" in p]
+    if bad:
+        out["error"] = f"(rank, error): {bad}"
+        return out
+    smax = max(p["seconds"] for p in per)
+    out.update(seconds=smax, steps_per_s=args.sample_steps / smax, finite=all(p["finite"] for p in per), std=per[0]["std"], mean=per[0]["mean"],
+               seconds_max=smax, seconds_per_rank=[p["seconds"] for p in per], seeds=[p["seed"] for p in per],
+               std_per_rank=[p["std"] for p in per], aggregate_steps_per_s=world * args.sample_steps / smax,
+               note="one chain per rank (independent cubes, no collective), started together; hipGraph-captured denoise step, in-kernel "
+                    "Philox noise; seconds = the slowest chain, aggregate = chains * steps / that")
+    if args.config == "c256":      # context only (BASELINE.md section 1): the one rate the reference publishes, other hardware
+        out["reference_published"] = {
+            "value": 2.50, "unit": "denoise steps/s", "steps": 250, "cube": 256, "chs": [16, 32, 64, 128],
+            "hardware": "one NVIDIA GPU of the 80 GB class (model not stated)",
+            "source": "/root/reference ICML_figures.ipynb cell 103 (tqdm rate), configs.yaml:127-143, generate_3D.py:61"}
+    return out
+
+
 def self_spawn(n, argv):
     """`python bench.py --gpus N` (N > 1) outside torchrun: start the N ranks as fresh child processes of this one - which has not
     made a single HIP call (and never execs after one) - with the torchrun environment on 127.0.0.1, forward rank 0's stdout (the
@@ -196,7 +250,7 @@ def main():
         opt.step()
         return loss
 
-    loss, prof, elapsed, ms_per_step, value = None, None, 0.0, None, None
+    loss, prof, elapsed, ms_per_step, value, per_rank_s = None, None, 0.0, None, None, []
     if not args.sample_only:
         for _ in range(2):      # setup, not warm-up: sizes the caching allocator's pools (main + side streams) and packs the weights once
             step()
@@ -227,11 +281,22 @@ def main():
         loss = float(loss.detach())          # (drop the autograd graph of the last eager step: a live AccumulateGrad node bound to the
                                              # default stream would be run inside the stream capture of the graphed step below)
         el = torch.tensor([elapsed], device=device, dtype=torch.float64)
+        per_rank_s = [elapsed]
         if world > 1:
+            gathered = [torch.zeros_like(el) for _ in range(world)]
+            dist.all_gather(gathered, el)                    # every rank's own clock around the same K steps: a straggler shows
+            per_rank_s = [g.item() for g in gathered]
             dist.all_reduce(el, op=dist.ReduceOp.MAX)
         elapsed = el.item()
         ms_per_step = 1e3 * elapsed / args.steps
         value = world * B * D ** 3 * args.steps / elapsed
+
+    # Second half of the BASELINE metric: the n-step reverse-diffusion sample.  EVERY rank runs its own chain (independent cubes shard over
+    # the GPUs with no collective - /root/reference/generate_3D.py:43-68, the reference's 6-process fan-out), seeded by its global chain
+    # id as entry.generate_3d does; the ranks start together (barrier) and rank 0 reports the slowest chain and the aggregate rate.
+    sample_res = None
+    if args.sample_steps:
+        sample_res = sample_leg(args, vdm, batch, D, device, rank, world)
 
     if rank == 0:
         scale = 1.0 if chs == [32, 64, 128, 256] else None
@@ -244,6 +309,9 @@ def main():
                        "global_batch": world * B, "cube": D, "parallelism": f"dp{world}"},
             "loss": loss,
         }
+        if per_rank_s and not args.sample_only:
+            out["ms_per_step_per_rank"] = {"min": 1e3 * min(per_rank_s) / args.steps, "max": 1e3 * max(per_rank_s) / args.steps,
+                                           "all": [1e3 * t / args.steps for t in per_rank_s]}
         roof = {}
         if prof is not None:
             agg = prof.summary()
@@ -306,6 +374,7 @@ def main():
             # replays.  `value` above stays the eager run - its kernels carry the per-launch events of the roofline object.
             try:
                 from vdm4cdm_amd.trainer import GraphedTrainStep
+                vdm.train()                                  # (the sampling leg above left the model in eval mode)
                 gs = GraphedTrainStep(vdm, opt, params, 0.5, batch)
                 for _ in range(max(args.warmup, 2)):
                     gs(batch)
@@ -321,40 +390,16 @@ def main():
             except Exception as e:                          # never lose the eager line over the extra measurement
                 out["graph_step"] = {"error": repr(e)}
                 hip_ops.SEED_STEP = None
-        if args.sample_steps:
-            try:
-                vdm.eval()
-                s = batch["conditioning"][:1]
-                v = [batch["conditioning_values"][0][:1]]
-                vdm.draw_samples(batch_size=1, n_sampling_steps=3, s_conditioning=s, v_conditionings=v)
-                z1 = torch.randn(1, 1, D, D, D, device=device)          # z_1 ~ N(0, I), resident before the clock starts
-                torch.cuda.synchronize()
-                t1 = time.perf_counter()
-                z = vdm.draw_samples(batch_size=1, n_sampling_steps=args.sample_steps, z=z1, s_conditioning=s, v_conditionings=v, seed=1234)
-                torch.cuda.synchronize()
-                secs = time.perf_counter() - t1
-                finite = bool(torch.isfinite(z).all())
-                out["sample"] = {"steps": args.sample_steps, "seconds": secs, "steps_per_s": args.sample_steps / secs, "cube": D, "batch": 1,
-                                 "finite": finite, "std": float(z.std()), "mean": float(z.mean()),
-                                 "note": "one chain on rank 0, hipGraph-captured denoise step, in-kernel Philox noise (seed 1234); "
-                                         "chains on other GPUs are independent"}
-                if not finite:
-                    raise RuntimeError(f"the {args.sample_steps}-step sample is not finite")
-                if args.config == "c256":      # context only: the one rate the reference publishes, other hardware
-                    out["sample"]["reference_published"] = {
-                        "value": 2.50, "unit": "denoise steps/s", "steps": 250, "cube": 256, "chs": [16, 32, 64, 128],
-                        "hardware": "one NVIDIA GPU of the 80 GB class (model not stated)",
-                        "source": "/root/reference ICML_figures.ipynb cell 103 (tqdm rate), configs.yaml:127-143, generate_3D.py:61"}
-            except Exception as e:                          # never lose the training line over the secondary measurement
-                out["sample"] = dict(out.get("sample") or {}, error=repr(e))
+        if sample_res is not None:
+            out["sample"] = sample_res
         if not args.no_cpu_baseline and world == 1 and not args.sample_only:
             try:
                 out["cpu_baseline"] = cpu_baseline(chs)
             except Exception as e:                          # never lose the GPU line over the host-side baseline
                 out["cpu_baseline"] = {"error": repr(e)}
         print(json.dumps(out), flush=True)
-        if "error" in (out.get("sample") or {}) and args.sample_only:
-            raise SystemExit(3)
+    if args.sample_only and "error" in (sample_res or {}):
+        raise SystemExit(3)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()

@@ -110,3 +110,31 @@ def test_generate_3d_chain_sharding_gloo_world2(tmp_path):
         assert a.shape == (3, 1, 8, 8, 8) and np.array_equal(a, b), name
     g0 = np.load(one / "gen_0.npy")
     assert not np.array_equal(g0[0], g0[1])
+
+
+def test_ddp_gradient_equals_full_batch_gloo_world2(tmp_path):
+    """Data parallelism is an identity, not just a consensus: 2 ranks x 2 samples with the gradient averaged over the ranks equal
+    1 process x 4 samples on the same samples / times / noise (per-sample GroupNorm; loss = batch mean).  CPU twin (torch backend, gloo)
+    of tests/test_train_step_gpu.py::test_two_ranks_times_two_samples_equal_one_rank_times_four."""
+    port = _free_port()
+    procs = []
+    for rank in range(2):
+        env = dict(os.environ, OMP_NUM_THREADS="2", RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port), DDP_DEVICE="cpu")
+        procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "_ddp_equiv_worker.py"), str(tmp_path)], env=env,
+                                      stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
+    outs = [p.communicate(timeout=600) for p in procs]
+    for p, (so, se) in zip(procs, outs):
+        assert p.returncode == 0, so[-2000:] + se[-4000:]
+    o0, o1 = torch.load(tmp_path / "out0.pt"), torch.load(tmp_path / "out1.pt")
+    assert torch.equal(o0["grad"], o1["grad"])
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import _ddp_equiv_worker as W
+    vdm, net, batch = W.build("fp32", "cpu")
+    loss = W.loss_of(vdm, batch, slice(0, 4))
+    loss.backward()
+    g1 = net.flat.grad.detach()
+    gmax = g1.abs().max().item()
+    assert (o0["grad"] - g1).abs().max().item() <= 1e-5 * gmax
+    assert abs(float(loss) - 0.5 * (o0["loss"] + o1["loss"])) <= 1e-5 * abs(float(loss))
+    assert (2.0 * o0["grad"] - g1).abs().max().item() > 1e-2 * gmax          # (a SUM without the division would be this far off)

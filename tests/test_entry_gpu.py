@@ -227,7 +227,7 @@ def test_bench_self_spawn_two_ranks_share_one_gpu():
     import json
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT")}
     env.update(VDM4CDM_SHARE_GPU="1", VDM4CDM_DIST_BACKEND="gloo")
-    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--config", "tiny", "--steps", "4", "--warmup", "2", "--no-cpu-baseline", "--sample-steps", "0"]
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--config", "tiny", "--steps", "4", "--warmup", "2", "--no-cpu-baseline", "--sample-steps", "12"]
     r = subprocess.run(cmd + ["--gpus", "2"], env=env, cwd=ROOT, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
     lines = [ln for ln in r.stdout.strip().splitlines() if ln.startswith("{")]
@@ -236,6 +236,15 @@ def test_bench_self_spawn_two_ranks_share_one_gpu():
     assert d["n_gpus"] == 2 and d["config"]["global_batch"] == 4 and d["config"]["parallelism"] == "dp2"
     assert d["value"] == pytest.approx(2 * 2 * 32 ** 3 / (d["ms_per_step"] * 1e-3), rel=1e-6)
     assert d["roofline"]["kernel"] and d["roofline"]["largest_by_total_time"]["kernel"]
+    # every rank's own clock around the timed steps; `ms_per_step` is the slowest
+    pr = d["ms_per_step_per_rank"]
+    assert len(pr["all"]) == 2 and pr["max"] == pytest.approx(d["ms_per_step"], rel=1e-9) and pr["min"] <= pr["max"]
+    # the sampling half of the metric on N GPUs: one chain per rank, different seeds -> different cubes, aggregate over the chains
+    sm = d["sample"]
+    assert "error" not in sm and sm["chains"] == 2 and sm["steps"] == 12 and sm["finite"]
+    assert len(sm["seconds_per_rank"]) == 2 and sm["seconds_max"] == max(sm["seconds_per_rank"]) == sm["seconds"]
+    assert sm["seeds"][0] != sm["seeds"][1] and sm["std_per_rank"][0] != sm["std_per_rank"][1], "the two ranks sampled the same chain"
+    assert sm["aggregate_steps_per_s"] == pytest.approx(2 * 12 / sm["seconds_max"], rel=1e-9)
     # --gpus 4 inside a WORLD_SIZE=1 environment: refused, no line
     r = subprocess.run(cmd + ["--gpus", "4"], env=dict(env, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0"), cwd=ROOT, capture_output=True,
                        text=True, timeout=900)
@@ -259,3 +268,18 @@ def test_calc_ss_on_device_matches_reference_golden(case):
     """calc_ss.get_stats on CUDA tensors (rocFFT P(k), device-side histograms) against the outputs of the reference's
     own calc_SS.py functions (tests/golden/ss_golden.npz): histogram counts (edge elements: see check_ss_case), P(k) within 1e-4."""
     ENTRY_CPU.check_ss_case(case, DEV)
+
+
+@pytest.mark.parametrize("mode,precision", [("nocache", "bf16"), ("nocache", "fp32"), ("cached", "bf16")], ids=["nocache_bf16", "nocache_fp32", "cached_bf16"])
+def test_streams_and_allocator_hazards(mode, precision):
+    """Flush cross-stream memory hazards out deliberately (the round-3 use-after-free through the caching allocator surfaced 200 tests
+    later, in rocFFT): one process runs [3 training steps (+ the graph-captured step) -> sampler -> rocFFT P(k) -> teardown] three times
+    with identical seeds and must reproduce round 0 bit for bit - with PYTORCH_NO_CUDA_MEMORY_CACHING=1 (every free is a hipFree) and
+    with the default allocator under empty_cache() between the phases (tests/_stream_hazard_worker.py)."""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
+    env.update(HAZARD_MODE=mode, HAZARD_PRECISION=precision)
+    if mode == "nocache":
+        env["PYTORCH_NO_CUDA_MEMORY_CACHING"] = "1"
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "_stream_hazard_worker.py")], env=env, cwd=ROOT, capture_output=True,
+                       text=True, timeout=900)
+    assert r.returncode == 0 and "HAZARD_OK" in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]

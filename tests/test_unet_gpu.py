@@ -821,7 +821,12 @@ def test_graphed_training_step_matches_eager_and_trains():
         losses = [float(l) for l in losses]
         assert all(math.isfinite(l) for l in losses) and len(set(losses)) > 50, "replays do not draw fresh noise"
         assert sum(losses[-10:]) < 0.8 * sum(losses[:10]), f"graph-replayed training does not fit the batch: {losses[:3]} ... {losses[-3:]}"
-        assert gs.counter.item() == 63                          # 3 eager warm-up steps + 60 replays bumped the device counter
+        assert gs.counter.item() == 60                          # 60 replays bumped the device counter (the 3 warm-up steps are undone)
+        # the counter is scoped to the graphed step: eager steps of the same process (a ragged last batch, validation, a later fit) draw
+        # u0 and their Philox seeds from the host generators again - two eager steps on the same batch see different times and noise
+        assert ops.SEED_STEP is None
+        e1, e2 = vdm2.training_step(b2, 0).detach().clone(), vdm2.training_step(b2, 0).detach().clone()
+        assert not torch.equal(e1, e2) and gs.counter.item() == 60
         vdm2.eval()                                             # the packed weights follow the in-graph optimizer steps
         with torch.no_grad():
             out = hip_forward(net2, x, t, sc, v)

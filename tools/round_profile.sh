@@ -2,7 +2,7 @@
 # Round checkpoint on the GPU box: default bench line, rocprofv3 kernel stats + per-launch timeline of the same command, PMC traffic passes,
 # the sampler alone, the step ablation.   usage (repo root, GPU box): bash tools/round_profile.sh <tag>     outputs under gpurun_out/<tag>_*
 set -e
-tag=${1:-r03}
+tag=${1:-r04}
 out=$PWD/gpurun_out
 mkdir -p "$out"
 python bench.py > "$out/${tag}_bench_c3.json" 2> "$out/${tag}_bench_c3.err"
@@ -20,6 +20,14 @@ rocprofv3 --pmc WRITE_SIZE --output-format csv -d "$out/${tag}_pmc_w" -- python3
 python tools/pmc_traffic.py "$out/${tag}_pmc_f" "$out/${tag}_pmc_w" "$out/${tag}_pmc_bench_traffic.json"
 rm -rf "$out/${tag}_pmc_f" "$out/${tag}_pmc_w"
 echo "pmc done"
+# matrix-pipe / LDS / wait / L2 counters of the same command (one set per pass: 8 SQ + 2 GRBM slots, then 4 TCC slots; no trace domain
+# next to --pmc).  A pass whose counter set the device refuses is skipped, the table is built from the passes that ran.
+B="python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-kernel-events --sample-steps 0"
+rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_LDS_IDX_ACTIVE SQ_LDS_BANK_CONFLICT GRBM_GUI_ACTIVE --output-format csv -d "$out/${tag}_pmc_sq" -- $B > /dev/null 2> "$out/${tag}_pmc_sq.err" || echo "pmc sq pass failed"
+rocprofv3 --pmc TCC_HIT_sum TCC_MISS_sum GRBM_GUI_ACTIVE SQ_WAIT_INST_LDS SQ_ACTIVE_INST_ANY SQ_WAVE_CYCLES SQ_INSTS_LDS SQ_INSTS_VMEM_RD --output-format csv -d "$out/${tag}_pmc_l2" -- $B > /dev/null 2> "$out/${tag}_pmc_l2.err" || echo "pmc l2 pass failed"
+python tools/pmc_counters.py "$out/${tag}_pmc_mfma_util.json" "$out/${tag}_pmc_sq" "$out/${tag}_pmc_l2" || true
+rm -rf "$out/${tag}_pmc_sq" "$out/${tag}_pmc_l2"
+echo "pmc counters done"
 # the sampler alone (BASELINE config C5: 128^3, batch 1, hipGraph-captured step)
 rocprofv3 --kernel-trace --stats --output-format csv -d "$out/${tag}_samp_stats" -- python3 tools/sampler_profile.py --steps 100 > "$out/${tag}_sampler_profile.json" 2> "$out/${tag}_samp.err"
 cp "$(ls "$out/${tag}_samp_stats"/*/*kernel_stats.csv | head -1)" "$out/${tag}_rocprofv3_kernel_stats_sampler_c5.csv"

@@ -371,6 +371,17 @@ __global__ void __launch_bounds__(256) wgrad_cls_reduce_kernel(const float* __re
     }
 }
 
+// timing ablation (tools/ablate_step.sh): the slab reduce is NOT launched - weight gradients are garbage.  Says so, loudly, once.
+static bool ablate_reduce() {
+    static const bool on = [] {
+        const bool v = getenv("VDM4CDM_ABLATE_REDUCE") != nullptr;
+        if (v) fprintf(stderr, "\n*** libvdm4cdm_hip: VDM4CDM_ABLATE_REDUCE is set - weight-gradient slab reduces are SKIPPED, gradients are WRONG "
+                               "(timing ablation only; unset it for any real run) ***\n\n");
+        return v;
+    }();
+    return on;
+}
+
 template <typename T, int KS, int STRIDE, int UPS, int TZ, int TY, int NTA = WG<T>::NT, int NTB = WG<T>::NT>
 static int launch_wgrad_cfg(WgradArgs w, float* dw, float* dbias, int accumulate, int cout, int cin, size_t ws_bytes, hipStream_t s) {
     using G = Geo<KS, STRIDE, TZ, TY>;
@@ -398,10 +409,9 @@ static int launch_wgrad_cfg(WgradArgs w, float* dw, float* dbias, int accumulate
     }
     hipLaunchKernelGGL(kern, dim3(npairs * P), dim3(256), lds, s, w);
     VDM_LAUNCH_CHECK("conv_wgrad_kernel");
-    static const bool no_reduce = getenv("VDM4CDM_ABLATE_REDUCE") != nullptr;      // timing ablation only (wrong results)
-    if (no_reduce) return VDM_OK;
+    if (ablate_reduce()) return VDM_OK;
     const int total = G::TAPS * cout * cin;
-    static const bool grouped_only = getenv("VDM4CDM_GROUPED_REDUCE") != nullptr;
+    static const bool grouped_only = getenv("VDM4CDM_GROUPED_REDUCE") != nullptr;      // (same result, other launch shape)
     if (P * per_wg <= 32 && !grouped_only)
         hipLaunchKernelGGL(wgrad_reduce_direct_kernel, dim3(cdiv(total, 256)), dim3(256), 0, s,
                            (const float*)w.slabs, dw, G::TAPS, cout, cin, w.ncb, w.nkb, CL, P * per_wg, accumulate);
@@ -444,8 +454,7 @@ static int launch_wgrad_cls(WgradArgs w, float* dw, float* dbias, int accumulate
     }
     hipLaunchKernelGGL(kern, dim3(npairs * P), dim3(256), lds, s, w);
     VDM_LAUNCH_CHECK("conv_wgrad_kernel(class)");
-    static const bool no_reduce = getenv("VDM4CDM_ABLATE_REDUCE") != nullptr;      // timing ablation only (wrong results)
-    if (no_reduce) return VDM_OK;
+    if (ablate_reduce()) return VDM_OK;
     hipLaunchKernelGGL(wgrad_cls_reduce_kernel, dim3(cdiv(27 * cout * cin, 64)), dim3(256), 0, s, (const float*)w.slabs, dw, cout, cin, w.ncb,
                        w.nkb, CL, P, accumulate);
     VDM_LAUNCH_CHECK("wgrad_cls_reduce_kernel");

@@ -294,7 +294,13 @@ class AstroDataModule:
         idx = list(indices)
         if shuffle:
             idx = [idx[i] for i in torch.randperm(len(idx), generator=self._gen).tolist()]
-        idx = self.shard(idx, rank, world)                       # data parallelism: equal-length strided shards of the epoch
+        if kind == "eval" and world > 1:
+            # validation / test: every item exactly once over the ranks (strided, NO wrap-around padding: a duplicated item would be
+            # over-weighted in val_loss and emitted twice by a sharded test pass); ranks may differ by one item - Trainer.validate
+            # weights its one all-reduce by the samples each rank really saw
+            idx = idx[rank::world]
+        else:
+            idx = self.shard(idx, rank, world)                   # data parallelism: equal-length strided shards of the epoch
         for b0 in range(0, len(idx), self.batch_size):
             yield self.make_batch([self.draw_sample(i, train, gen) for i in idx[b0:b0 + self.batch_size]])
 

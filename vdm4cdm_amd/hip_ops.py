@@ -15,6 +15,10 @@ GN_EPS = 1e-5
 # timing ablations (tools/ablate_step.sh): kernels named here are NOT launched (wrong results - only bench.py timing runs set this)
 import os as _os
 ABLATE = set(filter(None, _os.environ.get("VDM4CDM_ABLATE", "").split(",")))
+if ABLATE or "VDM4CDM_ABLATE_REDUCE" in _os.environ:
+    import sys as _sys
+    print(f"\n*** vdm4cdm_amd.hip_ops: VDM4CDM_ABLATE={sorted(ABLATE)} / VDM4CDM_ABLATE_REDUCE set - kernels are SKIPPED and results are WRONG "
+          "(timing ablations of tools/ablate_step.sh only; Trainer.fit refuses to run) ***\n", file=_sys.stderr, flush=True)
 
 
 class KernelProfiler:
@@ -102,10 +106,19 @@ def _s():
     return torch.cuda.current_stream().cuda_stream
 
 
+# The side stream a launch is being issued on (set by unet_hip.SideStream.run around its body), else None.  Every tensor whose pointer
+# goes to a kernel while it is set is recorded on that stream HERE - one choke point instead of a record_stream per call site: memory
+# that was allocated on the main stream and is still referenced by a queued side-stream kernel (weight gradients run up to a whole
+# backward pass behind the main stream) cannot be handed to a new owner by the caching allocator before that kernel has run.
+SIDE_STREAM = None
+
+
 def _p(t):
     if t is None:
         return None
     assert t.is_cuda, "HIP ops need device tensors"
+    if SIDE_STREAM is not None:
+        t.record_stream(SIDE_STREAM)
     return t.data_ptr()
 
 

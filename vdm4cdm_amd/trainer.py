@@ -14,6 +14,20 @@ import torch
 import torch.distributed as dist
 
 
+def _accepts(fn, name, positional=0):
+    """Does `fn` take a parameter called `name` (or **kwargs), or at least `positional` positional arguments (or *args)?  Decided from
+    the signature - a TypeError raised INSIDE the user's method must surface, not silently switch graphing / sharding off."""
+    import inspect
+    try:
+        ps = inspect.signature(fn).parameters.values()
+    except (TypeError, ValueError):
+        return False
+    if any(p.kind == p.VAR_KEYWORD or p.name == name for p in ps):
+        return True
+    npos = sum(p.kind in (p.POSITIONAL_ONLY, p.POSITIONAL_OR_KEYWORD) for p in ps)
+    return positional > 0 and (npos >= positional or any(p.kind == p.VAR_POSITIONAL for p in ps))
+
+
 def dist_env():
     return int(os.environ.get("RANK", 0)), int(os.environ.get("LOCAL_RANK", 0)), int(os.environ.get("WORLD_SIZE", 1))
 
@@ -87,19 +101,40 @@ class GraphedTrainStep:
     def __init__(self, model, opt, params, clip_val, batch, warmup=3):
         from . import hip_ops as ops
         assert ops.PROFILER is None, "per-launch events cannot be recorded inside a captured graph"
+        assert ops.SEED_STEP is None, "another graphed step is being built / run in this process"
         self.model, self.opt, self.params, self.clip = model, opt, params, clip_val
         dev = params[0].device
         self.static = {k: ([t.clone() for t in v] if isinstance(v, (list, tuple)) else (None if v is None else v.clone())) for k, v in batch.items()}
         self.counter = torch.zeros(1, dtype=torch.int32, device=dev)
-        ops.SEED_STEP = self.counter                            # from now on every seed is (host seed, device step counter)
+        # The device counter is mixed into the seeds ONLY while this object's own step runs (hip_ops.SEED_STEP is set inside _step and
+        # cleared on the way out): eager steps of the same process - a ragged last batch, validation, a later fit - keep drawing u0 and
+        # their Philox seeds from the host generators and never see a stale counter.
+        inner = getattr(model, "model", model)
         cur = torch.cuda.current_stream(dev)
         side = torch.cuda.Stream(device=dev)
+        # eager warm-up (allocator pools, workspaces, packed weights, optimizer state): NOT real steps - parameters, optimizer
+        # moments / step count and the device counter are put back afterwards, so the first replay is optimizer step 1 on this batch
+        keep = [p.detach().clone() for p in params]
         side.wait_stream(cur)
-        with torch.cuda.stream(side):                           # eager warm-up: allocator pools, workspaces, packed weights, optimizer state
+        with torch.cuda.stream(side):
             for _ in range(warmup):
                 self._step()
+            with torch.no_grad():
+                for p, k in zip(params, keep):
+                    p.copy_(k)
+                for st in opt.state.values():
+                    for v in st.values():
+                        if torch.is_tensor(v):
+                            v.zero_()
+                self.counter.zero_()
+            sm = getattr(inner, "score_model", None)
+            if hasattr(sm, "mark_weights_dirty"):
+                sm.mark_weights_dirty()
+                if hasattr(sm, "repack_weights"):
+                    sm.repack_weights()
         cur.wait_stream(side)
         torch.cuda.synchronize(dev)
+        del keep
         self.graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(self.graph):
             self.loss, self.gnorm = self._step()
@@ -107,12 +142,16 @@ class GraphedTrainStep:
 
     def _step(self):
         from . import hip_ops as ops
-        loss = self.model.training_step(self.static, 0)
-        self.opt.zero_grad(set_to_none=True)
-        loss.backward()
-        gnorm = clip_grad_norm_flat_(self.params, self.clip, True, want_norm=True) if self.clip else None
-        self.opt.step()
-        ops.step_inc(self.counter)
+        ops.SEED_STEP = self.counter                            # every seed of THIS step is (host seed, device step counter)
+        try:
+            loss = self.model.training_step(self.static, 0)
+            self.opt.zero_grad(set_to_none=True)
+            loss.backward()
+            gnorm = clip_grad_norm_flat_(self.params, self.clip, True, want_norm=True) if self.clip else None
+            self.opt.step()
+            ops.step_inc(self.counter)
+        finally:
+            ops.SEED_STEP = None
         return loss, gnorm
 
     def __call__(self, batch):
@@ -180,9 +219,15 @@ class Trainer:
             sm.enable_ddp(self.world)
         use_hip = dev_type == "cuda" and getattr(model.model.score_model, "backend", "") == "hip"
         graphed = self.graph_step and use_hip and self.world == 1 and getattr(model.model, "noise_schedule", "") == "fixed_linear"
-        try:
+        if use_hip:
+            from . import hip_ops as ops
+            if ops.ABLATE or "VDM4CDM_ABLATE_REDUCE" in os.environ:      # timing switches of tools/ablate_step.sh skip kernels: never train with them
+                raise RuntimeError(f"VDM4CDM_ABLATE={sorted(ops.ABLATE)} is set: kernels are skipped and gradients are garbage - unset it")
+        if _accepts(model.configure_optimizers, "capturable"):
             opt = model.configure_optimizers(capturable=graphed)
-        except TypeError:                                    # (a user model with the reference's zero-argument signature)
+        else:                                                # (a user model with the reference's zero-argument signature)
+            if graphed and self.rank == 0:
+                print("Trainer: configure_optimizers() takes no `capturable` argument - the training step stays eager", flush=True)
             opt, graphed = model.configure_optimizers(), False
         gstep = None
         epoch, t0 = 0, time.time()
@@ -192,8 +237,8 @@ class Trainer:
             for batch in datamodule.train_dataloader(self.rank, self.world):
                 n_batches += 1
                 if graphed and gstep is None and self.max_steps - self.global_step >= 8:
-                    gstep = GraphedTrainStep(model, opt, params, self.gradient_clip_val, batch)      # captured at the first batch
-                    self.global_step += 3                     # (its eager warm-up steps were real optimizer steps on this batch)
+                    # captured at the first batch (its eager warm-up steps are undone: parameters / optimizer state restored)
+                    gstep = GraphedTrainStep(model, opt, params, self.gradient_clip_val, batch)
                 if gstep is not None and gstep.static["x"].shape == batch["x"].shape:
                     loss, gnorm = gstep(batch), gstep.gnorm   # one hipGraph replay = the whole step
                 else:                                         # eager step (N > 1 ranks, short runs, a ragged last batch, the torch backend)
@@ -235,21 +280,26 @@ class Trainer:
         model.eval()
         losses, last = [], None
         world = getattr(self, "world", 1)
-        try:                                                   # the validation split is sharded like the training split
+        if _accepts(datamodule.val_dataloader, "rank", positional=2):      # the validation split is sharded like the training split
             loader = datamodule.val_dataloader(self.rank, world)
-        except TypeError:                                      # (a user datamodule with the reference's zero-argument signature)
+        else:                                                  # (a user datamodule with the reference's zero-argument signature)
+            if world > 1 and self.rank == 0:
+                print("Trainer: val_dataloader() takes no (rank, world): every rank evaluates the whole validation split", flush=True)
             loader = datamodule.val_dataloader()
+        nseen = 0
         for i, batch in enumerate(loader):
-            if i >= self.limit_val_batches:
+            if i >= self.limit_val_batches:                    # (per rank: at world N the loss averages up to N * limit_val_batches batches)
                 break
-            losses.append(model.validation_step(batch, i).detach().float())
+            nb = int(batch["x"].shape[0]) if isinstance(batch, dict) and torch.is_tensor(batch.get("x")) else 1
+            losses.append(model.validation_step(batch, i).detach().float() * nb)      # sample-weighted: short / uneven last batches
+            nseen += nb
             last = batch
         dev = losses[0].device if losses else torch.device("cpu")
         tot = torch.stack([torch.stack(losses).sum() if losses else torch.zeros((), device=dev),
-                           torch.tensor(float(len(losses)), device=dev)])
+                           torch.tensor(float(nseen), device=dev)])
         if world > 1:                                          # one collective, entered by EVERY rank (also one whose shard was empty)
             dist.all_reduce(tot, op=dist.ReduceOp.SUM)
-        rec = {"step": self.global_step, "val_loss": float(tot[0] / tot[1].clamp(min=1.0)), **dict(model.logged)}
+        rec = {"step": self.global_step, "val_loss": float(tot[0] / tot[1].clamp(min=1.0)), "val_samples": int(tot[1].item()), **dict(model.logged)}
         if last is not None and model.draw_figure is not None and self.rank == 0:
             x, kw = model._unpack(last)
             samples = model.draw_samples(batch_size=x.shape[0], n_sampling_steps=self.n_val_sampling_steps, **model._filter(kw))

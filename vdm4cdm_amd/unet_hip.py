@@ -25,12 +25,6 @@ FUSED_SKIP = os.environ.get("VDM4CDM_FUSED_SKIP", "1") != "0"
 # inference: norm2's GroupNorm + SiLU applied inside conv2 (to the staged halo image) instead of by a pass of its own.  Measured: the
 # VALU work on the 2.1x halo costs the conv what the 5 TB/s pass cost - off by default
 GN_PROLOGUE = os.environ.get("VDM4CDM_GN_PROLOGUE", "0") == "1"
-# Opt-in experiment: the per-step weight re-packing on a stream of its own, next to the head of the next step (-0.05 ms per step).
-# OFF by default: with it, 4 of 6 runs of the whole GPU test suite in one process died in a later rocFFT / hipFree call (0 of 4
-# without it) - a captured wait on the hook's event was one cause (fixed in _wait_pack); the buffers the launch touches were
-# not recorded on the pack stream (fixed below, see pack_weights); the default stays off.
-PACK_OVERLAP = os.environ.get("VDM4CDM_PACK_OVERLAP", "0") == "1"
-
 
 class SideStream:
     """Weight-gradient kernels run on a side HIP stream: their results are needed only by the optimiser, so they overlap
@@ -48,8 +42,12 @@ class SideStream:
             return fn()
         main = torch.cuda.current_stream()
         self.side.wait_stream(main)
-        with torch.cuda.stream(self.side):
-            fn()
+        prev, ops.SIDE_STREAM = ops.SIDE_STREAM, self.side      # hip_ops._p: every tensor handed to a launch in here is recorded on the
+        try:                                                    # side stream (the ONE place where main-stream memory meets a side queue)
+            with torch.cuda.stream(self.side):
+                fn()
+        finally:
+            ops.SIDE_STREAM = prev
         for t in tensors:
             if t is not None:
                 t.record_stream(self.side)
@@ -337,7 +335,6 @@ class HipUNet:
         self.attn = _Attn(net) if net.mid_attn else None
         self._packed_key = None
         self._pack_plan = None
-        self._pack_stream = self._pack_event = self._pack_event_obj = None
         self.saved = None
         self._ss = None
 
@@ -354,10 +351,9 @@ class HipUNet:
         return out
 
     def pack_weights(self, flat, dtype, need_dgrad, overlap=False):
-        """Re-pack master fp32 weights into MFMA fragment order when the parameters changed.
-        overlap (the optimizer post-step hook): the launch goes to a stream of its own, ordered behind the optimizer step; the next
-        forward waits for it only in front of its first conv, so the head of the next step (noise draws, forward diffusion, input
-        packing, conditioning table) runs next to it instead of behind it."""
+        """Re-pack master fp32 weights into MFMA fragment order when the parameters changed (one launch on the current stream, ordered
+        behind the optimizer step that changed them).  `overlap` is accepted and ignored: running the launch on a stream of its own next
+        to the head of the next step bought 0.05 ms and cost a cross-stream use-after-free and a broken capture (rounds 3-4); deleted."""
         # flat._version alone is NOT enough: fused optimizers (torch._fused_adamw_) update the parameters without bumping the
         # version counter.  net.weights_epoch is bumped by every backward pass of this executor (an optimizer step follows) and by
         # CUNet.mark_weights_dirty() (the optimizer post-step hook LightVDM.configure_optimizers installs).
@@ -369,37 +365,8 @@ class HipUNet:
         pkey = (flat.data_ptr(), dtype, bool(need_dgrad))
         if self._pack_plan is None or self._pack_plan[0] != pkey:         # one launch for all ~120 (conv, form) packings
             self._pack_plan = (pkey, ops.PackPlan([(conv, self.net.view(name, flat)) for conv, name in self._all_convs()], dtype, need_dgrad))
-        if overlap and PACK_OVERLAP and flat.is_cuda and not torch.cuda.is_current_stream_capturing():
-            if self._pack_stream is None or self._pack_stream.device != flat.device:
-                self._pack_stream = torch.cuda.Stream(device=flat.device)
-            self._pack_stream.wait_stream(torch.cuda.current_stream(flat.device))
-            # every tensor the launch touches is handed to the pack stream: without record_stream the caching allocator may give a
-            # freed buffer (a net deleted right after its last step) to a new owner on the main stream while the re-packing - queued
-            # behind the whole step - has not yet run: a write into somebody else's memory
-            plan = self._pack_plan[1]
-            for t in [flat, plan.items, plan.chunks] + [b for conv, _ in self._all_convs() for b in (conv.wf, conv.wd) if b is not None]:
-                t.record_stream(self._pack_stream)
-            with torch.cuda.stream(self._pack_stream):
-                self._pack_plan[1].run()
-                if self._pack_event_obj is None:         # ONE event per executor, never destroyed while a stream may still wait on it
-                    self._pack_event_obj = torch.cuda.Event()
-                self._pack_event_obj.record(self._pack_stream)
-                self._pack_event = self._pack_event_obj
-        else:
-            self._wait_pack()                        # (never two packings in flight)
-            self._pack_plan[1].run()
+        self._pack_plan[1].run()
         self._packed_key = key
-
-    def _wait_pack(self):
-        """The current stream waits for a re-packing that is still running on the pack stream."""
-        if self._pack_event is not None:
-            # Under stream capture the event must NOT be waited for: it was recorded outside the capture (the post-step hook of an
-            # eager step), and a captured wait on uncaptured work leaves a broken graph behind (seen as aborts / segfaults in later
-            # hipFree / rocFFT calls of the same process).  Nothing to wait for either: a capture begins with a device-wide
-            # synchronize, so a re-packing issued before it has finished.
-            if not torch.cuda.is_current_stream_capturing():
-                torch.cuda.current_stream().wait_event(self._pack_event)
-            self._pack_event = None
 
     def enable_ddp(self, world, group=None):
         """Average the gradient over `world` ranks inside backward(), bucket by bucket (see GradBuckets); CUNet.grad_synced tells
@@ -432,7 +399,6 @@ class HipUNet:
         L = len(net.chs)
         ss = self._side_stream(flat.device)
         xin = ops.pack_input(z, s_cond, dtype)
-        self._wait_pack()
         h = self.conv_in.fwd(xin, P("conv_in.bias"), gn=FUSED_GN)
         skips = []
         for i in range(L):
