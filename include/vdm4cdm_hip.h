@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define VDM_ABI_VERSION 10
+#define VDM_ABI_VERSION 11
 
 typedef enum { VDM_OK = 0, VDM_ERR_ARG = -1, VDM_ERR_HIP = -2, VDM_ERR_UNSUPPORTED = -3 } vdm_status;
 typedef enum { VDM_F32 = 0, VDM_BF16 = 1 } vdm_dtype;
@@ -260,6 +260,21 @@ int vdm_diffuse(const float* x, const float* eps, const float* alpha, const floa
 /* workspace: >= 2048 * 3 floats (per-workgroup partials, folded in a fixed order: the loss is bit-reproducible). */
 int vdm_loss_terms(const float* x, const float* eps, const float* eps_hat, const float* eps0, float sigma0_over_alpha0,
                    const float* coef, int n, int64_t per, float* sums, float* d_eps_hat, float* workspace, void* stream);
+
+/* Fused head of the training step (ABI v11) [replaces the randn_like -> alpha x + sigma eps -> cat([z_t, s_conditioning]) chain of
+ * VDM.get_loss + CUNet.forward, NB vdm_model.py:309-327 / networks.py:259-265]: z_t = alpha[n] x + sigma[n] eps, written as fp32
+ * (z_t, may be NULL) AND as conv_in's NDHWC input packed[n][voxel][16 B] = {z_t, s_cond (0 if NULL), 0 ...} in `dtype` - one pass over
+ * x instead of vdm_randn + vdm_diffuse + vdm_pack_input.  eps == NULL: the noise is drawn inside the kernel from the Philox counters
+ * (seed, stream_id, element group; seed_step as for vdm_randn) - exactly the field vdm_randn(seed, stream_id) would have written;
+ * eps != NULL: supplied noise (parity tests).  per % 4 == 0. */
+int vdm_diffuse_pack(const float* x, const float* s_cond, const float* eps, uint64_t seed, uint64_t stream_id, const int32_t* seed_step,
+                     const float* alpha, const float* sigma, int n, int64_t per, int dtype, float* z_t, void* packed, void* stream);
+/* vdm_loss_terms with eps and / or eps0 regenerated from their Philox counters when NULL (the fields vdm_randn(seed_eps, stream_eps) /
+ * vdm_randn(seed_eps0, stream_eps0) would have written): the training step never materialises its noise fields.  per % 4 == 0;
+ * workspace as vdm_loss_terms.  With both fields supplied the sums equal this kernel's sums for the regenerated fields bit for bit. */
+int vdm_loss_terms_rng(const float* x, const float* eps, uint64_t seed_eps, uint64_t stream_eps, const float* eps_hat, const float* eps0,
+                       uint64_t seed_eps0, uint64_t stream_eps0, const int32_t* seed_step, float sigma0_over_alpha0, const float* coef, int n,
+                       int64_t per, float* sums, float* d_eps_hat, float* workspace, void* stream);
 
 /* ---- data path: crop + log-normalise + flip + permute on the device -----------------------------
  * Replaces the per-sample CPU DataLoader work of [REF src/dataset/CAMELS_3D_dataset.py:53-73] (AstroDataset.__getitem__) and

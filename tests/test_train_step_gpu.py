@@ -151,8 +151,8 @@ def _adamw_cpu(params0, grads, lr, clip):
     return clipped, after, norms
 
 
-@pytest.mark.parametrize("scales", [(1.0, 400.0), (300.0, 1.0e-3)], ids=["below_then_above", "above_then_below"])
-def test_clip_and_fused_adamw_match_torch(scales):
+@pytest.mark.parametrize("targets", [(0.2, 60.0), (35.0, 0.3)], ids=["below_then_above", "above_then_below"])
+def test_clip_and_fused_adamw_match_torch(targets):
     """One optimizer step of the product = K10 sum of squares -> vdm_clip_scale (coefficient min(1, 0.5 / (norm + 1e-6)) derived on the
     device) -> fused AdamW over the flat vector.  Two consecutive steps whose gradient norms sit on different sides of the 0.5 threshold
     (AdamW's FIRST step is invariant to the gradient's scale: only the second one sees a wrong coefficient).
@@ -167,9 +167,12 @@ def test_clip_and_fused_adamw_match_torch(scales):
     opt = vdm.configure_optimizers()
     flat0 = net.flat.detach().cpu().clone()
     hip_grads, ora_grads, hip_clipped, hip_after, hip_norms = [], [], [], [], []
-    for step, sc in enumerate(scales):
+    for step, target in enumerate(targets):                      # gradient norms 0.2 / 60 (35 / 0.3): on either side of the 0.5 threshold
         x, t, s, v = inputs(net, 2, seed=3 + 10 * step)
-        w = (grf((2, 1) + net.shape[1:], 77 + step) + 0.5) * sc
+        w = grf((2, 1) + net.shape[1:], 77 + step) + 0.5
+        opt.zero_grad(set_to_none=True)                          # (the gradient is linear in w: probe its norm, then scale w)
+        (hip_forward(net, x, t, s, v) * w.to(DEV)).sum().backward()
+        w = w * (target / net.flat.grad.norm().item())
         # the oracle's gradient at the CURRENT product weights
         _, gref = _oracle_grads(net, x, t, s, v, w)
         ora_grads.append(gref)
@@ -187,7 +190,8 @@ def test_clip_and_fused_adamw_match_torch(scales):
     assert (norms[0] > clip) != (norms[1] > clip), f"the two steps must straddle the threshold: norms {norms}"
     prev = flat0
     for k in range(2):
-        assert hip_norms[k] == pytest.approx(norms[k], rel=1e-5)
+        assert hip_norms[k] == pytest.approx(hip_grads[k].double().norm().item(), rel=1e-5)       # (fp64 norm; torch's fp32 CPU norm
+        assert hip_norms[k] == pytest.approx(norms[k], rel=1e-4)                                   #  itself is only good to ~2e-5)
         gmax = clipped[k].abs().max().item()
         assert (hip_clipped[k] - clipped[k]).abs().max().item() <= 1e-6 * gmax, f"step {k}: clipped gradient"
         d_hip, d_ref = hip_after[k] - prev, after[k] - prev
@@ -287,3 +291,78 @@ def test_two_ranks_times_two_samples_equal_one_rank_times_four(tmp_path, precisi
     assert float(loss) == pytest.approx(0.5 * (o0["loss"] + o1["loss"]), rel=1e-5)
     if precision == "fp32":                                    # the wrong pairings are far outside the tolerance
         assert (2.0 * o0["grad"] - g1).abs().max().item() > 100 * tol * gmax
+
+
+# ------------------------------------------------------------------------------------------ fused head of the step (K7 + input packing, K8 with regenerated noise)
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16], ids=["f32", "bf16"])
+@pytest.mark.parametrize("D", [12, 20, 32], ids=["12cube", "20cube", "32cube"])
+def test_diffuse_pack_equals_randn_diffuse_pack_input(dtype, D):
+    """vdm_diffuse_pack (eps drawn in the kernel) == vdm_randn -> vdm_diffuse -> vdm_pack_input, bit for bit: z_t and conv_in's packed
+    NDHWC input, ragged sizes (the packed pieces are re-dealt across the lanes of a wave: tails matter), with and without s_conditioning;
+    with supplied eps it equals the three-kernel chain on that eps; alpha / sigma per sample against the oracle formula."""
+    from vdm4cdm_amd import hip_ops as ops
+    B = 3
+    x = grf((B, 1, D, D, D), 5).to(DEV)
+    s = grf((B, 1, D, D, D), 6).to(DEV)
+    al, si = torch.tensor([0.9, 0.5, 0.1], device=DEV), torch.tensor([0.3, 0.8, 0.99], device=DEV)
+    seed, sid = 123456789012345, 7
+    eps = ops.randn(torch.empty_like(x), seed, sid)
+    zref = ops.diffuse(x, eps, al, si)
+    assert torch.allclose(zref.cpu(), (al.view(B, 1, 1, 1, 1) * x + si.view(B, 1, 1, 1, 1) * eps).cpu(), atol=1e-6)      # the oracle's z_t
+    for sc in (s, None):
+        pref = ops.pack_input(zref.reshape(B, D, D, D), None if sc is None else sc.reshape(B, D, D, D), dtype)
+        z, packed = ops.diffuse_pack(x, sc, al, si, dtype, seed=seed, stream_id=sid, want_z=True)
+        assert torch.equal(z, zref) and packed.shape == pref.shape and torch.equal(packed.view(torch.uint8), pref.view(torch.uint8))
+        z2, p2 = ops.diffuse_pack(x, sc, al, si, dtype, eps=eps, want_z=True)
+        assert torch.equal(z2, zref) and torch.equal(p2.view(torch.uint8), pref.view(torch.uint8))
+        z3, p3 = ops.diffuse_pack(x, sc, al, si, dtype, seed=seed, stream_id=sid + 1, want_z=False)
+        assert z3 is None and not torch.equal(p3.view(torch.uint8), pref.view(torch.uint8))
+
+
+def test_loss_terms_regenerates_its_noise_fields():
+    """vdm_loss_terms_rng with eps / eps0 = NULL regenerates the fields vdm_randn would have written: sums and d_eps_hat equal the
+    supplied-field call bit for bit, and both agree with the formula."""
+    from vdm4cdm_amd import hip_ops as ops
+    B, per = 3, 20 ** 3
+    x, eh = grf((B, 1, 20, 20, 20), 1).reshape(B, per).to(DEV), grf((B, 1, 20, 20, 20), 2).reshape(B, per).to(DEV)
+    coef = torch.tensor([0.5, 1.5, 2.0], device=DEV)
+    rng = ((111, 3), (222, 4))
+    eps, e0 = ops.randn(torch.empty_like(x), *rng[0]), ops.randn(torch.empty_like(x), *rng[1])
+    out = []
+    for a, b, r in ((eps, e0, None), (None, None, rng), (eps, None, rng), (None, e0, rng)):
+        sums, d = torch.zeros(B, 3, device=DEV), torch.empty(B, per, device=DEV)
+        ops.loss_terms(x, a, eh, b, 0.01, coef, sums, d, rng=r)
+        out.append((sums.cpu(), d.cpu()))
+    for sm, d in out[1:]:
+        assert torch.equal(sm, out[0][0]) and torch.equal(d, out[0][1])
+    ref = torch.stack([((eh - eps) ** 2).sum(1), (x ** 2).sum(1), ((0.01 * e0) ** 2).sum(1)], 1).cpu()
+    assert torch.allclose(out[0][0], ref, rtol=1e-5) and torch.allclose(out[0][1], (coef[:, None] * (eh - eps)).cpu(), atol=1e-6)
+
+
+@pytest.mark.parametrize("precision", ["fp32", "bf16"])
+def test_fused_head_training_step_equals_unfused(precision, monkeypatch):
+    """VDM.get_loss with the fused head (no noise field in memory, z_t and conv_in's input from one pass) against the unfused chain
+    (randn x 2 -> diffuse -> pack_input -> ... -> loss_terms on the stored fields) from the same generator state: the same loss, ELBO
+    parts and parameter gradient, bit for bit (dropout on: the masks depend only on the seed counter)."""
+    import vdm4cdm_amd.unet_hip as uh
+    net = make_net(precision=precision, dropout=0.1, **CFGS[0])
+    vdm = make_vdm(net).to(DEV).train()
+    x, _, s, v = inputs(net, 2)
+    kw = dict(s_conditioning=s.to(DEV), v_conditionings=[a.to(DEV) for a in v])
+    res = []
+    for fused in (True, False):
+        monkeypatch.setattr(vdm_model_mod_ref(), "FUSED_HEAD", fused)
+        torch.manual_seed(9)
+        uh._seed_counter[0] = 0
+        vdm_model_mod_ref().reset_train_generators()
+        net.flat.grad = None
+        loss, metrics = vdm.model.get_loss(x.to(DEV), **kw)
+        loss.backward()
+        res.append((loss.detach().clone(), {k: m.clone() for k, m in metrics.items()}, net.flat.grad.clone()))
+    assert torch.equal(res[0][0], res[1][0]) and all(torch.equal(res[0][1][k], res[1][1][k]) for k in res[0][1])
+    assert torch.equal(res[0][2], res[1][2]) and torch.isfinite(res[0][2]).all() and res[0][2].abs().max().item() > 0
+
+
+def vdm_model_mod_ref():
+    import vdm4cdm_amd.vdm_model as m
+    return m

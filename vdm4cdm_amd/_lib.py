@@ -64,7 +64,7 @@ class AugmentSample(C.Structure):
 PACK_CHUNK = 16384                   # VDM_PACK_CHUNK
 _p, _i, _i64, _u64, _f, _sz = C.c_void_p, C.c_int, C.c_int64, C.c_uint64, C.c_float, C.c_size_t
 _D = C.POINTER(ConvDesc)
-ABI_VERSION = 10                      # VDM_ABI_VERSION of include/vdm4cdm_hip.h this binding was written for
+ABI_VERSION = 11                      # VDM_ABI_VERSION of include/vdm4cdm_hip.h this binding was written for
 
 # name -> (restype, argtypes); mirrors include/vdm4cdm_hip.h one to one
 SIGNATURES = {
@@ -110,6 +110,8 @@ SIGNATURES = {
     "vdm_channel_dot_sums": (_i, [_p, _p, _i, _p, _i, _i, _i64, _i, _p, _p]),
     "vdm_diffuse": (_i, [_p, _p, _p, _p, _i, _i64, _p, _p]),
     "vdm_loss_terms": (_i, [_p, _p, _p, _p, _f, _p, _i, _i64, _p, _p, _p, _p]),
+    "vdm_diffuse_pack": (_i, [_p, _p, _p, _u64, _u64, _p, _p, _p, _i, _i64, _i, _p, _p, _p]),
+    "vdm_loss_terms_rng": (_i, [_p, _p, _u64, _u64, _p, _p, _u64, _u64, _p, _f, _p, _i, _i64, _p, _p, _p, _p]),
     "vdm_ancestral_step": (_i, [_p, _p, _p, _p, _p, _u64, _i64, _p]),
     "vdm_ancestral_step_cfg": (_i, [_p, _p, _p, _f, _p, _p, _p, _u64, _i64, _p]),
     "vdm_randn": (_i, [_p, _i64, _u64, _u64, _p, _p]),

@@ -27,22 +27,23 @@ namespace vdm {
 
 static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
 static constexpr int GNP_TABLE_BYTES = 512 * 2 * 4;          // GroupNorm prologue: (A, B) of up to 512 input channels
-static constexpr int GN_SCRATCH_BYTES = 4 * 64 * 2 * 4;      // 4 waves x (NC <= 4) * 16 channels x (sum, sumsq) floats
+static constexpr int GN_SCRATCH_BYTES = 8 * 64 * 2 * 4;      // <= 8 waves x (NC <= 4) * 16 channels x (sum, sumsq) floats
 
 // ---------------------------------------------------------------------------------------------
 // geometry
 // ---------------------------------------------------------------------------------------------
-template <int KS_, int STRIDE_, int TZ_, int TY_>
+template <int KS_, int STRIDE_, int TZ_, int TY_, int NW_ = 4>
 struct Geo {
     static constexpr int KS = KS_, STRIDE = STRIDE_, TZ = TZ_, TY = TY_, TX = 16;
+    static constexpr int NW = NW_;                       // waves per workgroup (the rows of a tile are split over them)
     static constexpr int PAD = KS / 2;
     static constexpr int TAPS = KS * KS * KS;
     static constexpr int HZ = (TZ - 1) * STRIDE + KS, HY = (TY - 1) * STRIDE + KS, HX = (TX - 1) * STRIDE + KS;
     static constexpr int HVOX = HZ * HY * HX;
     static constexpr int ROWS = TZ * TY;                 // 16-voxel MFMA columns-tiles per workgroup
-    static constexpr int NV = ROWS / 4;                  // per wave
+    static constexpr int NV = ROWS / NW;                 // per wave
     static constexpr int OVOX = ROWS * 16;
-    static_assert(ROWS % 4 == 0, "rows must split over 4 waves");
+    static_assert(ROWS % NW == 0, "rows must split over the waves");
 };
 
 struct ConvArgs {
@@ -114,9 +115,9 @@ static __device__ uint4 g_zero_page[16];
 // sD*: source tensor dims.
 // NWAVES: waves that share the chunks (4: all waves of a workgroup; 1: a wave stages a private image - conv_ksplit_kernel).
 template <typename T, typename G, int UPS, int NWAVES = 4>
-__device__ __forceinline__ void stage_halo_dma_gen(char* lds, const T* __restrict__ x, const ConvArgs& a, int n, int oz0, int oy0,
-                                                   int ox0, int kb, int wave, int lane, int ss, int soz, int soy, int sox, int sDz,
-                                                   int sDy, int sDx) {
+__device__ __forceinline__ void stage_halo_dma_chunks(char* lds, const T* __restrict__ x, const ConvArgs& a, int n, int oz0, int oy0,
+                                                      int ox0, int kb, int wave, int lane, int ss, int soz, int soy, int sox, int sDz,
+                                                      int sDy, int sDx) {
     constexpr int EPL = DT<T>::EPL, KB = DT<T>::KB;
     constexpr int NCHUNK = (G::HVOX + 15) / 16;
     constexpr int STEP = 16 * NWAVES;                       // halo voxels between two chunks of one wave
@@ -156,6 +157,98 @@ __device__ __forceinline__ void stage_halo_dma_gen(char* lds, const T* __restric
         if (hx >= G::HX) { hx -= G::HX; hy += 1; }
         if (hy >= G::HY) { hy -= G::HY; hz += 1; }
     }
+}
+
+
+// ---------------------------------------------------------------------------------------------
+// Row-wise staging (round 4).  Counters (profiles/r04_pmc_mfma_util.json): the level-0 conv issued 2 070 vector instructions per wave
+// and tile next to its 432 MFMAs, and about half of them were the address arithmetic of the chunk walk above - it re-derives
+// (hz, hy, hx), the wrap / bounds tests, two 24-bit multiplies and a 64-bit pointer select per lane for every one of a wave's 17
+// chunks, because a 16-voxel chunk of the linear halo image straddles two halo rows.  A SIMD issues one vector instruction per 4
+// cycles from a wave and an MFMA holds the issue port for 8 of its 16: the staging arithmetic of one workgroup costs the co-resident
+// workgroup's tap loop about as many issue slots as the taps themselves (why "fewer staged chunks" bought 8-11 % and more waves nothing).
+// Same LDS image, another walk: a halo ROW (hz, hy) is wave-uniform, so its validity, its wrap and its source address are SCALAR
+// arithmetic (the scalar unit is otherwise idle); per lane only the x offset of its voxel / piece remains, and that is the same for
+// every row - computed once per tile.  Per row: NSEG LDS-DMAs of 16 voxels (16 B per lane, hx = 16 s ... 16 s + 15) and, for the
+// HX - 16 NSEG leftover voxels at the end of the row (hx = 16, 17 of an 18-voxel row), ONE 4-byte-per-lane LDS-DMA with 16 lanes per
+// voxel active (the leftover voxels of a row are contiguous in the image; masked lanes write nothing).
+// ---------------------------------------------------------------------------------------------
+#ifndef VDM_ROWSTAGE
+#define VDM_ROWSTAGE 1
+#endif
+template <typename T, typename G, int UPS, int NWAVES = 4>
+__device__ __forceinline__ void stage_halo_dma_rows(char* lds, const T* __restrict__ x, const ConvArgs& a, int n, int oz0, int oy0,
+                                                    int ox0, int kb, int wave, int lane, int ss, int soz, int soy, int sox, int sDz,
+                                                    int sDy, int sDx) {
+    constexpr int EPL = DT<T>::EPL, KB = DT<T>::KB, SH = DT<T>::SHIFT;
+    constexpr int HX = G::HX, HY = G::HY, HZ = G::HZ, PAD = G::PAD;
+    constexpr int NSEG = HX / 16, NTAIL = HX - 16 * NSEG, NROW = HZ * HY;
+    static_assert(NTAIL <= 4, "the leftover voxels of a row go out as one 256-byte LDS-DMA");
+    const int iz0 = oz0 * G::STRIDE - PAD, iy0 = oy0 * G::STRIDE - PAD, ix0 = ox0 * G::STRIDE - PAD;
+    const char* xn = reinterpret_cast<const char*>(x + (size_t)n * ((size_t)sDz * sDy * sDx * a.CinStride));
+    const char* zp = reinterpret_cast<const char*>(g_zero_page);
+    // ---- per-lane x part, once per tile: byte offset of the lane's 16 B (segments) / 4 B (tail) inside a source row, or "take zeros"
+    auto xpart = [&](int hx, int slot, unsigned& off) -> bool {
+        const int pc = slot ^ ((hx >> 1) & 3);                                // source piece of this LDS slot (x-swizzle)
+        const int ci = kb * KB + pc * EPL;
+        int ix = ix0 + hx;
+        bool ok = ci < a.Cin;
+        if (a.circular) ix = wrap(ix, a.Ix);
+        else ok = ok && (unsigned)ix < (unsigned)a.Ix;
+        if (UPS) ix >>= 1;
+        const unsigned sx = (unsigned)(ss * ix + sox) & 0xffffffu;
+        off = (__umul24(sx, (unsigned)a.CinStride) + (unsigned)ci) << SH;
+        return ok;
+    };
+    unsigned xoff[NSEG], toff = 0;
+    bool okx[NSEG], tok = false;
+#pragma unroll
+    for (int sgm = 0; sgm < NSEG; ++sgm) okx[sgm] = xpart(16 * sgm + (lane >> 2), lane & 3, xoff[sgm]);
+    if constexpr (NTAIL > 0) {
+        const int d = lane & 15;                                              // dword of the tail voxel lane >> 4
+        tok = xpart(16 * NSEG + (lane >> 4), d >> 2, toff) && lane < 16 * NTAIL;
+        toff += (unsigned)(d & 3) * 4u;
+    }
+    // ---- rows: scalar address arithmetic, NSEG (+1) LDS-DMAs per row
+    for (int r = wave; r < NROW; r += NWAVES) {
+        const int hz = r / HY, hy = r % HY;
+        int iz = iz0 + hz, iy = iy0 + hy;
+        bool okrow = true;
+        if (a.circular) {
+            iz = wrap(iz, a.Iz); iy = wrap(iy, a.Iy);
+        } else {
+            okrow = (unsigned)iz < (unsigned)a.Iz && (unsigned)iy < (unsigned)a.Iy;
+        }
+        if (UPS) { iz >>= 1; iy >>= 1; }
+        const unsigned sz = okrow ? (unsigned)(ss * iz + soz) : 0u, sy = okrow ? (unsigned)(ss * iy + soy) : 0u;
+        const size_t rowel = (size_t)((sz * (unsigned)sDy + sy) * (unsigned)sDx) * (unsigned)a.CinStride;      // (a sample's elements fit 32 bits: host check)
+        const char* rowp = xn + (rowel << SH);
+        char* lrow = lds + r * (HX * 64);
+#pragma unroll
+        for (int sgm = 0; sgm < NSEG; ++sgm) {
+            const char* src = (okrow && okx[sgm]) ? rowp + xoff[sgm] : zp;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                             (__attribute__((address_space(3))) void*)(lrow + sgm * 1024), 16, 0, 0);
+        }
+        if constexpr (NTAIL > 0) {
+            if (lane < 16 * NTAIL) {
+                const char* src = (okrow && tok) ? rowp + toff : zp;
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                                 (__attribute__((address_space(3))) void*)(lrow + NSEG * 1024), 4, 0, 0);
+            }
+        }
+    }
+}
+
+template <typename T, typename G, int UPS, int NWAVES = 4>
+__device__ __forceinline__ void stage_halo_dma_gen(char* lds, const T* __restrict__ x, const ConvArgs& a, int n, int oz0, int oy0,
+                                                   int ox0, int kb, int wave, int lane, int ss, int soz, int soy, int sox, int sDz,
+                                                   int sDy, int sDx) {
+#if VDM_ROWSTAGE
+    stage_halo_dma_rows<T, G, UPS, NWAVES>(lds, x, a, n, oz0, oy0, ox0, kb, wave, lane, ss, soz, soy, sox, sDz, sDy, sDx);
+#else
+    stage_halo_dma_chunks<T, G, UPS, NWAVES>(lds, x, a, n, oz0, oy0, ox0, kb, wave, lane, ss, soz, soy, sox, sDz, sDy, sDx);
+#endif
 }
 
 // GroupNorm + SiLU applied to the staged halo image in place (inference: the conv input is silu(gn(x)) of a tensor nobody else
@@ -213,7 +306,7 @@ __device__ __forceinline__ void gn_prologue_table(float* tab, const ConvArgs& a,
 template <typename T, typename G, int UPS>
 __device__ __forceinline__ void stage_halo_dma(char* lds, const T* __restrict__ x, const ConvArgs& a, int n,
                                                int oz0, int oy0, int ox0, int kb, int wave, int lane) {
-    stage_halo_dma_gen<T, G, UPS>(lds, x, a, n, oz0, oy0, ox0, kb, wave, lane, 1, 0, 0, 0, a.Sz, a.Sy, a.Sx);
+    stage_halo_dma_gen<T, G, UPS, G::NW>(lds, x, a, n, oz0, oy0, ox0, kb, wave, lane, 1, 0, 0, 0, a.Sz, a.Sy, a.Sx);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -432,7 +525,7 @@ __device__ __forceinline__ float row16_sum(float v) {
     return v;
 }
 
-template <int NC>
+template <int NC, int NW = 4>
 __device__ __forceinline__ void gn_partials_reduce(float (&gs)[NC * 4], float (&gq)[NC * 4], float* sm, float* dst /* [Cout][2] of this tile */,
                                                    int cout0, int Cout, int wave, int lane, int qstride = NC * 4) {
     const int lx = lane & 15, q = lane >> 4;
@@ -452,7 +545,10 @@ __device__ __forceinline__ void gn_partials_reduce(float (&gs)[NC * 4], float (&
     const int t = wave * 64 + lane;
     if (t < NC * 16 * 2) {
         const int c = ((t >> 1) / (NC * 4)) * qstride + (t >> 1) % (NC * 4);      // lane group q owns NC*4 channels every qstride
-        const float tot = (sm[t] + sm[NC * 16 * 2 + t]) + (sm[2 * NC * 16 * 2 + t] + sm[3 * NC * 16 * 2 + t]);
+        float tot = (sm[t] + sm[NC * 16 * 2 + t]) + (sm[2 * NC * 16 * 2 + t] + sm[3 * NC * 16 * 2 + t]);
+        if constexpr (NW == 8)
+            tot += (sm[4 * NC * 16 * 2 + t] + sm[5 * NC * 16 * 2 + t]) + (sm[6 * NC * 16 * 2 + t] + sm[7 * NC * 16 * 2 + t]);
+        static_assert(NW == 4 || NW == 8, "4 or 8 waves fold their tile sums");
         if (cout0 + c < Cout) dst[(size_t)(cout0 + c) * 2 + (t & 1)] = tot;
     }
 }
@@ -577,8 +673,8 @@ __device__ __forceinline__ void conv_epilogue(const f32x4 (&acc)[NV][NC], const 
         }
     }
     if (a.gnp)                                            // workgroup-uniform
-        gn_partials_reduce<NC>(gs, gq, gn_sm, a.gnp + ((size_t)n * (a.ntz * a.nty * a.ntx) + tile) * a.Cout * 2, cout0, a.Cout,
-                               cwave, lane, qstride);
+        gn_partials_reduce<NC, G::NW>(gs, gq, gn_sm, a.gnp + ((size_t)n * (a.ntz * a.nty * a.ntx) + tile) * a.Cout * 2, cout0, a.Cout,
+                                      cwave, lane, qstride);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -766,8 +862,8 @@ __device__ __forceinline__ void conv_epilogue_gnb(const f32x4 (&acc)[NV][NC], co
             st_sub<T, SUB>(out + (vox * (unsigned)C + (unsigned)(cbase + sc * SUB)), d);
         }
     }
-    gn_partials_reduce<NC>(gsum, gsq, gn_sm, a.gnp + ((size_t)n * (a.ntz * a.nty * a.ntx) + tile) * a.Cout * 2, cout0, a.Cout, cwave,
-                           lane, qstride);
+    gn_partials_reduce<NC, G::NW>(gsum, gsq, gn_sm, a.gnp + ((size_t)n * (a.ntz * a.nty * a.ntx) + tile) * a.Cout * 2, cout0, a.Cout, cwave,
+                                  lane, qstride);
 }
 
 struct ClsEntry { int lds_off; int dx; };                   // halo offset ((dz*HY+dy)*HX)*64 bytes and dx in 0..2

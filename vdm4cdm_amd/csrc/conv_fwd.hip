@@ -12,12 +12,15 @@ namespace vdm {
 // GNB: the GroupNorm+SiLU backward reduction is folded into the epilogue (dgrad launches that feed a GroupNorm: conv_epilogue_gnb).
 // GNP: the conv input is silu(gn(x)) of the raw tensor x (inference): GroupNorm + SiLU are applied to the staged image in LDS
 // (gn_prologue_inplace) instead of by a pass of their own.
-template <typename T, typename TO, int KS, int STRIDE, int UPS, int NC, int TZ, int TY, bool SPLIT = false, bool GNB = false, bool GNP = false>
-__global__ void __launch_bounds__(256, (TZ * TY <= 16 && NC <= 2) ? 3 : 2) conv_fwd_kernel(const ConvArgs a) {
+// NW = 8 (large bf16 3x3x3 stride-1 grids): the SAME tile and LDS image shared by eight waves of NV = 4 rows - two workgroups per CU
+// are then four waves per SIMD (<= 128 registers each) instead of two: twice the waves to issue the staging DMA, to cover the
+// barrier-to-barrier phases of the co-resident workgroup and to drain the epilogue, at unchanged staged bytes per voxel.
+template <typename T, typename TO, int KS, int STRIDE, int UPS, int NC, int TZ, int TY, bool SPLIT = false, bool GNB = false, bool GNP = false, int NW = 4>
+__global__ void __launch_bounds__(64 * NW, NW == 8 ? 4 : ((TZ * TY <= 16 && NC <= 2) ? 3 : 2)) conv_fwd_kernel(const ConvArgs a) {
     static_assert(!SPLIT || NC == 2, "half-chunk mode is the NC=2 kernel on NC=4 weights");
     static_assert(!(GNB && GNP), "the prologue belongs to forward convs, the folded backward to dgrad convs");
     constexpr int NCW = SPLIT ? 4 : NC;
-    using G = Geo<KS, STRIDE, TZ, TY>;
+    using G = Geo<KS, STRIDE, TZ, TY, NW>;
     constexpr int NV = G::NV, TAPS = G::TAPS;
     extern __shared__ __attribute__((aligned(16))) char lds[];
 
@@ -53,19 +56,23 @@ __global__ void __launch_bounds__(256, (TZ * TY <= 16 && NC <= 2) ? 3 : 2) conv_
     // the loads retire behind the first staging barrier instead of stalling the epilogue
     const int e_cout0 = SPLIT ? (chunk >> 1) * 64 + (chunk & 1) * 8 : chunk * NC * 16, e_qstride = SPLIT ? 16 : NC * 4;
     GnbRegs<T, NC, GNB ? NV : 1> gr;
-    if constexpr (GNB && NC <= 2) gnb_issue<T, G, NC, NV>(gr, a, n, oz0, oy0, ox0, wave, lane, e_cout0, e_qstride);
+    constexpr bool GNB_PRE = GNB && NC <= 2 && NW == 4;      // (eight-wave workgroups: 128 registers per wave, the rolling window instead)
+    if constexpr (GNB_PRE) gnb_issue<T, G, NC, NV>(gr, a, n, oz0, oy0, ox0, wave, lane, e_cout0, e_qstride);
     float badd[NC * 4];                                      // bias + conditioning bias of the lane's channels (latency hidden behind the taps)
     if constexpr (!GNB) load_badd<NC>(badd, a, n, e_cout0 + (lane >> 4) * e_qstride);
 
     for (int kb = 0; kb < a.nkb; ++kb) {
         if (kb) __syncthreads();
-        stage_halo_dma<T, G, UPS>(lds, x, a, n, oz0, oy0, ox0, kb, wave, lane);
+        if constexpr (GNP)      // (the in-place GroupNorm prologue re-walks the chunks a wave staged: the chunk walk)
+            stage_halo_dma_chunks<T, G, UPS, NW>(lds, x, a, n, oz0, oy0, ox0, kb, wave, lane, 1, 0, 0, 0, a.Sz, a.Sy, a.Sx);
+        else
+            stage_halo_dma<T, G, UPS>(lds, x, a, n, oz0, oy0, ox0, kb, wave, lane);
         if (kb == 0) VDM_STAMP(6);
         constexpr int IMG_ = ((G::HVOX + 15) / 16) * 1024;
         float* gn_tab = reinterpret_cast<float*>(lds + IMG_ + GN_SCRATCH_BYTES);
         if constexpr (GNP) {
             if (kb == 0) {                                  // (behind the first DMA issue: the table is built while the halo is in flight)
-                gn_prologue_table(gn_tab, a, n, tid, 256);
+                gn_prologue_table(gn_tab, a, n, tid, 64 * NW);
                 __syncthreads();
             }
         }
@@ -77,13 +84,13 @@ __global__ void __launch_bounds__(256, (TZ * TY <= 16 && NC <= 2) ? 3 : 2) conv_
             if constexpr (RR) rr_prefetch_weights<NC, WPD, NCW>(wf, wk);
             else taps_prefetch_weights<TAPS, NC, WPD, NCW>(wf, wk);
             if (kb == 0) VDM_STAMP(1);
-            if constexpr (GNP) gn_prologue_inplace<T, G>(lds, gn_tab, a, oz0, oy0, ox0, kb, wave, lane);
+            if constexpr (GNP) gn_prologue_inplace<T, G, NW>(lds, gn_tab, a, oz0, oy0, ox0, kb, wave, lane);
             __syncthreads();
             if (kb == 0) VDM_STAMP(2);
             if constexpr (RR) taps_rowreuse<T, G, NC, NV, WPD, NCW>(acc, lds, wk, wf, lanex);
             else taps_pipelined<T, G, NC, NV, WPD, NCW>(acc, lds, wk, wf, lanex);
         } else {
-            if constexpr (GNP) gn_prologue_inplace<T, G>(lds, gn_tab, a, oz0, oy0, ox0, kb, wave, lane);
+            if constexpr (GNP) gn_prologue_inplace<T, G, NW>(lds, gn_tab, a, oz0, oy0, ox0, kb, wave, lane);
             __syncthreads();
             taps_rolled<T, G, NC, NV>(acc, lds, wk, lanex);
         }
@@ -94,14 +101,14 @@ __global__ void __launch_bounds__(256, (TZ * TY <= 16 && NC <= 2) ? 3 : 2) conv_
     const int tile = (tz * a.nty + ty) * a.ntx + tx;
     if constexpr (GNB) {
         static_assert(sizeof(T) == sizeof(TO), "the folded GroupNorm backward stores dyh in the activation dtype");
-        conv_epilogue_gnb<T, G, NC, NV, (NC <= 2)>(acc, a, gr, n, oz0, oy0, ox0, wave, lane, gn_sm, tile, e_cout0, e_qstride);
+        conv_epilogue_gnb<T, G, NC, NV, GNB_PRE>(acc, a, gr, n, oz0, oy0, ox0, wave, lane, gn_sm, tile, e_cout0, e_qstride);
     } else
         conv_epilogue<T, TO, G, NC, NV>(acc, a, badd, n, oz0, oy0, ox0, wave, lane, gn_sm, tile, e_cout0, e_qstride);
 #ifdef VDM_TIMELINE
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // (the stores of the epilogue have left the wave's queue)
     VDM_STAMP(4);
     if (a.stamps && lane == 0) {
-        unsigned long long* o = a.stamps + ((size_t)blockIdx.x * 4 + wave) * 8;
+        unsigned long long* o = a.stamps + ((size_t)blockIdx.x * NW + wave) * 8;
         for (int k = 0; k < 7; ++k) o[k] = tl_t[k];
         o[7] = ((unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 20) << 32) | (unsigned)__builtin_amdgcn_s_getreg((31 << 11) | 4);
     }
@@ -306,14 +313,14 @@ __global__ void __launch_bounds__(256, GNB ? 2 : 4) conv_kpack_kernel(const Conv
                                         (tz * a.nty + ty) * a.ntx + tx, chunk * NC * 16, NC * 4);
 }
 
-template <typename T, typename TO, int KS, int STRIDE, int UPS, int NC, int TZ, int TY, bool SPLIT = false, bool GNB = false, bool GNP = false>
+template <typename T, typename TO, int KS, int STRIDE, int UPS, int NC, int TZ, int TY, bool SPLIT = false, bool GNB = false, bool GNP = false, int NW = 4>
 static int launch_fwd_cfg(const ConvArgs& a0, hipStream_t s) {
-    using G = Geo<KS, STRIDE, TZ, TY>;
+    using G = Geo<KS, STRIDE, TZ, TY, NW>;
     ConvArgs a = a0;
     if (SPLIT) a.nchunks *= 2;
     a.ntz = cdiv(a.Dz, TZ); a.nty = cdiv(a.Dy, TY); a.ntx = cdiv(a.Dx, 16);
     const size_t lds = (size_t)((G::HVOX + 15) / 16) * 1024 + GN_SCRATCH_BYTES + (GNP ? GNP_TABLE_BYTES : 0);
-    auto kern = conv_fwd_kernel<T, TO, KS, STRIDE, UPS, NC, TZ, TY, SPLIT, GNB, GNP>;
+    auto kern = conv_fwd_kernel<T, TO, KS, STRIDE, UPS, NC, TZ, TY, SPLIT, GNB, GNP, NW>;
     static unsigned long long lds_done = 0;
     {
         int e = set_lds(kern, lds, lds_done);
@@ -324,9 +331,15 @@ static int launch_fwd_cfg(const ConvArgs& a0, hipStream_t s) {
 #ifdef VDM_TIMELINE
     a.stamps = g_timeline_stamps;
 #endif
-    hipLaunchKernelGGL(kern, dim3((unsigned)nwg), dim3(256), lds, s, a);
+    hipLaunchKernelGGL(kern, dim3((unsigned)nwg), dim3(64 * NW), lds, s, a);
     VDM_LAUNCH_CHECK("conv_fwd_kernel");
     return VDM_OK;
+}
+
+// VDM4CDM_WG8: bit mask of the NC = 2 kernel classes that run eight-wave workgroups on the 4x8x16 tile - 1: plain, 2: folded GroupNorm backward
+static bool wg8_enabled(int nc, bool gnb) {
+    static const int mask = getenv("VDM4CDM_WG8") ? atoi(getenv("VDM4CDM_WG8")) : 0;
+    return nc == 2 && ((mask >> (gnb ? 1 : 0)) & 1);
 }
 
 template <typename T, typename TO, int NC, int TY, bool GNB>
@@ -367,6 +380,10 @@ static int launch_fwd_geo(const ConvArgs& a, hipStream_t s) {
         }
         if (tz == 1) return ty == 4 ? launch_fwd_cfg<T, TO, KS, STRIDE, UPS, NC, 1, 4, false, GNB, GNP>(a, s) : launch_fwd_cfg<T, TO, KS, STRIDE, UPS, NC, 1, 8, false, GNB, GNP>(a, s);
         if (tz == 2) return launch_fwd_cfg<T, TO, KS, STRIDE, UPS, NC, 2, 8, false, GNB, GNP>(a, s);
+        if constexpr (STRIDE == 1 && UPS == 0 && sizeof(TO) == 2 && NC == 2 && !GNP) {      // large grids: eight waves share the 4x8x16 tile
+            // (NC = 4 needs > 128 registers per wave: its accumulators alone are 64)
+            if (wg8_enabled(NC, GNB)) return launch_fwd_cfg<T, TO, KS, STRIDE, UPS, NC, 4, 8, false, GNB, GNP, 8>(a, s);
+        }
         return launch_fwd_cfg<T, TO, KS, STRIDE, UPS, NC, 4, 8, false, GNB, GNP>(a, s);
     } else
         return launch_fwd_cfg<T, TO, KS, STRIDE, UPS, NC, 4, 8, false, GNB, GNP>(a, s);

@@ -9,21 +9,43 @@ namespace vdm {
 
 // dOut tile of a wgrad workgroup by LDS-DMA: OVOX voxels x 64 B (one cout block), same x-swizzled voxel-major
 // image as stage_halo_dma (one chunk = one 16-voxel row).
+// (row-wise like stage_halo_dma_rows: the row (oz, oy) is wave-uniform - scalar validity and address; per lane only the x part,
+// computed once per tile.)  sub = 1: the class sub-grid dOut[2c + p] of the up-sampling conv's parity class (pz, py, px).
 template <typename T, typename G>
-__device__ __forceinline__ void stage_dout_dma(char* lds, const T* __restrict__ g, const ConvArgs& a, int n, int oz0, int oy0,
-                                               int ox0, int cb, int cstride, int wave, int lane) {
-    constexpr int EPL = DT<T>::EPL, KB = DT<T>::KB;
+__device__ __forceinline__ void stage_dout_dma_gen(char* lds, const T* __restrict__ g, const ConvArgs& a, int n, int oz0, int oy0,
+                                                   int ox0, int cb, int cstride, int sub, int pz, int py, int px, int wave, int lane) {
+    constexpr int EPL = DT<T>::EPL, KB = DT<T>::KB, SH = DT<T>::SHIFT;
     const int k = lane >> 2, j = lane & 3;
     const int pc = j ^ ((k >> 1) & 3);
     const int co = cb * KB + pc * EPL;
+    const int ox = ox0 + k;
+    const int m = sub ? 2 : 1;                                               // fine-grid voxels per tile voxel and dimension
+    const bool okx = co < a.Cout && ox < a.Dx;
+    const unsigned xoff = (__umul24((unsigned)(m * ox + px) & 0xffffffu, (unsigned)cstride) + (unsigned)co) << SH;
+    const char* gn = reinterpret_cast<const char*>(g) + (((size_t)n * (m * a.Dz) * (m * a.Dy) * (m * a.Dx) * cstride) << SH);
+    const char* zp = reinterpret_cast<const char*>(g_zero_page);
     for (int r = wave; r < G::ROWS; r += 4) {
-        const int oz = oz0 + r / G::TY, oy = oy0 + r % G::TY, ox = ox0 + k;
-        const bool ok = co < a.Cout && oz < a.Dz && oy < a.Dy && ox < a.Dx;
-        const size_t off = ((((size_t)n * a.Dz + oz) * a.Dy + oy) * a.Dx + ox) * cstride + co;
-        const void* src = ok ? static_cast<const void*>(g + off) : static_cast<const void*>(g_zero_page);
+        const int oz = oz0 + r / G::TY, oy = oy0 + r % G::TY;
+        const bool okrow = oz < a.Dz && oy < a.Dy;
+        const unsigned fz = okrow ? (unsigned)(m * oz + pz) : 0u, fy = okrow ? (unsigned)(m * oy + py) : 0u;
+        const size_t rowel = (size_t)((fz * (unsigned)(m * a.Dy) + fy) * (unsigned)(m * a.Dx)) * (unsigned)cstride;
+        const char* src = (okrow && okx) ? gn + (rowel << SH) + xoff : zp;
         __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
                                          (__attribute__((address_space(3))) void*)(lds + r * 1024), 16, 0, 0);
     }
+}
+
+template <typename T, typename G>
+__device__ __forceinline__ void stage_dout_dma(char* lds, const T* __restrict__ g, const ConvArgs& a, int n, int oz0, int oy0,
+                                               int ox0, int cb, int cstride, int wave, int lane) {
+    stage_dout_dma_gen<T, G>(lds, g, a, n, oz0, oy0, ox0, cb, cstride, 0, 0, 0, 0, wave, lane);
+}
+
+// dOut tile of one parity class of the up-sampling conv: the tile's coarse voxels c map to the fine voxels 2c + p.
+template <typename T, typename G>
+__device__ __forceinline__ void stage_dout_dma_sub(char* lds, const T* __restrict__ g, const ConvArgs& a, int n, int oz0, int oy0,
+                                                   int ox0, int cb, int cstride, int pz, int py, int px, int wave, int lane) {
+    stage_dout_dma_gen<T, G>(lds, g, a, n, oz0, oy0, ox0, cb, cstride, 1, pz, py, px, wave, lane);
 }
 
 // Transposed operand fetch from the x-swizzled voxel-major image: 16 channels (tile ct of the 64-B block) x the
@@ -32,24 +54,6 @@ __device__ __forceinline__ void stage_dout_dma(char* lds, const T* __restrict__ 
 //         lane: g = lane>>4 (voxels 4g..4g+3), li = lane&15: voxel-in-quad q' = li>>2, column quad p = li&3.
 //         Voxels x and x+4 of a 32-lane half use opposite piece pairs ((hx>>1)&3 differs by 2): conflict-free.
 //   fp32: NOFF = 4, four ds_read_b32 (MFMA step s reads voxel x = 4*s + (lane>>4), channel lane&15).
-// dOut tile of one parity class of the up-sampling conv: the tile's coarse voxels c map to the fine voxels 2c + p.
-template <typename T, typename G>
-__device__ __forceinline__ void stage_dout_dma_sub(char* lds, const T* __restrict__ g, const ConvArgs& a, int n, int oz0, int oy0,
-                                                   int ox0, int cb, int cstride, int pz, int py, int px, int wave, int lane) {
-    constexpr int EPL = DT<T>::EPL, KB = DT<T>::KB;
-    const int k = lane >> 2, j = lane & 3;
-    const int pc = j ^ ((k >> 1) & 3);
-    const int co = cb * KB + pc * EPL;
-    for (int r = wave; r < G::ROWS; r += 4) {
-        const int oz = oz0 + r / G::TY, oy = oy0 + r % G::TY, ox = ox0 + k;
-        const bool ok = co < a.Cout && oz < a.Dz && oy < a.Dy && ox < a.Dx;
-        const size_t off = ((((size_t)n * (2 * a.Dz) + 2 * oz + pz) * (2 * a.Dy) + 2 * oy + py) * (2 * a.Dx) + 2 * ox + px) * cstride + co;
-        const void* src = ok ? static_cast<const void*>(g + off) : static_cast<const void*>(g_zero_page);
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-                                         (__attribute__((address_space(3))) void*)(lds + r * 1024), 16, 0, 0);
-    }
-}
-
 template <typename T> struct TrFetch;
 template <> struct TrFetch<bf16_t> {
     static constexpr int NOFF = 1;

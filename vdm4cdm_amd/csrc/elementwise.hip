@@ -592,6 +592,103 @@ __global__ void __launch_bounds__(256) randn_kernel(float* __restrict__ out, int
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Fused head of the training step (K7 + the input packing of conv_in): z_t = alpha[n] x + sigma[n] eps with eps drawn IN the kernel
+// (Philox, the counters of randn_kernel: same (seed, stream id, element group) -> the same field vdm_randn would have written) or
+// read (supplied noise: parity tests), written once as fp32 (optional) and once as the NDHWC input of conv_in
+// [z_t, s_conditioning, 0 ...] in the compute dtype - randn + diffuse + pack_input in one pass over x.
+// A thread owns 4 consecutive voxels (one Philox call); the 16-byte pieces of the packed tensor are re-dealt inside the wave so
+// that every store instruction writes 1 KiB contiguously (lane L stores piece 64 r + L of the wave's 256 in round r).
+// ---------------------------------------------------------------------------------------------
+template <typename T>
+__global__ void __launch_bounds__(256) diffuse_pack_kernel(const float* __restrict__ x, const float* __restrict__ sc, const float* __restrict__ eps,
+                                                          uint64_t seed0, uint64_t sid, const int32_t* __restrict__ seed_step,
+                                                          const float* __restrict__ alpha, const float* __restrict__ sigma, int64_t per,
+                                                          float* __restrict__ z, T* __restrict__ packed, int blocks_per_n) {
+    constexpr int EPL = DT<T>::EPL;
+    const int n = blockIdx.x / blocks_per_n, bn = blockIdx.x % blocks_per_n;
+    const uint64_t seed = mix_seed(seed0, seed_step);
+    const float al = alpha[n], si = sigma[n];
+    const int64_t n4 = per >> 2;                                   // (host: per % 4 == 0)
+    const size_t base = (size_t)n * per;
+    const float4* x4 = reinterpret_cast<const float4*>(x + base);
+    const float4* s4 = sc ? reinterpret_cast<const float4*>(sc + base) : nullptr;
+    const float4* e4 = eps ? reinterpret_cast<const float4*>(eps + base) : nullptr;
+    float4* z4 = z ? reinterpret_cast<float4*>(z + base) : nullptr;
+    const int lane = threadIdx.x & 63;
+    const int src0 = lane >> 2, comp = lane & 3;
+    const int64_t rounds = (n4 + (int64_t)blocks_per_n * 256 - 1) / ((int64_t)blocks_per_n * 256);      // uniform trip count: the
+    for (int64_t it = 0; it < rounds; ++it) {                                                           // shuffles need every lane
+        const int64_t i = (it * blocks_per_n + bn) * 256 + threadIdx.x;
+        const bool ok = i < n4;
+        const int64_t ic = ok ? i : n4 - 1;
+        const float4 xv = x4[ic];
+        const float4 sv = s4 ? s4[ic] : make_float4(0.f, 0.f, 0.f, 0.f);
+        const float4 ev = e4 ? e4[ic] : randn4(seed, sid, (uint64_t)((int64_t)n * n4 + ic));
+        const float zz[4] = {al * xv.x + si * ev.x, al * xv.y + si * ev.y, al * xv.z + si * ev.z, al * xv.w + si * ev.w};
+        const float ss[4] = {sv.x, sv.y, sv.z, sv.w};
+        if (z4 && ok) z4[i] = make_float4(zz[0], zz[1], zz[2], zz[3]);
+        const int64_t wave_g0 = i - lane;                            // first group of this wave (lane 0's)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int src = 16 * r + src0;
+            float zr = 0.f, sr = 0.f;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const float a = __shfl(zz[k], src, 64), b = __shfl(ss[k], src, 64);
+                if (k == comp) { zr = a; sr = b; }
+            }
+            const int64_t vox = 4 * wave_g0 + 64 * r + lane;        // voxel inside the sample
+            if (vox < per) {
+                Piece<T> pc;
+#pragma unroll
+                for (int j = 0; j < EPL; ++j) pc.f[j] = 0.f;
+                pc.f[0] = zr; pc.f[1] = sr;
+                *reinterpret_cast<uint4*>(packed + (base + (size_t)vox) * EPL) = pc.store();
+            }
+        }
+    }
+}
+
+// K8 with the noise fields regenerated from their Philox counters instead of read (eps / eps0 NULL): the two 4-byte-per-element
+// fields of a training step never exist in memory.  Vector form of loss_terms_kernel (4 elements per thread; per % 4 == 0).
+__global__ void __launch_bounds__(256) loss_terms_rng_kernel(const float* __restrict__ x, const float* __restrict__ eps, uint64_t seed_e0,
+                                                            uint64_t sid_e, const float* __restrict__ eh, const float* __restrict__ eps0,
+                                                            uint64_t seed_00, uint64_t sid_0, const int32_t* __restrict__ seed_step, float s0a0,
+                                                            const float* __restrict__ coef, int64_t per, float* __restrict__ part,
+                                                            float* __restrict__ deh, int blocks_per_n) {
+    const int n = blockIdx.x / blocks_per_n, bn = blockIdx.x % blocks_per_n;
+    const float cf = coef[n];
+    const size_t base = (size_t)n * per;
+    const int64_t n4 = per >> 2;
+    const uint64_t seed_e = mix_seed(seed_e0, seed_step), seed_0 = mix_seed(seed_00, seed_step);
+    const float4* x4 = reinterpret_cast<const float4*>(x + base);
+    const float4* h4 = reinterpret_cast<const float4*>(eh + base);
+    const float4* e4 = eps ? reinterpret_cast<const float4*>(eps + base) : nullptr;
+    const float4* o4 = eps0 ? reinterpret_cast<const float4*>(eps0 + base) : nullptr;
+    float4* d4 = reinterpret_cast<float4*>(deh + base);
+    float acc[3] = {0.f, 0.f, 0.f};
+    for (int64_t i = (int64_t)bn * 256 + threadIdx.x; i < n4; i += (int64_t)blocks_per_n * 256) {
+        const uint64_t g = (uint64_t)((int64_t)n * n4 + i);
+        const float4 xv = x4[i], hv = h4[i];
+        const float4 ev = e4 ? e4[i] : randn4(seed_e, sid_e, g);
+        const float4 ov = o4 ? o4[i] : randn4(seed_0, sid_0, g);
+        const float d0 = hv.x - ev.x, d1 = hv.y - ev.y, d2 = hv.z - ev.z, d3 = hv.w - ev.w;
+        acc[0] += (d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3);
+        acc[1] += (xv.x * xv.x + xv.y * xv.y) + (xv.z * xv.z + xv.w * xv.w);
+        const float r0 = s0a0 * ov.x, r1 = s0a0 * ov.y, r2 = s0a0 * ov.z, r3 = s0a0 * ov.w;
+        acc[2] += (r0 * r0 + r1 * r1) + (r2 * r2 + r3 * r3);
+        d4[i] = make_float4(cf * d0, cf * d1, cf * d2, cf * d3);
+    }
+    __shared__ float sm[12];
+    block_sum<3>(acc, sm);
+    if (threadIdx.x == 0) {
+        part[(size_t)blockIdx.x * 3 + 0] = acc[0];
+        part[(size_t)blockIdx.x * 3 + 1] = acc[1];
+        part[(size_t)blockIdx.x * 3 + 2] = acc[2];
+    }
+}
+
 // eu != NULL: classifier-free guidance - the noise estimate is (1 + w) * eh - w * eu (conditional / v-masked UNet outputs, the two
 // halves of one batch-doubled forward), blended here so that the guided estimate never exists in memory.
 __global__ void __launch_bounds__(256) ancestral_kernel(float* __restrict__ z, const float* __restrict__ eh,
@@ -948,6 +1045,36 @@ extern "C" int vdm_loss_terms(const float* x, const float* eps, const float* eps
                        d_eps_hat, bpn);
     hipLaunchKernelGGL(fold_partials_kernel, dim3(n * 3), dim3(256), 0, (hipStream_t)stream, (const float*)workspace, bpn, 3, sums, 1);
     VDM_LAUNCH_CHECK("loss_terms_kernel");
+    return VDM_OK;
+}
+
+extern "C" int vdm_diffuse_pack(const float* x, const float* s_cond, const float* eps, uint64_t seed, uint64_t stream_id,
+                                const int32_t* seed_step, const float* alpha, const float* sigma, int n, int64_t per, int dtype, float* z_t,
+                                void* packed, void* stream) {
+    VDM_REQUIRE(x && alpha && sigma && packed && n > 0 && per > 0 && per % 4 == 0, "diffuse_pack: bad arguments (per must be a multiple of 4)");
+    VDM_REQUIRE(dtype == VDM_F32 || dtype == VDM_BF16, "diffuse_pack: bad dtype %d", dtype);
+    const int bpn = bpn_for(per / 4, n);
+    hipStream_t s = (hipStream_t)stream;
+    if (dtype == VDM_F32)
+        hipLaunchKernelGGL(diffuse_pack_kernel<float>, dim3(bpn * n), dim3(256), 0, s, x, s_cond, eps, seed, stream_id, seed_step, alpha, sigma, per,
+                           z_t, (float*)packed, bpn);
+    else
+        hipLaunchKernelGGL(diffuse_pack_kernel<bf16_t>, dim3(bpn * n), dim3(256), 0, s, x, s_cond, eps, seed, stream_id, seed_step, alpha, sigma, per,
+                           z_t, (bf16_t*)packed, bpn);
+    VDM_LAUNCH_CHECK("diffuse_pack_kernel");
+    return VDM_OK;
+}
+
+extern "C" int vdm_loss_terms_rng(const float* x, const float* eps, uint64_t seed_eps, uint64_t stream_eps, const float* eps_hat,
+                                  const float* eps0, uint64_t seed_eps0, uint64_t stream_eps0, const int32_t* seed_step, float s0a0,
+                                  const float* coef, int n, int64_t per, float* sums, float* d_eps_hat, float* workspace, void* stream) {
+    VDM_REQUIRE(x && eps_hat && coef && sums && d_eps_hat && workspace && n > 0 && per > 0 && per % 4 == 0,
+                "loss_terms_rng: bad arguments (per must be a multiple of 4)");
+    const int bpn = bpn_for(per / 4, n);
+    hipLaunchKernelGGL(loss_terms_rng_kernel, dim3(bpn * n), dim3(256), 0, (hipStream_t)stream, x, eps, seed_eps, stream_eps, eps_hat, eps0,
+                       seed_eps0, stream_eps0, seed_step, s0a0, coef, per, workspace, d_eps_hat, bpn);
+    hipLaunchKernelGGL(fold_partials_kernel, dim3(n * 3), dim3(256), 0, (hipStream_t)stream, (const float*)workspace, bpn, 3, sums, 1);
+    VDM_LAUNCH_CHECK("loss_terms_rng_kernel");
     return VDM_OK;
 }
 

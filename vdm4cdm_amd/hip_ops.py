@@ -704,6 +704,23 @@ def diffuse(x, eps, alpha, sigma, out=None):
     return out
 
 
+def diffuse_pack(x, s_cond, alpha, sigma, dtype, eps=None, seed=0, stream_id=0, want_z=False):
+    """Fused head of the training step (vdm_diffuse_pack): z_t = alpha[n] x + sigma[n] eps -> (z_t fp32 or None, conv_in's NDHWC input
+    [N, D, H, W, cpad(2)] = {z_t, s_cond, 0...} in `dtype`).  eps None: drawn inside the kernel from Philox(seed, stream_id) - the field
+    randn(out, seed, stream_id) would have written."""
+    L = _lib.lib()
+    _contig(x, s_cond, eps, alpha, sigma)
+    n = x.shape[0]
+    per = x.numel() // n
+    assert x.dtype == torch.float32 and per % 4 == 0 and (s_cond is None or (s_cond.shape == x.shape and s_cond.dtype == torch.float32))
+    sp = tuple(x.shape[2:]) if x.dim() == 5 else tuple(x.shape[1:])
+    packed = torch.empty((n,) + sp + (cpad(2, dtype),), dtype=dtype, device=x.device)
+    z = torch.empty_like(x) if want_z else None
+    check(L.vdm_diffuse_pack(_p(x), _p(s_cond), _p(eps), int(seed), int(stream_id), _p(SEED_STEP), _p(alpha), _p(sigma), n, per, dt_id(dtype),
+                             _p(z), _p(packed), _s()), "vdm_diffuse_pack")
+    return z, packed
+
+
 _red_ws = {}
 
 
@@ -716,11 +733,22 @@ def _reduce_ws(device):
     return ws
 
 
-def loss_terms(x, eps, eps_hat, eps0, sigma0_over_alpha0, coef, sums, d_eps_hat):
+def loss_terms(x, eps, eps_hat, eps0, sigma0_over_alpha0, coef, sums, d_eps_hat, rng=None):
+    """K8.  rng = ((seed_eps, stream_eps), (seed_eps0, stream_eps0)): a noise field passed as None is regenerated inside the kernel from
+    its Philox counters (vdm_loss_terms_rng) instead of read."""
     L = _lib.lib()
     _contig(x, eps, eps_hat, eps0, coef, sums, d_eps_hat)
     n = x.shape[0]
-    check(L.vdm_loss_terms(_p(x), _p(eps), _p(eps_hat), _p(eps0), float(sigma0_over_alpha0), _p(coef), n, x.numel() // n,
+    per = x.numel() // n
+    if per % 4 == 0 and (rng is not None or (eps is not None and eps0 is not None)):      # vector kernel (also for supplied fields: one
+        (se, ie), (s0, i0) = rng if rng is not None else ((0, 0), (0, 0))                   # summation order for both forms)
+        assert rng is not None or (eps is not None and eps0 is not None)
+        check(L.vdm_loss_terms_rng(_p(x), _p(eps), int(se), int(ie), _p(eps_hat), _p(eps0), int(s0), int(i0), _p(SEED_STEP),
+                                   float(sigma0_over_alpha0), _p(coef), n, per, _p(sums), _p(d_eps_hat), _p(_reduce_ws(x.device)), _s()),
+              "vdm_loss_terms_rng")
+        return
+    assert eps is not None and eps0 is not None, "loss_terms: noise fields missing (and no Philox counters to regenerate them from)"
+    check(L.vdm_loss_terms(_p(x), _p(eps), _p(eps_hat), _p(eps0), float(sigma0_over_alpha0), _p(coef), n, per,
                            _p(sums), _p(d_eps_hat), _p(_reduce_ws(x.device)), _s()), "vdm_loss_terms")
 
 

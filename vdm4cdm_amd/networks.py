@@ -341,7 +341,9 @@ class CUNet(nn.Module):
         return specs
 
     # ------------------------------------------------------------------ forward
-    def forward(self, x, t=None, s_conditioning=None, v_conditionings=None, **ignored):
+    def forward(self, x, t=None, s_conditioning=None, v_conditionings=None, _packed_input=None, **ignored):
+        """_packed_input (HIP backend, internal): conv_in's NDHWC input [B, D, H, W, cpad(2)] = {x, s_conditioning, 0...} already packed in
+        the compute dtype by the caller (VDM.get_loss' fused head: vdm_diffuse_pack wrote it while it formed x = z_t)."""
         B = x.shape[0]
         if t is not None:
             t = torch.as_tensor(t, dtype=torch.float32, device=x.device).reshape(-1)
@@ -363,7 +365,7 @@ class CUNet(nn.Module):
             assert t is not None, "t_conditioning=True needs t"
         vs = list(v_conditionings or [])
         assert len(vs) == len(self.v_conditioning_dims), "len(v_conditionings) != len(v_conditioning_dims)"
-        return hip_unet_apply(self, x, s_conditioning, t=t, v_conditionings=vs)
+        return hip_unet_apply(self, x, s_conditioning, t=t, v_conditionings=vs, packed=_packed_input)
 
     # ------------------------------------------------------------------ explicit torch backend (C1 plumbing)
     def _conv_t(self, x, wname, bname, stride=1):

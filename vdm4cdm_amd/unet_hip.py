@@ -386,8 +386,9 @@ class HipUNet:
         return self._ss
 
     # ---------------------------------------------------------------------------------------
-    def forward(self, flat, table, z, s_cond, train, seed, dropout_p=None):
+    def forward(self, flat, table, z, s_cond, train, seed, dropout_p=None, packed=None):
         """z, s_cond: fp32 [N, D, H, W] (single channel).  Returns eps_hat fp32 [N, D, H, W].
+        packed: conv_in's input {z, s_cond, 0...} already in NDHWC / compute dtype (the fused head of the training step wrote it).
         train: save the activations the backward pass needs (autograd is recording).  dropout_p: dropout probability of this
         call (None: net.dropout_prob in training mode, 0 in eval mode - the nn.Dropout / F.dropout(training=self.training)
         semantics of the reference stack, independent of whether autograd records)."""
@@ -398,7 +399,12 @@ class HipUNet:
         P = lambda name: net.view(name, flat)
         L = len(net.chs)
         ss = self._side_stream(flat.device)
-        xin = ops.pack_input(z, s_cond, dtype)
+        if packed is not None:
+            assert packed.dtype == dtype and tuple(packed.shape) == tuple(z.shape) + (ops.cpad(2, dtype),) and packed.is_contiguous(), \
+                "packed conv_in input does not match (z, compute dtype)"
+            xin = packed
+        else:
+            xin = ops.pack_input(z, s_cond, dtype)
         h = self.conv_in.fwd(xin, P("conv_in.bias"), gn=FUSED_GN)
         skips = []
         for i in range(L):
@@ -500,7 +506,7 @@ class _HipUNetFn(torch.autograd.Function):
     as is."""
 
     @staticmethod
-    def forward(ctx, flat, table, z, s_cond, ex, train, seed, t, *vs):
+    def forward(ctx, flat, table, z, s_cond, ex, train, seed, t, packed, *vs):
         ctx.ex, ctx.train, ctx.cond, ctx.table_grad, ctx.nvs = ex, train, None, False, len(vs)
         net = ex.net
         with torch.no_grad():
@@ -516,14 +522,14 @@ class _HipUNetFn(torch.autograd.Function):
             else:
                 tab = table.detach().contiguous()
                 ctx.table_grad = table.requires_grad
-            return ex.forward(fl, tab, z, s_cond, train, seed)
+            return ex.forward(fl, tab, z, s_cond, train, seed, packed=packed)
 
     @staticmethod
     def backward(ctx, d_eps):
         if not ctx.train:
             raise RuntimeError("HIP CUNet: backward requested but the forward ran without saving activations")
         gflat, dtable = ctx.ex.backward(d_eps, ctx.cond)
-        return (gflat, dtable if ctx.table_grad else None, None, None, None, None, None, None) + (None,) * ctx.nvs
+        return (gflat, dtable if ctx.table_grad else None, None, None, None, None, None, None, None) + (None,) * ctx.nvs
 
 
 _seed_counter = [0]
@@ -534,7 +540,7 @@ def _dist_rank():
     return dist.get_rank() if dist.is_available() and dist.is_initialized() else 0
 
 
-def hip_unet_apply(net, x, s_conditioning, table=None, t=None, v_conditionings=None):
+def hip_unet_apply(net, x, s_conditioning, table=None, t=None, v_conditionings=None, packed=None):
     """x: [B, 1, D, H, W] fp32 on the GPU (NCDHW API; C == 1 so NDHWC is the same memory).
     table: optional precomputed conditioning table [B, table_width] (the sampler); otherwise t ([B]) / v_conditionings feed K6."""
     if net._exec is None:
@@ -563,5 +569,5 @@ def hip_unet_apply(net, x, s_conditioning, table=None, t=None, v_conditionings=N
     _seed_counter[0] += 1000
     # per-rank dropout masks under data parallelism: every rank calls seed_everything(42), so fold the rank in
     seed = (torch.initial_seed() + _seed_counter[0] + 0x9E3779B97F4A7C15 * _dist_rank()) & 0x7fffffffffffffff
-    eps = _HipUNetFn.apply(net.flat, table, z, s, net._exec, train, seed, t, *vs)
+    eps = _HipUNetFn.apply(net.flat, table, z, s, net._exec, train, seed, t, packed, *vs)
     return eps.view(x.shape)

@@ -20,7 +20,11 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
+import os
+
 DATA_NOISE = 1.0e-3
+# Fused head of the HIP training step (vdm_diffuse_pack + vdm_loss_terms_rng; VDM4CDM_FUSED_HEAD=0: randn -> diffuse -> pack_input, A/B)
+FUSED_HEAD = os.environ.get("VDM4CDM_FUSED_HEAD", "1") != "0"
 
 
 class _DiffusionLossFn(torch.autograd.Function):
@@ -46,11 +50,12 @@ class _ElboFn(torch.autograd.Function):
     (vdm_elbo_assemble) - three launches; the metrics are not differentiable, d elbo / d eps_hat = coef_n (eps_hat - eps)."""
 
     @staticmethod
-    def forward(ctx, eps_hat, x, eps, eps0, s0a0, coef, consts):
+    def forward(ctx, eps_hat, x, eps, eps0, s0a0, coef, consts, rng=None):
+        """rng = ((seed, stream) of eps, (seed, stream) of eps0): fields passed as None are regenerated in the kernel (fused head)."""
         from . import hip_ops as ops
         d = torch.empty_like(eps_hat)
         sums = torch.zeros(x.shape[0], 3, device=x.device)
-        ops.loss_terms(x, eps, eps_hat.contiguous(), eps0, s0a0, coef, sums, d)
+        ops.loss_terms(x, eps, eps_hat.contiguous(), eps0, s0a0, coef, sums, d, rng=rng)
         out = ops.elbo_assemble(sums, coef, *consts)
         ctx.save_for_backward(d)
         elbo, parts = out[0], out[1:]
@@ -60,7 +65,7 @@ class _ElboFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g, _):
         (d,) = ctx.saved_tensors
-        return g * d, None, None, None, None, None, None
+        return g * d, None, None, None, None, None, None, None
 
 
 class VDM(nn.Module):
@@ -176,10 +181,20 @@ class VDM(nn.Module):
                 raise NotImplementedError("HIP training path supports noise_schedule='fixed_linear' (all 3D scripts); "
                                           "'learned_linear' needs d loss / d z_t which the HIP backward does not emit")
             rank, world = self._rank_world()               # (Philox stream id = 2*rank + {1,2}: different noise fields per rank)
-            if eps is None:
-                eps = ops.randn(torch.empty_like(x), noise_seed(), 2 * rank + 1)
-            if eps0 is None:
-                eps0 = ops.randn(torch.empty_like(x), noise_seed(), 2 * rank + 2)
+            # Fused head: with no noise supplied, eps and eps0 are never materialised - K7 draws eps from its Philox
+            # counters while it forms z_t and writes conv_in's packed input in the same pass, K8 regenerates both fields from the same
+            # counters.  The host draws the two seeds exactly as the unfused path does (same generator state -> same noise fields).
+            sm = self.score_model
+            fuse = (FUSED_HEAD and eps is None and eps0 is None and numel % 4 == 0 and (self.w_cfg is None or self.training)
+                    and x.dim() == 5 and getattr(sm, "s_conditioning_channels", 0) <= 1)
+            rng = None
+            if fuse:
+                rng = ((noise_seed(), 2 * rank + 1), (noise_seed(), 2 * rank + 2))
+            else:
+                if eps is None:
+                    eps = ops.randn(torch.empty_like(x), noise_seed(), 2 * rank + 1)
+                if eps0 is None:
+                    eps0 = ops.randn(torch.empty_like(x), noise_seed(), 2 * rank + 2)
             # the scalar side of the step in ONE launch: time grid (stratified over the global batch), alpha_t, sigma_t, the per-sample
             # loss weight 2 w_n = gamma'(t) bpd / B and the network's normalised time - no ATen launch between the noise draw and K7
             if times is None and self.antithetic_time_sampling and ops.SEED_STEP is not None:
@@ -195,15 +210,24 @@ class VDM(nn.Module):
                     times = self.sample_times(B, x.device)
                 sc = ops.train_scalars(B, x.device, 0, 1, self.gamma_min, self.gamma_max, bpd / B,
                                        times=times.to(device=x.device, dtype=torch.float32).contiguous())
-            z_t = ops.diffuse(x, eps.contiguous(), sc[1], sc[2])
-            if self.w_cfg is None or self.training:        # get_pred_noise's plain branch, t_norm straight from the scalar kernel
-                eps_hat = self.score_model(z_t, t=sc[4], **kwargs)
+            if fuse:
+                s_c = kwargs.get("s_conditioning") if sm.s_conditioning_channels else None
+                assert s_c is not None or not sm.s_conditioning_channels, "s_conditioning_channels=1 needs s_conditioning"
+                if s_c is not None:
+                    s_c = s_c.to(device=x.device, dtype=torch.float32).expand(x.shape).contiguous()
+                dt = torch.bfloat16 if sm.precision == "bf16" else torch.float32
+                z_t, xin = ops.diffuse_pack(x, s_c, sc[1], sc[2], dt, seed=rng[0][0], stream_id=rng[0][1], want_z=True)
+                eps_hat = self.score_model(z_t, t=sc[4], _packed_input=xin, **kwargs)
             else:
-                eps_hat = self.get_pred_noise(z_t, self.gamma(sc[0]), **kwargs)
+                z_t = ops.diffuse(x, eps.contiguous(), sc[1], sc[2])
+                if self.w_cfg is None or self.training:    # get_pred_noise's plain branch, t_norm straight from the scalar kernel
+                    eps_hat = self.score_model(z_t, t=sc[4], **kwargs)
+                else:
+                    eps_hat = self.get_pred_noise(z_t, self.gamma(sc[0]), **kwargs)
             dn = self.data_noise
             consts = (float(0.5 * numel * (var1 - torch.log(var1) - 1.0) * bpd), float(0.5 * (1.0 - var1) * bpd),
                       float(0.5 / dn ** 2 * bpd), float(numel * (math.log(dn) + 0.5 * math.log(2 * math.pi)) * bpd))
-            loss, parts = _ElboFn.apply(eps_hat, x, eps, eps0.contiguous(), float(s0 / a0), sc[3], consts)
+            loss, parts = _ElboFn.apply(eps_hat, x, eps, None if eps0 is None else eps0.contiguous(), float(s0 / a0), sc[3], consts, rng)
             metrics = {"elbo": loss.detach(), "diffusion_loss": parts[0], "latent_loss": parts[1], "reconstruction_loss": parts[2]}
             return loss, metrics
         else:
