@@ -136,15 +136,22 @@ def test_c2_backward_batch2_fp32():
 
 
 # ------------------------------------------------------------------------------------------ (b) clip + AdamW
-def _adamw_cpu(params0, grads, lr, clip):
+def _adamw_cpu(params0, grads, lr, clip, exact_norm=False):
     """torch reference on the CPU: clip_grad_norm_(clip) + AdamW(lr) (defaults of the product: betas (0.9, 0.999), eps 1e-8, wd 1e-2),
-    one step per gradient in `grads`.  Returns (clipped gradients, parameter vectors after each step, norms)."""
+    one step per gradient in `grads`.  exact_norm: the clip coefficient min(1, clip / (norm + 1e-6)) from the fp64 norm instead of
+    torch's fp32 CPU norm (which is itself only good to ~2e-5 over 10^6 terms) - the same formula, evaluated exactly.
+    Returns (clipped gradients, parameter vectors after each step, norms)."""
     p = torch.nn.Parameter(params0.clone())
     opt = torch.optim.AdamW([p], lr=lr)
     clipped, after, norms = [], [], []
     for g in grads:
         p.grad = g.clone()
-        norms.append(float(torch.nn.utils.clip_grad_norm_([p], clip)))
+        if exact_norm:
+            nrm = g.double().norm().item()
+            p.grad.mul_(min(1.0, clip / (nrm + 1e-6)))
+            norms.append(nrm)
+        else:
+            norms.append(float(torch.nn.utils.clip_grad_norm_([p], clip)))
         clipped.append(p.grad.clone())
         opt.step()
         after.append(p.detach().clone())
@@ -186,12 +193,13 @@ def test_clip_and_fused_adamw_match_torch(targets):
         opt.step()
         hip_after.append(net.flat.detach().cpu().clone())
     # (1) identical gradients in, torch arithmetic on the CPU
-    clipped, after, norms = _adamw_cpu(flat0, hip_grads, lr, clip)
+    clipped, after, norms = _adamw_cpu(flat0, hip_grads, lr, clip, exact_norm=True)
+    clipped_t, _, norms_t = _adamw_cpu(flat0, hip_grads, lr, clip)           # torch.nn.utils.clip_grad_norm_ itself (fp32 norm)
     assert (norms[0] > clip) != (norms[1] > clip), f"the two steps must straddle the threshold: norms {norms}"
     prev = flat0
     for k in range(2):
-        assert hip_norms[k] == pytest.approx(hip_grads[k].double().norm().item(), rel=1e-5)       # (fp64 norm; torch's fp32 CPU norm
-        assert hip_norms[k] == pytest.approx(norms[k], rel=1e-4)                                   #  itself is only good to ~2e-5)
+        assert hip_norms[k] == pytest.approx(norms[k], rel=1e-5) and hip_norms[k] == pytest.approx(norms_t[k], rel=1e-4)
+        assert (hip_clipped[k] - clipped_t[k]).abs().max().item() <= 1e-4 * clipped_t[k].abs().max().item()
         gmax = clipped[k].abs().max().item()
         assert (hip_clipped[k] - clipped[k]).abs().max().item() <= 1e-6 * gmax, f"step {k}: clipped gradient"
         d_hip, d_ref = hip_after[k] - prev, after[k] - prev

@@ -156,11 +156,8 @@ __global__ void __launch_bounds__(256, 2) conv_cls_kernel(const ClsArgs ca) {
     int b = xcd_remap(blockIdx.x, gridDim.x);
     int cls = 0;
     if (MODE == 0) { cls = b & 7; b >>= 3; }
-    const int tx = b % a.ntx; b /= a.ntx;
-    const int ty = b % a.nty; b /= a.nty;
-    const int tz = b % a.ntz; b /= a.ntz;
-    const int n = b % a.N;
-    const int chunk = b / a.N;
+    int tx, ty, tz, n, chunk;
+    decode_tile(a, (uint32_t)b, tx, ty, tz, n, chunk);
     const int oz0 = tz * G::TZ, oy0 = ty * G::TY, ox0 = tx * 16;
 
     f32x4 acc[NV][NC];
@@ -206,6 +203,7 @@ static int launch_cls_cfg(const ClsArgs& ca0, hipStream_t s) {
     ClsArgs ca = ca0;
     ConvArgs& a = ca.c;
     a.ntz = cdiv(a.Dz, G::TZ); a.nty = cdiv(a.Dy, G::TY); a.ntx = cdiv(a.Dx, 16);
+    set_tile_divs(a);
     const size_t lds = (size_t)((G::HVOX + 15) / 16) * 1024 + GN_SCRATCH_BYTES;
     auto kern = conv_cls_kernel<T, NC, MODE>;
     static unsigned long long lds_done = 0;

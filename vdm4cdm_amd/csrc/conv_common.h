@@ -46,6 +46,24 @@ struct Geo {
     static_assert(ROWS % NW == 0, "rows must split over the waves");
 };
 
+// Division of a block / tile index by a launch constant as multiply-high + shifts (Granlund-Montgomery round-up form, exact for all
+// 32-bit n): on wave-uniform operands it is three SCALAR instructions - `b % a.ntx; b /= a.ntx` on runtime divisors compiled to a
+// float-reciprocal sequence on the vector unit (~20 vector instructions per division, eight divisions per workgroup).
+struct FastDiv { uint32_t m, s1, s2; };
+static inline FastDiv make_fastdiv(uint32_t d) {
+    FastDiv f;
+    uint32_t l = 0;
+    while ((1ull << l) < d) ++l;                          // ceil(log2 d)
+    f.m = (uint32_t)(((1ull << 32) * ((1ull << l) - d)) / d + 1);
+    f.s1 = l < 1 ? l : 1;
+    f.s2 = l > 0 ? l - 1 : 0;
+    return f;
+}
+__device__ __forceinline__ uint32_t fdiv(uint32_t n, const FastDiv& f) {
+    const uint32_t t = __umulhi(n, f.m);
+    return (t + ((n - t) >> f.s1)) >> f.s2;
+}
+
 struct ConvArgs {
     const void* x;       // staged operand (input for fwd/wgrad, dOut for dgrad)
     const void* w;       // packed weights
@@ -61,6 +79,7 @@ struct ConvArgs {
     int Cout;            // output channels (exact stride of out / res)
     int circular;
     int ntz, nty, ntx, nchunks, nkb;
+    FastDiv fdx, fdy, fdz, fdn;      // divisions by ntx, nty, ntz, N (set_tile_divs)
     float* gnp;          // optional GroupNorm partials of the output: [N][ntz*nty*ntx][Cout][2] = (sum, sum of squares) per tile
     // GroupNorm backward folded into a dgrad epilogue (conv_epilogue_gnb): the conv result is dL/dy of y = drop(silu(gn(x)));
     // the epilogue turns it into dyh = dL/dy * keep * silu'(yhat), stores THAT, and reduces per tile and channel
@@ -89,6 +108,23 @@ extern unsigned long long* g_timeline_stamps;            // set by vdm_debug_set
 #else
 #define VDM_STAMP(k) do { } while (0)
 #endif
+
+static inline void set_tile_divs(ConvArgs& a) {
+    a.fdx = make_fastdiv((uint32_t)a.ntx); a.fdy = make_fastdiv((uint32_t)a.nty); a.fdz = make_fastdiv((uint32_t)a.ntz);
+    a.fdn = make_fastdiv((uint32_t)a.N);
+}
+// linear tile id -> (tx, ty, tz, n, rest) with b = (((rest * N + n) * ntz + tz) * nty + ty) * ntx + tx; scalar arithmetic
+__device__ __forceinline__ void decode_tile(const ConvArgs& a, uint32_t b, int& tx, int& ty, int& tz, int& n, int& rest) {
+    uint32_t q = fdiv(b, a.fdx);
+    tx = (int)(b - q * (uint32_t)a.ntx); b = q;
+    q = fdiv(b, a.fdy);
+    ty = (int)(b - q * (uint32_t)a.nty); b = q;
+    q = fdiv(b, a.fdz);
+    tz = (int)(b - q * (uint32_t)a.ntz); b = q;
+    q = fdiv(b, a.fdn);
+    n = (int)(b - q * (uint32_t)a.N);
+    rest = (int)q;
+}
 
 __device__ __forceinline__ int wrap(int i, int n) {
     i %= n;
@@ -525,15 +561,37 @@ __device__ __forceinline__ float row16_sum(float v) {
     return v;
 }
 
+// the same for K values at once with the DPP operand folded into the add (v_add_f32_dpp): the builtin form above compiles to a
+// v_mov_b32_dpp + v_add_f32 pair per step (128 vector instructions for the 16 sums of an NC = 2 epilogue instead of 64).  One asm
+// statement per rotation step over all K values: a value is read by its next step K instructions later (the 2 wait states a DPP read
+// needs after a vector write of the same register are covered inside the statement; hipcc pads nothing inside asm).
+template <int K>
+__device__ __forceinline__ void row16_sum_block(float (&v)[K]) {
+    static_assert(K % 4 == 0 && K >= 4, "blocks of four values per statement");
+#define VDM_DPP4(ctl)                                                                                                            \
+    for (int i = 0; i < K; i += 4)                                                                                               \
+        asm volatile("s_nop 1\n\tv_add_f32_dpp %0, %0, %0 " ctl " row_mask:0xf bank_mask:0xf\n\t"                               \
+                     "v_add_f32_dpp %1, %1, %1 " ctl " row_mask:0xf bank_mask:0xf\n\t"                                         \
+                     "v_add_f32_dpp %2, %2, %2 " ctl " row_mask:0xf bank_mask:0xf\n\t"                                         \
+                     "v_add_f32_dpp %3, %3, %3 " ctl " row_mask:0xf bank_mask:0xf\n\ts_nop 0"                                  \
+                     : "+v"(v[i]), "+v"(v[i + 1]), "+v"(v[i + 2]), "+v"(v[i + 3]))
+#pragma unroll
+    VDM_DPP4("row_ror:8");
+#pragma unroll
+    VDM_DPP4("row_ror:4");
+#pragma unroll
+    VDM_DPP4("row_ror:2");
+#pragma unroll
+    VDM_DPP4("row_ror:1");
+#undef VDM_DPP4
+}
+
 template <int NC, int NW = 4>
 __device__ __forceinline__ void gn_partials_reduce(float (&gs)[NC * 4], float (&gq)[NC * 4], float* sm, float* dst /* [Cout][2] of this tile */,
                                                    int cout0, int Cout, int wave, int lane, int qstride = NC * 4) {
     const int lx = lane & 15, q = lane >> 4;
-#pragma unroll
-    for (int j = 0; j < NC * 4; ++j) {
-        gs[j] = row16_sum(gs[j]);
-        gq[j] = row16_sum(gq[j]);
-    }
+    row16_sum_block<NC * 4>(gs);
+    row16_sum_block<NC * 4>(gq);
     if (lx == 0) {
 #pragma unroll
         for (int j = 0; j < NC * 4; ++j) {
@@ -607,6 +665,56 @@ __device__ __forceinline__ void conv_epilogue(const f32x4 (&acc)[NV][NC], const 
     TO* out = reinterpret_cast<TO*>(a.out) + sample;
     const T* res = a.res ? reinterpret_cast<const T*>(a.res) + sample : nullptr;
     const RowMap<G, NV> rm(a, oz0, oy0, ox0, cwave, lane);
+    // Fast path (round 4): interior tile, whole channel chunk, bf16 output - which is every workgroup of the 128^3 network.  The
+    // general loop below tests row / lane / channel validity per row and element (the compiler keeps both the vector and the scalar
+    // tail path per row: ~900 vector instructions and ~500 scalar branches per wave); here the validity is ONE scalar test, the rows
+    // are straight-line code and a row's address is the wave-uniform row stride added to a per-lane base.
+    if constexpr (sizeof(TO) == 2 && sizeof(T) == 2 && NC >= 2) {
+        const bool fast = oz0 + G::TZ <= a.Dz && oy0 + G::TY <= a.Dy && ox0 + 16 <= a.Dx && a.Cout % (NC * 4) == 0 &&
+                          cout0 + 3 * qstride + NC * 4 <= a.Cout;
+        if (fast) {
+            const unsigned e0 = rm.vox0 * (unsigned)a.Cout + (unsigned)cbase, rs = (unsigned)(a.Dx * a.Cout);
+            uint16_t* o16 = reinterpret_cast<uint16_t*>(out) + e0;
+            const uint16_t* r16 = res ? reinterpret_cast<const uint16_t*>(res) + e0 : nullptr;
+            const bool want = a.gnp != nullptr;
+            auto row = [&](int v, bool with_res) {
+                float val[NC * 4];
+#pragma unroll
+                for (int c = 0; c < NC; ++c)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) val[c * 4 + j] = acc[v][c][j] + badd[c * 4 + j];
+                if (with_res) {
+#pragma unroll
+                    for (int i = 0; i < NC / 2; ++i) {
+                        Piece<bf16_t> pr;
+                        pr.load(*reinterpret_cast<const uint4*>(r16 + (size_t)v * rs + i * 8));
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) val[i * 8 + j] += pr.f[j];
+                    }
+                }
+                if (want) {
+#pragma unroll
+                    for (int j = 0; j < NC * 4; ++j) { gs[j] += val[j]; gq[j] = fmaf(val[j], val[j], gq[j]); }
+                }
+#pragma unroll
+                for (int i = 0; i < NC / 2; ++i)
+                    *reinterpret_cast<uint4*>(o16 + (size_t)v * rs + i * 8) =
+                        make_uint4(pack_bf16x2(val[i * 8], val[i * 8 + 1]), pack_bf16x2(val[i * 8 + 2], val[i * 8 + 3]),
+                                   pack_bf16x2(val[i * 8 + 4], val[i * 8 + 5]), pack_bf16x2(val[i * 8 + 6], val[i * 8 + 7]));
+            };
+            if (r16) {
+#pragma unroll
+                for (int v = 0; v < NV; ++v) row(v, true);
+            } else {
+#pragma unroll
+                for (int v = 0; v < NV; ++v) row(v, false);
+            }
+            if (want)
+                gn_partials_reduce<NC, G::NW>(gs, gq, gn_sm, a.gnp + ((size_t)n * (a.ntz * a.nty * a.ntx) + tile) * a.Cout * 2, cout0, a.Cout,
+                                              cwave, lane, qstride);
+            return;
+        }
+    }
 #pragma unroll
     for (int v = 0; v < NV; ++v) {
         if (!rm.ok(a, v)) continue;

@@ -32,12 +32,8 @@ __global__ void __launch_bounds__(64 * NW, NW == 8 ? 4 : ((TZ * TY <= 16 && NC <
     VDM_STAMP(0);
 #endif
 
-    int b = xcd_remap(blockIdx.x, gridDim.x);
-    const int tx = b % a.ntx; b /= a.ntx;
-    const int ty = b % a.nty; b /= a.nty;
-    const int tz = b % a.ntz; b /= a.ntz;
-    const int n = b % a.N;
-    const int chunk = b / a.N;
+    int tx, ty, tz, n, chunk;
+    decode_tile(a, (uint32_t)xcd_remap(blockIdx.x, gridDim.x), tx, ty, tz, n, chunk);
     const int oz0 = tz * TZ, oy0 = ty * TY, ox0 = tx * 16;
 
     f32x4 acc[NV][NC];
@@ -142,12 +138,8 @@ __global__ void __launch_bounds__(256, 1) conv_ksplit_kernel(const ConvArgs a) {
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
 
-    int b = xcd_remap(blockIdx.x, gridDim.x);
-    const int tx = b % a.ntx; b /= a.ntx;
-    const int ty = b % a.nty; b /= a.nty;
-    const int tz = b % a.ntz; b /= a.ntz;
-    const int n = b % a.N;
-    const int chunk = b / a.N;
+    int tx, ty, tz, n, chunk;
+    decode_tile(a, (uint32_t)xcd_remap(blockIdx.x, gridDim.x), tx, ty, tz, n, chunk);
     const int oz0 = tz, oy0 = ty * TY, ox0 = tx * 16;
     const int cout0 = chunk * NC * 16, qstride = NC * 4;
 
@@ -224,12 +216,8 @@ __global__ void __launch_bounds__(256, GNB ? 2 : 4) conv_kpack_kernel(const Conv
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
 
-    int b = xcd_remap(blockIdx.x, gridDim.x);
-    const int tx = b % a.ntx; b /= a.ntx;
-    const int ty = b % a.nty; b /= a.nty;
-    const int tz = b % a.ntz; b /= a.ntz;
-    const int n = b % a.N;
-    const int chunk = b / a.N;
+    int tx, ty, tz, n, chunk;
+    decode_tile(a, (uint32_t)xcd_remap(blockIdx.x, gridDim.x), tx, ty, tz, n, chunk);
     const int oz0 = tz * G::TZ, oy0 = ty * G::TY, ox0 = tx * 16;
 
     GnbRegs<T, NC, GNB ? NV : 1> gr;
@@ -319,6 +307,7 @@ static int launch_fwd_cfg(const ConvArgs& a0, hipStream_t s) {
     ConvArgs a = a0;
     if (SPLIT) a.nchunks *= 2;
     a.ntz = cdiv(a.Dz, TZ); a.nty = cdiv(a.Dy, TY); a.ntx = cdiv(a.Dx, 16);
+    set_tile_divs(a);
     const size_t lds = (size_t)((G::HVOX + 15) / 16) * 1024 + GN_SCRATCH_BYTES + (GNP ? GNP_TABLE_BYTES : 0);
     auto kern = conv_fwd_kernel<T, TO, KS, STRIDE, UPS, NC, TZ, TY, SPLIT, GNB, GNP, NW>;
     static unsigned long long lds_done = 0;
@@ -347,6 +336,7 @@ static int launch_ksplit(const ConvArgs& a0, hipStream_t s) {
     using G = Geo<3, 1, 1, TY>;
     ConvArgs a = a0;
     a.ntz = a.Dz; a.nty = cdiv(a.Dy, TY); a.ntx = cdiv(a.Dx, 16);
+    set_tile_divs(a);
     const size_t lds = 4 * (size_t)((G::HVOX + 15) / 16) * 1024 + GN_SCRATCH_BYTES;
     auto kern = conv_ksplit_kernel<T, TO, NC, TY, GNB>;
     static unsigned long long lds_done = 0;
@@ -412,6 +402,7 @@ static int launch_kpack(const ConvArgs& a0, hipStream_t s) {
     using G = Geo<3, 1, 4, 8>;
     ConvArgs a = a0;
     a.ntz = cdiv(a.Dz, G::TZ); a.nty = cdiv(a.Dy, G::TY); a.ntx = cdiv(a.Dx, 16);
+    set_tile_divs(a);
     const size_t lds = (size_t)((G::HVOX + 63) / 64) * 1024 + GN_SCRATCH_BYTES;
     const long long nwg = (long long)a.N * a.ntz * a.nty * a.ntx * a.nchunks;
     if (nwg > 0x7fffffffLL) { set_error("conv: grid too large"); return VDM_ERR_ARG; }

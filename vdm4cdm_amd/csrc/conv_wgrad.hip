@@ -164,11 +164,8 @@ __global__ void __launch_bounds__(256, 2) conv_wgrad_kernel(const WgradArgs w) {
     auto in_base = [&](int r) { return (((r / TY) * STRIDE * G::HY + (r % TY) * STRIDE) * G::HX) * 64; };
 
     for (int tile = pidx; tile < w.ntiles; tile += w.P) {
-        int b = tile;
-        const int tx = b % a.ntx; b /= a.ntx;
-        const int ty = b % a.nty; b /= a.nty;
-        const int tz = b % a.ntz; b /= a.ntz;
-        const int n = b;
+        int tx, ty, tz, n, rest_;
+        decode_tile(a, (uint32_t)tile, tx, ty, tz, n, rest_);      // (tile < ntiles: rest_ == 0)
         const int oz0 = tz * TZ, oy0 = ty * TY, ox0 = tx * 16;
         __syncthreads();                                   // every wave is done reading the previous tile
         stage_halo_dma<T, G, CLS ? 0 : UPS>(lds_in, x, a, n, oz0, oy0, ox0, kb, wave, lane);
@@ -392,6 +389,7 @@ static int launch_wgrad_cfg(WgradArgs w, float* dw, float* dbias, int accumulate
     constexpr int CL = WG<T>::NT * 16;
     ConvArgs& a = w.c;
     a.ntz = cdiv(a.Dz, TZ); a.nty = cdiv(a.Dy, TY); a.ntx = cdiv(a.Dx, 16);
+    set_tile_divs(a);
     w.ntiles = a.N * a.ntz * a.nty * a.ntx;
     const int npairs = w.ncb * w.nkb;
     int P = wgrad_wgs() / npairs;             // persistent: ~2 workgroups per CU over all (cout, cin) block pairs
@@ -439,6 +437,7 @@ static int launch_wgrad_cls(WgradArgs w, float* dw, float* dbias, int accumulate
     a.Dz /= 2; a.Dy /= 2; a.Dx /= 2;                       // everything runs on the coarse grid
     a.Iz = a.Sz = a.Dz; a.Iy = a.Sy = a.Dy; a.Ix = a.Sx = a.Dx;
     a.ntz = cdiv(a.Dz, G::TZ); a.nty = cdiv(a.Dy, G::TY); a.ntx = cdiv(a.Dx, 16);
+    set_tile_divs(a);
     w.ntiles = a.N * a.ntz * a.nty * a.ntx;
     const int npairs = 8 * w.ncb * w.nkb;
     int P = (WGS * wgrad_wgs() / 512) / npairs;
