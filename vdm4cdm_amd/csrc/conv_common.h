@@ -79,6 +79,7 @@ struct ConvArgs {
     int Cout;            // output channels (exact stride of out / res)
     int circular;
     int ntz, nty, ntx, nchunks, nkb;
+    int nseg, zsteps;                // rolling-z kernel: segments per tile column, z steps (tiles) per segment
     FastDiv fdx, fdy, fdz, fdn;      // divisions by ntx, nty, ntz, N (set_tile_divs)
     float* gnp;          // optional GroupNorm partials of the output: [N][ntz*nty*ntx][Cout][2] = (sum, sum of squares) per tile
     // GroupNorm backward folded into a dgrad epilogue (conv_epilogue_gnb): the conv result is dL/dy of y = drop(silu(gn(x)));
@@ -212,42 +213,48 @@ __device__ __forceinline__ void stage_halo_dma_chunks(char* lds, const T* __rest
 #ifndef VDM_ROWSTAGE
 #define VDM_ROWSTAGE 1
 #endif
-template <typename T, typename G, int UPS, int NWAVES = 4>
-__device__ __forceinline__ void stage_halo_dma_rows(char* lds, const T* __restrict__ x, const ConvArgs& a, int n, int oz0, int oy0,
-                                                    int ox0, int kb, int wave, int lane, int ss, int soz, int soy, int sox, int sDz,
-                                                    int sDy, int sDx) {
-    constexpr int EPL = DT<T>::EPL, KB = DT<T>::KB, SH = DT<T>::SHIFT;
-    constexpr int HX = G::HX, HY = G::HY, HZ = G::HZ, PAD = G::PAD;
-    constexpr int NSEG = HX / 16, NTAIL = HX - 16 * NSEG, NROW = HZ * HY;
+// per-lane x part (once per tile / per persistent workgroup) + one halo row per call
+template <typename T, typename G, int UPS>
+struct RowStager {
+    static constexpr int EPL = DT<T>::EPL, KB = DT<T>::KB, SH = DT<T>::SHIFT;
+    static constexpr int HX = G::HX, HY = G::HY, HZ = G::HZ, PAD = G::PAD;
+    static constexpr int NSEG = HX / 16, NTAIL = HX - 16 * NSEG;
     static_assert(NTAIL <= 4, "the leftover voxels of a row go out as one 256-byte LDS-DMA");
-    const int iz0 = oz0 * G::STRIDE - PAD, iy0 = oy0 * G::STRIDE - PAD, ix0 = ox0 * G::STRIDE - PAD;
-    const char* xn = reinterpret_cast<const char*>(x + (size_t)n * ((size_t)sDz * sDy * sDx * a.CinStride));
-    const char* zp = reinterpret_cast<const char*>(g_zero_page);
-    // ---- per-lane x part, once per tile: byte offset of the lane's 16 B (segments) / 4 B (tail) inside a source row, or "take zeros"
-    auto xpart = [&](int hx, int slot, unsigned& off) -> bool {
-        const int pc = slot ^ ((hx >> 1) & 3);                                // source piece of this LDS slot (x-swizzle)
-        const int ci = kb * KB + pc * EPL;
-        int ix = ix0 + hx;
-        bool ok = ci < a.Cin;
-        if (a.circular) ix = wrap(ix, a.Ix);
-        else ok = ok && (unsigned)ix < (unsigned)a.Ix;
-        if (UPS) ix >>= 1;
-        const unsigned sx = (unsigned)(ss * ix + sox) & 0xffffffu;
-        off = (__umul24(sx, (unsigned)a.CinStride) + (unsigned)ci) << SH;
-        return ok;
-    };
-    unsigned xoff[NSEG], toff = 0;
-    bool okx[NSEG], tok = false;
+    unsigned xoff[NSEG], toff;
+    bool okx[NSEG], tok;
+    int lane;
+    const char* xn;
+    int iz0, iy0, ss, soz, soy, sDy, sDx;
+    // byte offset of the lane's 16 B (segments) / 4 B (tail) inside a source row, or "take zeros"
+    __device__ __forceinline__ RowStager(const T* __restrict__ x, const ConvArgs& a, int n, int oz0, int oy0, int ox0, int kb, int lane_, int ss_,
+                                         int soz_, int soy_, int sox, int sDz, int sDy_, int sDx_)
+        : lane(lane_), ss(ss_), soz(soz_), soy(soy_), sDy(sDy_), sDx(sDx_) {
+        iz0 = oz0 * G::STRIDE - PAD; iy0 = oy0 * G::STRIDE - PAD;
+        const int ix0 = ox0 * G::STRIDE - PAD;
+        xn = reinterpret_cast<const char*>(x + (size_t)n * ((size_t)sDz * sDy * sDx * a.CinStride));
+        auto xpart = [&](int hx, int slot, unsigned& off) -> bool {
+            const int pc = slot ^ ((hx >> 1) & 3);                            // source piece of this LDS slot (x-swizzle)
+            const int ci = kb * KB + pc * EPL;
+            int ix = ix0 + hx;
+            bool ok = ci < a.Cin;
+            if (a.circular) ix = wrap(ix, a.Ix);
+            else ok = ok && (unsigned)ix < (unsigned)a.Ix;
+            if (UPS) ix >>= 1;
+            const unsigned sx = (unsigned)(ss * ix + sox) & 0xffffffu;
+            off = (__umul24(sx, (unsigned)a.CinStride) + (unsigned)ci) << SH;
+            return ok;
+        };
+        toff = 0; tok = false;
 #pragma unroll
-    for (int sgm = 0; sgm < NSEG; ++sgm) okx[sgm] = xpart(16 * sgm + (lane >> 2), lane & 3, xoff[sgm]);
-    if constexpr (NTAIL > 0) {
-        const int d = lane & 15;                                              // dword of the tail voxel lane >> 4
-        tok = xpart(16 * NSEG + (lane >> 4), d >> 2, toff) && lane < 16 * NTAIL;
-        toff += (unsigned)(d & 3) * 4u;
+        for (int sgm = 0; sgm < NSEG; ++sgm) okx[sgm] = xpart(16 * sgm + (lane >> 2), lane & 3, xoff[sgm]);
+        if constexpr (NTAIL > 0) {
+            const int d = lane & 15;                                          // dword of the tail voxel lane >> 4
+            tok = xpart(16 * NSEG + (lane >> 4), d >> 2, toff) && lane < 16 * NTAIL;
+            toff += (unsigned)(d & 3) * 4u;
+        }
     }
-    // ---- rows: scalar address arithmetic, NSEG (+1) LDS-DMAs per row
-    for (int r = wave; r < NROW; r += NWAVES) {
-        const int hz = r / HY, hy = r % HY;
+    // halo row (hz, hy) of the tile (wave-uniform) -> LDS row `lrow` (HX * 64 bytes): NSEG (+1) LDS-DMAs, scalar address arithmetic
+    __device__ __forceinline__ void row(char* lrow, const ConvArgs& a, int hz, int hy) const {
         int iz = iz0 + hz, iy = iy0 + hy;
         bool okrow = true;
         if (a.circular) {
@@ -259,7 +266,7 @@ __device__ __forceinline__ void stage_halo_dma_rows(char* lds, const T* __restri
         const unsigned sz = okrow ? (unsigned)(ss * iz + soz) : 0u, sy = okrow ? (unsigned)(ss * iy + soy) : 0u;
         const size_t rowel = (size_t)((sz * (unsigned)sDy + sy) * (unsigned)sDx) * (unsigned)a.CinStride;      // (a sample's elements fit 32 bits: host check)
         const char* rowp = xn + (rowel << SH);
-        char* lrow = lds + r * (HX * 64);
+        const char* zp = reinterpret_cast<const char*>(g_zero_page);
 #pragma unroll
         for (int sgm = 0; sgm < NSEG; ++sgm) {
             const char* src = (okrow && okx[sgm]) ? rowp + xoff[sgm] : zp;
@@ -274,6 +281,15 @@ __device__ __forceinline__ void stage_halo_dma_rows(char* lds, const T* __restri
             }
         }
     }
+};
+
+template <typename T, typename G, int UPS, int NWAVES = 4>
+__device__ __forceinline__ void stage_halo_dma_rows(char* lds, const T* __restrict__ x, const ConvArgs& a, int n, int oz0, int oy0,
+                                                    int ox0, int kb, int wave, int lane, int ss, int soz, int soy, int sox, int sDz,
+                                                    int sDy, int sDx) {
+    const RowStager<T, G, UPS> st(x, a, n, oz0, oy0, ox0, kb, lane, ss, soz, soy, sox, sDz, sDy, sDx);
+    constexpr int HY = G::HY, NROW = G::HZ * G::HY;
+    for (int r = wave; r < NROW; r += NWAVES) st.row(lds + r * (G::HX * 64), a, r / HY, r % HY);
 }
 
 template <typename T, typename G, int UPS, int NWAVES = 4>
@@ -466,14 +482,16 @@ __device__ __forceinline__ void rr_prefetch_weights(uint4 (&wf)[WPD + 1][NC], co
         for (int c = 0; c < NC; ++c) wf[p][c] = wk[(rr_tap(p) * NCW + c) * 64];
 }
 
+// zoff: byte offsets of the three z slices (dz = 0, 1, 2) of the wave's output slab inside the image - the compile-time constants
+// {0, HSLAB, 2 HSLAB} of a tile image (taps_rowreuse below), or the wave-uniform ring slots of the rolling-z kernel.
 template <typename T, typename G, int NC, int NV, int WPD, int NCW = NC>
-__device__ __forceinline__ void taps_rowreuse(f32x4 (&acc)[NV][NC], const char* lds, const uint4* wk, uint4 (&wf)[WPD + 1][NC],
-                                              const int (&lanex)[3]) {
+__device__ __forceinline__ void taps_rowreuse_z(f32x4 (&acc)[NV][NC], const char* lds, const uint4* wk, uint4 (&wf)[WPD + 1][NC],
+                                                const int (&lanex)[3], const int (&zoff)[3]) {
     static_assert(G::KS == 3 && G::STRIDE == 1, "3x3x3 stride-1 geometry");
-    constexpr int NR = NV + 2, HROW = G::HX * 64, HSLAB = G::HY * HROW;
+    constexpr int NR = NV + 2, HROW = G::HX * 64;
     uint4 rows[NR];
 #pragma unroll
-    for (int r = 0; r < NR; ++r) rows[r] = *reinterpret_cast<const uint4*>(lds + lanex[0] + r * HROW);
+    for (int r = 0; r < NR; ++r) rows[r] = *reinterpret_cast<const uint4*>(lds + zoff[0] + lanex[0] + r * HROW);
 #pragma unroll
     for (int e = 0; e < 27; ++e) {
         const int g = e / 3, dy = e % 3;
@@ -491,7 +509,7 @@ __device__ __forceinline__ void taps_rowreuse(f32x4 (&acc)[NV][NC], const char* 
             __builtin_amdgcn_sched_barrier(0);
         } else {                                           // last use of the rows: refill them for group g + 1 as they die
             const int g1 = g + 1;
-            const char* nb = lds + lanex[g1 % 3] + (g1 / 3) * HSLAB;
+            const char* nb = lds + lanex[g1 % 3] + zoff[g1 / 3];
             __builtin_amdgcn_sched_barrier(0);
             rows[0] = *reinterpret_cast<const uint4*>(nb);                     // (rows 0 and 1 died with the dy = 1 tap)
             rows[1] = *reinterpret_cast<const uint4*>(nb + HROW);
@@ -505,6 +523,14 @@ __device__ __forceinline__ void taps_rowreuse(f32x4 (&acc)[NV][NC], const char* 
             }
         }
     }
+}
+
+template <typename T, typename G, int NC, int NV, int WPD, int NCW = NC>
+__device__ __forceinline__ void taps_rowreuse(f32x4 (&acc)[NV][NC], const char* lds, const uint4* wk, uint4 (&wf)[WPD + 1][NC],
+                                              const int (&lanex)[3]) {
+    constexpr int HSLAB = G::HY * G::HX * 64;
+    const int zoff[3] = {0, HSLAB, 2 * HSLAB};
+    taps_rowreuse_z<T, G, NC, NV, WPD, NCW>(acc, lds, wk, wf, lanex, zoff);
 }
 
 // fp32 (exact v_mfma_f32_16x16x4_f32, 1/16 of the bf16 rate): MFMA-bound.  Rolled tap loop (low register pressure), the

@@ -32,6 +32,13 @@ __global__ void __launch_bounds__(64 * NW, NW == 8 ? 4 : ((TZ * TY <= 16 && NC <
     VDM_STAMP(0);
 #endif
 
+#ifdef VDM_STAGGER
+    // experiment: the second workgroup a CU receives at launch (wave slot 1 of its SIMDs) starts half a tile period late, so that the
+    // two co-resident workgroups run in anti-phase (one stages / stores while the other is in its tap loop)
+    if (blockIdx.x < 2u * 256u && (__builtin_amdgcn_s_getreg((4 << 11) | 4) & 1)) {      // HW_REG_HW_ID bits [3:0] = wave slot
+        for (int i = 0; i < VDM_STAGGER; ++i) __builtin_amdgcn_s_sleep(127);
+    }
+#endif
     int tx, ty, tz, n, chunk;
     decode_tile(a, (uint32_t)xcd_remap(blockIdx.x, gridDim.x), tx, ty, tz, n, chunk);
     const int oz0 = tz * TZ, oy0 = ty * TY, ox0 = tx * 16;
@@ -83,8 +90,14 @@ __global__ void __launch_bounds__(64 * NW, NW == 8 ? 4 : ((TZ * TY <= 16 && NC <
             if constexpr (GNP) gn_prologue_inplace<T, G, NW>(lds, gn_tab, a, oz0, oy0, ox0, kb, wave, lane);
             __syncthreads();
             if (kb == 0) VDM_STAMP(2);
+#ifdef VDM_TAP_PRIO
+            __builtin_amdgcn_s_setprio(VDM_TAP_PRIO);      // experiment: the wave in its tap loop wins instruction arbitration against the co-resident wave
+#endif
             if constexpr (RR) taps_rowreuse<T, G, NC, NV, WPD, NCW>(acc, lds, wk, wf, lanex);
             else taps_pipelined<T, G, NC, NV, WPD, NCW>(acc, lds, wk, wf, lanex);
+#ifdef VDM_TAP_PRIO
+            __builtin_amdgcn_s_setprio(0);
+#endif
         } else {
             if constexpr (GNP) gn_prologue_inplace<T, G, NW>(lds, gn_tab, a, oz0, oy0, ox0, kb, wave, lane);
             __syncthreads();
@@ -109,6 +122,95 @@ __global__ void __launch_bounds__(64 * NW, NW == 8 ? 4 : ((TZ * TY <= 16 && NC <
         o[7] = ((unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 20) << 32) | (unsigned)__builtin_amdgcn_s_getreg((31 << 11) | 4);
     }
 #endif
+}
+
+// ---------------------------------------------------------------------------------------------
+// Rolling-z kernel (round 4) for the single-K-block bf16 3x3x3 stride-1 convs on large grids (level 0: 32 reduction channels).
+// A tile stages 6 z-slices of the halo for 4 output slabs and its z neighbour stages 2 of them again (halo factor 2.1 = 6/4 * 10/8 *
+// 18/16; beyond the 4 MB L2 of an XCD the re-read comes from the Infinity Cache / HBM).  Here a PERSISTENT workgroup walks up a
+// column of tiles (fixed y, x; z ascending): the LDS image is a ring of 6 slice slots, a step stages only the 4 NEW slices (the two
+// top slices of the previous step are the two bottom ones of this step) - 46 KB instead of 69.6 KB per tile, 34 % fewer LDS-DMA
+// instructions, and the y / x halos are shared through the L2 with the neighbour columns that walk up in step.  Wave w owns output
+// slab w of the step: its three input slices are ring slots (wave-uniform, taps_rowreuse_z).  The staging of step s + 1 is issued
+// right behind the tap loop of step s (the slots it overwrites are free once every wave has left the taps) and lands under the
+// epilogue's stores.
+// ---------------------------------------------------------------------------------------------
+template <typename T, int NC, bool GNB>
+__global__ void __launch_bounds__(256, 2) conv_roll_kernel(const ConvArgs a) {
+    static_assert(sizeof(T) == 2, "bf16 storage");
+    using G = Geo<3, 1, 4, 8>;
+    constexpr int NV = G::NV, TAPS = G::TAPS, NCW = NC, R = 6;
+    constexpr int SLICE = G::HY * G::HX * 64;
+    static_assert(NV == G::TY, "a wave owns one z slab of the step");
+    extern __shared__ __attribute__((aligned(16))) char lds[];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+
+    // block -> (tx, ty, segment of the column, n, chunk)
+    uint32_t b = (uint32_t)xcd_remap(blockIdx.x, gridDim.x);
+    uint32_t q = fdiv(b, a.fdx);
+    const int tx = (int)(b - q * (uint32_t)a.ntx); b = q;
+    q = fdiv(b, a.fdy);
+    const int ty = (int)(b - q * (uint32_t)a.nty); b = q;
+    q = fdiv(b, a.fdz);                                     // (fdz divides by nseg here)
+    const int seg = (int)(b - q * (uint32_t)a.nseg); b = q;
+    q = fdiv(b, a.fdn);
+    const int n = (int)(b - q * (uint32_t)a.N);
+    const int chunk = (int)q;
+    const int zs0 = seg * a.zsteps, zs1 = min(a.ntz, zs0 + a.zsteps);
+    const int oy0 = ty * G::TY, ox0 = tx * 16;
+
+    int lanex[3];
+    operand_lane_offsets<G, NV>(lanex, 0, lane);            // (no slab offset: the slab is a ring slot)
+    const uint4* wk = reinterpret_cast<const uint4*>(a.w) + (size_t)chunk * TAPS * NCW * 64 + lane;
+    const T* x = reinterpret_cast<const T*>(a.x);
+    const int e_cout0 = chunk * NC * 16, e_qstride = NC * 4;
+    float badd[NC * 4];
+    if constexpr (!GNB) load_badd<NC>(badd, a, n, e_cout0 + (lane >> 4) * e_qstride);
+    // the per-lane x part of the staging is the same for every step of the column
+    const RowStager<T, G, 0> st(x, a, n, 0, oy0, ox0, 0, lane, 1, 0, 0, 0, a.Sz, a.Sy, a.Sx);
+    float* gn_sm = reinterpret_cast<float*>(lds + R * SLICE);
+    constexpr int WPD = WPipe<NC>::WPD;
+
+    // slices are addressed by their position p = iz + 1 - 4 zs0 >= 0 in the column walk; slot = p mod 6
+    auto stage = [&](int p0, int cnt) {                      // positions p0 .. p0 + cnt - 1
+        for (int r = wave; r < cnt * G::HY; r += 4) {
+            const int sl = r / G::HY, hy = r % G::HY;
+            const int p = p0 + sl;
+            st.row(lds + (p % R) * SLICE + hy * (G::HX * 64), a, 4 * zs0 + p, hy);      // (RowStager: iz = iz0 + hz with iz0 = -1)
+        }
+    };
+    stage(0, R);
+    for (int s = zs0; s < zs1; ++s) {
+        const int oz0 = s * G::TZ, p0 = 4 * (s - zs0);      // this step reads positions p0 .. p0 + 5
+        f32x4 acc[NV][NC];
+#pragma unroll
+        for (int v = 0; v < NV; ++v)
+#pragma unroll
+            for (int c = 0; c < NC; ++c) acc[v][c] = f32x4{0.f, 0.f, 0.f, 0.f};
+        GnbRegs<T, NC, GNB ? NV : 1> gr;                   // (filled by the epilogue through its rolling window: the loop-carried state of
+                                                           //  the walk leaves no room to prefetch all rows in front of the taps)
+        // (LICM would hoist the 54 weight-fragment addresses of the unrolled tap loop out of the step loop: 108 registers and spills;
+        //  an opaque copy of the pointer per step keeps them inside)
+        const uint4* wks = wk;
+        asm volatile("" : "+v"(wks));
+        uint4 wf[WPD + 1][NC];
+        rr_prefetch_weights<NC, WPD, NCW>(wf, wks);
+        __syncthreads();                                    // (vmcnt(0) + barrier: the slices of this step have landed)
+        const int zoff[3] = {((p0 + wave) % R) * SLICE, ((p0 + wave + 1) % R) * SLICE, ((p0 + wave + 2) % R) * SLICE};
+        taps_rowreuse_z<T, G, NC, NV, WPD, NCW>(acc, lds, wks, wf, lanex, zoff);
+        if (s + 1 < zs1) {                                  // next step's four new slices, behind this step's taps
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();                   // every wave has read its operands: positions p0 .. p0 + 3 are free
+            stage(p0 + R, 4);
+        }
+        const int tile = (s * a.nty + ty) * a.ntx + tx;
+        if constexpr (GNB)
+            conv_epilogue_gnb<T, G, NC, NV, false>(acc, a, gr, n, oz0, oy0, ox0, wave, lane, gn_sm, tile, e_cout0, e_qstride);
+        else
+            conv_epilogue<T, T, G, NC, NV>(acc, a, badd, n, oz0, oy0, ox0, wave, lane, gn_sm, tile, e_cout0, e_qstride);
+    }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -308,7 +410,8 @@ static int launch_fwd_cfg(const ConvArgs& a0, hipStream_t s) {
     if (SPLIT) a.nchunks *= 2;
     a.ntz = cdiv(a.Dz, TZ); a.nty = cdiv(a.Dy, TY); a.ntx = cdiv(a.Dx, 16);
     set_tile_divs(a);
-    const size_t lds = (size_t)((G::HVOX + 15) / 16) * 1024 + GN_SCRATCH_BYTES + (GNP ? GNP_TABLE_BYTES : 0);
+    static const int lds_pad = getenv("VDM4CDM_LDS_PAD") ? atoi(getenv("VDM4CDM_LDS_PAD")) : 0;      // experiments: fewer workgroups per CU
+    const size_t lds = (size_t)((G::HVOX + 15) / 16) * 1024 + GN_SCRATCH_BYTES + (GNP ? GNP_TABLE_BYTES : 0) + (size_t)(lds_pad > 0 ? lds_pad : 0);
     auto kern = conv_fwd_kernel<T, TO, KS, STRIDE, UPS, NC, TZ, TY, SPLIT, GNB, GNP, NW>;
     static unsigned long long lds_done = 0;
     {
@@ -329,6 +432,38 @@ static int launch_fwd_cfg(const ConvArgs& a0, hipStream_t s) {
 static bool wg8_enabled(int nc, bool gnb) {
     static const int mask = getenv("VDM4CDM_WG8") ? atoi(getenv("VDM4CDM_WG8")) : 0;
     return nc == 2 && ((mask >> (gnb ? 1 : 0)) & 1);
+}
+
+// rolling-z kernel: bf16, one K-block, 3x3x3 stride 1, bf16 output, 4x8x16 steps; VDM4CDM_ROLL=0 switches it off (A/B)
+static bool roll_enabled() {
+    static const bool on = getenv("VDM4CDM_ROLL") ? atoi(getenv("VDM4CDM_ROLL")) != 0 : true;
+    return on;
+}
+template <typename T, int NC, bool GNB>
+static int launch_roll(const ConvArgs& a0, hipStream_t s) {
+    using G = Geo<3, 1, 4, 8>;
+    ConvArgs a = a0;
+    a.ntz = cdiv(a.Dz, G::TZ); a.nty = cdiv(a.Dy, G::TY); a.ntx = cdiv(a.Dx, 16);
+    const long long ncols = (long long)a.N * a.nty * a.ntx * a.nchunks;
+    int nseg = (int)((2LL * cu_count() + ncols - 1) / ncols);          // ~2 persistent workgroups per CU
+    if (nseg > a.ntz / 2) nseg = a.ntz / 2;                             // >= 2 steps per segment, or the walk saves nothing
+    if (nseg < 1) nseg = 1;
+    a.zsteps = cdiv(a.ntz, nseg);
+    a.nseg = cdiv(a.ntz, a.zsteps);
+    a.fdx = make_fastdiv((uint32_t)a.ntx); a.fdy = make_fastdiv((uint32_t)a.nty); a.fdz = make_fastdiv((uint32_t)a.nseg);
+    a.fdn = make_fastdiv((uint32_t)a.N);
+    const size_t lds = (size_t)6 * G::HY * G::HX * 64 + GN_SCRATCH_BYTES;
+    auto kern = conv_roll_kernel<T, NC, GNB>;
+    static unsigned long long lds_done = 0;
+    {
+        int e = set_lds(kern, lds, lds_done);
+        if (e) return e;
+    }
+    const long long nwg = ncols * a.nseg;
+    if (nwg > 0x7fffffffLL) { set_error("conv: grid too large"); return VDM_ERR_ARG; }
+    hipLaunchKernelGGL(kern, dim3((unsigned)nwg), dim3(256), lds, s, a);
+    VDM_LAUNCH_CHECK("conv_roll_kernel");
+    return VDM_OK;
 }
 
 template <typename T, typename TO, int NC, int TY, bool GNB>
@@ -370,6 +505,9 @@ static int launch_fwd_geo(const ConvArgs& a, hipStream_t s) {
         }
         if (tz == 1) return ty == 4 ? launch_fwd_cfg<T, TO, KS, STRIDE, UPS, NC, 1, 4, false, GNB, GNP>(a, s) : launch_fwd_cfg<T, TO, KS, STRIDE, UPS, NC, 1, 8, false, GNB, GNP>(a, s);
         if (tz == 2) return launch_fwd_cfg<T, TO, KS, STRIDE, UPS, NC, 2, 8, false, GNB, GNP>(a, s);
+        if constexpr (STRIDE == 1 && UPS == 0 && sizeof(TO) == 2 && NC == 2 && !GNP) {      // one K-block, large grid: persistent walk up z
+            if (a.nkb == 1 && cdiv(a.Dz, 4) >= 4 && roll_enabled()) return launch_roll<T, NC, GNB>(a, s);
+        }
         if constexpr (STRIDE == 1 && UPS == 0 && sizeof(TO) == 2 && NC == 2 && !GNP) {      // large grids: eight waves share the 4x8x16 tile
             // (NC = 4 needs > 128 registers per wave: its accumulators alone are 64)
             if (wg8_enabled(NC, GNB)) return launch_fwd_cfg<T, TO, KS, STRIDE, UPS, NC, 4, 8, false, GNB, GNP, 8>(a, s);

@@ -24,7 +24,10 @@ GNB_MIN_K = int(os.environ.get("VDM4CDM_GNB_MIN_K", "0"))      # fold only into 
 FUSED_SKIP = os.environ.get("VDM4CDM_FUSED_SKIP", "1") != "0"
 # inference: norm2's GroupNorm + SiLU applied inside conv2 (to the staged halo image) instead of by a pass of its own.  Measured: the
 # VALU work on the 2.1x halo costs the conv what the 5 TB/s pass cost - off by default
-GN_PROLOGUE = os.environ.get("VDM4CDM_GN_PROLOGUE", "0") == "1"
+# "deep" (default): only at the levels of <= 32^3 voxels, whose GroupNorm passes are launch-latency-bound (13 of the 19 passes of a
+# sampling step at 128^3); "1": everywhere; "0": nowhere
+GN_PROLOGUE = os.environ.get("VDM4CDM_GN_PROLOGUE", "deep")
+GN_PROLOGUE_MAX_VOXELS = 32 ** 3
 
 class SideStream:
     """Weight-gradient kernels run on a side HIP stream: their results are needed only by the optimiser, so they overlap
@@ -143,7 +146,8 @@ class _Res:
             a1 = ops.gn_silu_fwd(x1, x2, G, st1, P(n + ".norm1.weight"), P(n + ".norm1.bias"))
         h = self.conv1.fwd(a1, P(n + ".conv1.bias"), table[:, i.table_off:i.table_off + i.cout], gn=FUSED_GN)
         st2 = ops.gn_stats(h, None, G, chsum=save and FUSED_GNB)
-        inside = GN_PROLOGUE and not save and p == 0.0 and self.conv2.gn_in_ok(h)
+        inside = (GN_PROLOGUE != "0" and not save and p == 0.0 and (GN_PROLOGUE == "1" or h[0, ..., 0].numel() <= GN_PROLOGUE_MAX_VOXELS)
+                  and self.conv2.gn_in_ok(h))
         a2 = None if inside else ops.gn_silu_fwd(h, None, G, st2, P(n + ".norm2.weight"), P(n + ".norm2.bias"), p, seed, want_mask=save and FUSED_GNB)
         if ride:
             pass
