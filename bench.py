@@ -337,16 +337,29 @@ def main():
                 dom_key = max(main_c, key=lambda k: main_c[k]["ms"])
                 # HBM bytes per launch: NOT measured in this run - a static profile from separate rocprofv3 --pmc passes of this same
                 # command (tools/round_profile.sh -> tools/pmc_traffic.py, FETCH_SIZE doubled per the gfx950 correction)
-                traffic, traffic_src = None, None
-                for tag in ("r03", "r02"):
+                traffic, traffic_src, step_traffic, mfma_busy, mfma_src = None, None, None, None, None
+                for tag in ("r04", "r03", "r02"):
                     tpath = os.path.join(ROOT, "profiles", f"{tag}_pmc_bench_traffic.json")
                     if args.config == "c3" and os.path.exists(tpath):
-                        t = json.load(open(tpath))["kernels"].get(dom_key)
+                        tk = json.load(open(tpath))["kernels"]
+                        t = tk.get(dom_key)
                         if t:
                             traffic = t["hbm_bytes_per_launch"]
                             traffic_src = f"static profile profiles/{tag}_pmc_bench_traffic.json (separate --pmc FETCH_SIZE / WRITE_SIZE passes)"
+                            # whole-step counter traffic: every kernel of the profiled run (launch counts / hbm bytes), per step
+                            nst = t["launches"] / max(1, round(agg[dom_key]["launches"] / ev_steps))
+                            step_traffic = sum(v["hbm_bytes_per_launch"] * v["launches"] for v in tk.values()) / max(nst, 1) / 1e9
                             break
+                for tag in ("r04",):
+                    mpath = os.path.join(ROOT, "profiles", f"{tag}_pmc_mfma_util.json")
+                    if args.config == "c3" and os.path.exists(mpath):
+                        mk = json.load(open(mpath))["kernels"].get(dom_key)
+                        if mk and "mfma_busy_frac" in mk:
+                            mfma_busy = mk["mfma_busy_frac"]
+                            mfma_src = (f"static profile profiles/{tag}_pmc_mfma_util.json: SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs x GRBM_GUI_ACTIVE / 8), "
+                                        "kernel alone on the chip (counter collection serialises dispatches)")
                 roof = {"bound": "mfma", **roofline_of(dom_key), "traffic": traffic, "traffic_source": traffic_src,
+                        "mfma_busy_frac": mfma_busy, "mfma_busy_source": mfma_src, "step_traffic_GB": step_traffic,
                         "selection": "largest summed duration among the MFMA conv families launched on the main stream",
                         "share_of_step_time": main_c[dom_key]["ms"] / total_ms,
                         "events": "all launches, every timed step" if args.all_kernel_events

@@ -135,7 +135,20 @@ int vdm_conv_dgrad_gn(const vdm_conv_desc* d, const void* dout, const void* w_pa
 #define VDM_CONV_VARIANT_CLASS 1
 #define VDM_CONV_VARIANT_SPLIT 3 /* generic kernel, half-chunk workgroups (64-cout chunks on a small grid) */
 #define VDM_CONV_VARIANT_KSPLIT 4 /* deepest level: the waves of a workgroup split the K-blocks, one weight fetch per workgroup */
-#define VDM_CONV_VARIANT_KPACK 2 /* <= 8 reduction channels (conv_in, conv_out's input gradient): 4 taps per MFMA K-step */
+#define VDM_CONV_VARIANT_KPACK 2 /* Input gradient (folded GroupNorm backward, as vdm_conv_dgrad_gn) AND weight / bias gradient (as vdm_conv_wgrad) of ONE 3x3x3 stride-1
+ * conv in one launch that stages dout once (ABI v11; csrc/conv_dgw.hip) [replaces the backward of net1 / net2 of a ResNetBlock,
+ * NB blocks.py:129-132, for the convs vdm_conv_dgw_supported() accepts: bf16, 32 -> 32 channels, large grids - level 0 of the 128^3
+ * network].  act = the conv's saved input (the activated tensor a = drop(silu(gn(x)))); the fold's `partials` buffer holds
+ * vdm_conv_dgw_tiles(d) tiles (2 x 8 x 16 voxel steps); workspace >= vdm_conv_dgw_workspace_bytes(d).  Results equal the two separate
+ * entries up to fp32 summation order (the weight gradient sums the same products tile by tile in another order). */
+int vdm_conv_dgw_supported(const vdm_conv_desc* d);
+int vdm_conv_dgw_tiles(const vdm_conv_desc* d);
+size_t vdm_conv_dgw_workspace_bytes(const vdm_conv_desc* d);
+int vdm_conv_dgrad_gn_wgrad(const vdm_conv_desc* d, const void* dout, const void* w_packed_dgrad, const void* act, void* dyh,
+                            const vdm_gn_fold* fold, float* dw, float* dbias, int accumulate, void* workspace, size_t workspace_bytes,
+                            void* stream);
+
+/* <= 8 reduction channels (conv_in, conv_out's input gradient): 4 taps per MFMA K-step */
 int vdm_conv_kernel_variant(const vdm_conv_desc* d, int dgrad);
 
 size_t vdm_conv_wgrad_workspace_bytes(const vdm_conv_desc* d);

@@ -970,3 +970,72 @@ def test_last_groupnorm_backward_feeds_conv_in_wgrad(case):
     assert torch.equal(dw0, dw1) and torch.equal(dbias0, dbias1), f"max diff {(dw0 - dw1).abs().max().item()}"
     assert torch.equal(dg0, dg1) and torch.equal(db0, db1)
     assert dw1.abs().max().item() > 0
+
+
+# ------------------------------------------------------------------------------------------ fused dgrad (+ folded GroupNorm backward) + wgrad
+DGW_CASES = [  # name, N, (D,H,W), c1, c2 (GroupNorm input = conv input: c1 + c2 = 32), dropout p, circular, bias gradient
+    ("l0_like", 2, (16, 64, 128), 32, 0, 0.1, False, True),           # the level-0 shape in small: whole tiles, dropout mask, bias
+    ("ragged", 2, (13, 60, 120), 32, 0, 0.0, False, False),           # ragged in z (odd: half a step), y and x; no bias
+    ("circular_concat", 3, (10, 44, 128), 16, 16, 0.1, True, True),   # two-source GroupNorm input (16 + 16), circular padding, 3 samples
+]
+
+
+@pytest.mark.parametrize("case", DGW_CASES, ids=[c[0] for c in DGW_CASES])
+def test_fused_dgrad_wgrad_kernel(case):
+    """Conv.dgrad_gn_wgrad (csrc/conv_dgw.hip: one launch stages dout once and produces the folded input gradient, the GroupNorm
+    partial sums, the weight gradient and the bias gradient of a 32 -> 32 conv) against (a) torch.autograd of
+    x -> dropout(silu(group_norm(x))) -> conv3d on the CPU and (b) the two separate kernels it replaces: dyh bit for bit (the same
+    27-tap MFMA order per output), weight / bias gradients and GroupNorm sums to fp32 re-association."""
+    ops = _ops()
+    dtype = torch.bfloat16
+    name, N, (D, H, W), c1, c2, p, circ, want_bias = case
+    C, cout, G = c1 + c2, 32, 8
+
+    def produce(cx, seed):
+        cv = ops.Conv(8, cx, 3, circular=circ)
+        cv.pack(rnd((27, cx, 8), seed, dtype, scale=1.0 / math.sqrt(27 * 8)).to(DEV), dtype, need_dgrad=False)
+        return cv.fwd(to_dev(rnd((N, D, H, W, 8), seed + 1, dtype), dtype), (0.3 * rnd((cx,), seed + 2)).to(DEV), gn=True)
+    x1 = produce(c1, 10)
+    x2 = produce(c2, 20) if c2 else None
+    gamma, beta = (1.0 + 0.3 * rnd((C,), 3)).to(DEV), (0.2 * rnd((C,), 4)).to(DEV)
+    st = ops.gn_stats(x1, x2, G, chsum=True)
+    y = ops.gn_silu_fwd(x1, x2, G, st, gamma, beta, p, 777, want_mask=True)          # the conv's saved input a
+    w = rnd((27, cout, C), 30, dtype, scale=1.0 / math.sqrt(27 * C))
+    conv = ops.Conv(C, cout, 3, circular=circ)
+    conv.pack(w.to(DEV), dtype, need_dgrad=True)
+    dd = to_dev(rnd((N, D, H, W, cout), 31, dtype), dtype)
+    assert conv.dgw_ok(dd, c1, c2)
+    # (b) the separate kernels
+    dyh_s = conv.dgrad_gn(dd, x1, x2, G, st, gamma, beta, keep_mask=y.keep_mask, dropout_p=p)
+    dw_s, db_s = torch.zeros(27, cout, C, device=DEV), torch.zeros(cout, device=DEV)
+    conv.wgrad(y, dd, dw_s, db_s)
+    # the fused launch
+    dw_f = torch.full((27, cout, C), float("nan"), device=DEV)
+    db_f = torch.full((cout,), float("nan"), device=DEV) if want_bias else None
+    dyh_f = conv.dgrad_gn_wgrad(dd, y, x1, x2, G, st, gamma, beta, dw_f, db_f, keep_mask=y.keep_mask, dropout_p=p)
+    assert torch.equal(dyh_f, dyh_s), f"{name}: folded input gradient differs from vdm_conv_dgrad_gn ({(dyh_f.float() - dyh_s.float()).abs().max().item():.3e})"
+    wmax = dw_s.abs().max().item()
+    assert (dw_f - dw_s).abs().max().item() <= 2e-5 * wmax, f"{name}: dW vs vdm_conv_wgrad {(dw_f - dw_s).abs().max().item():.3e} / {wmax:.3e}"
+    if want_bias:
+        assert (db_f - db_s).abs().max().item() <= 2e-5 * db_s.abs().max().item() + 1e-4
+    s_f, s_s = dyh_f.gnb_partials.sum(1), dyh_s.gnb_partials.sum(1)              # per-(sample, channel) totals of the tile sums
+    assert (s_f - s_s).abs().max().item() <= 1e-4 * s_s.abs().max().item()
+    # (a) autograd on the CPU: weight gradient of the conv on the activated tensor the kernels saw
+    yr = y.float().cpu().requires_grad_(False)
+    wr = w.float().clone().requires_grad_(True)
+    ref_conv(yr, wr, None, None, None, 3, 1, 0, circ).backward(dd.float().cpu())
+    err = (dw_f.cpu() - wr.grad).abs().max().item()
+    assert err <= 2e-3 * wr.grad.abs().max().item(), f"{name}: dW vs autograd {err:.3e} / {wr.grad.abs().max().item():.3e}"
+    if want_bias:
+        bref = dd.float().cpu().sum((0, 1, 2, 3))
+        assert (db_f.cpu() - bref).abs().max().item() <= 1e-3 * bref.abs().max().item() + 1e-3
+    # and the folded backward through gn_bwd_fused is the one of the separate path
+    outs = []
+    for dyh in (dyh_f, dyh_s):
+        dgam, dbet = torch.zeros(C, device=DEV), torch.zeros(C, device=DEV)
+        dy_ = dyh.clone() if x2 is None else dyh                 # (one source: the apply pass writes dx in place)
+        dy_.gnb_partials = dyh.gnb_partials
+        dx1, dx2 = ops.gn_bwd_fused(x1, x2, G, st, gamma, dy_, dgam, dbet)
+        outs.append((dx1.float(), dgam, dbet))
+    assert (outs[0][0] - outs[1][0]).abs().max().item() <= 2.0 ** -7 * outs[1][0].abs().max().item()
+    assert (outs[0][1] - outs[1][1]).abs().max().item() <= 1e-4 * outs[1][1].abs().max().item() + 1e-5

@@ -59,7 +59,10 @@ def main():
         for op in args.ops.split(","):
             if op == "dgrad" and stride == 2:
                 continue
-            if op == "dgrad_gn":                            # dgrad with the GroupNorm backward folded into the epilogue (dropout mask on)
+            if op == "dgw":                                 # dgrad_gn + wgrad as one launch (csrc/conv_dgw.hip)
+                if not conv.dgw_ok(dout, cin, 0):
+                    continue
+            if op in ("dgrad_gn", "dgw"):                   # dgrad with the GroupNorm backward folded into the epilogue (dropout mask on)
                 if not conv.gn_fold_ok(cin, 0, dt) or stride != 1 or ups:
                     continue
                 G = 8
@@ -75,6 +78,7 @@ def main():
             fn = {"fwd": lambda: conv.fwd(x), "fwd_gn": lambda: conv.fwd(x, gn=True), "dgrad": lambda: conv.dgrad(dout),
                   "fwd_gnp": lambda: conv.fwd(x, gn=True, gn_in=(G, st, gam, bet)), "gn_silu": lambda: ops.gn_silu_fwd(x, None, G, st, gam, bet),
                   "wgrad": lambda: conv.wgrad(x, dout, dw),
+                  "dgw": lambda: conv.dgrad_gn_wgrad(dout, x, x, None, G, st, gam, bet, dw, None, keep_mask=mask, dropout_p=0.1),
                   "dgrad_gn": lambda: conv.dgrad_gn(dout, x, None, G, st, gam, bet, keep_mask=mask, dropout_p=0.1)}[op]
             for _ in range(3):
                 fn()

@@ -19,8 +19,12 @@ import sys
 
 def simplify(name):
     """rocprofv3 kernel name -> the key bench.py / hip_ops.py use for the same launch family."""
-    # conv_fwd_kernel<T, TO, KS, STRIDE, UPS, NC, TZ, TY, SPLIT, GNB, GNP>
-    m = re.search(r"conv_fwd_kernel<vdm::(\w+), (?:vdm::)?(\w+), (\d), (\d), (\d), (\d), \d+, \d+(?:, (true|false))?(?:, (true|false))?(?:, (?:true|false))?>", name)
+    # conv_roll_kernel<T, NC, GNB>: the rolling-z form of conv_fwd_kernel<T, T, 3, 1, 0, NC, 4, 8> - same family key
+    m = re.search(r"conv_roll_kernel<vdm::(\w+), (\d), (true|false)>", name)
+    if m:
+        return f"conv_fwd_kernel<{m.group(1)},k3,s1,NC{m.group(2)}>" + ("+gnb" if m.group(3) == "true" else "")
+    # conv_fwd_kernel<T, TO, KS, STRIDE, UPS, NC, TZ, TY, SPLIT, GNB, GNP, NW>
+    m = re.search(r"conv_fwd_kernel<vdm::(\w+), (?:vdm::)?(\w+), (\d), (\d), (\d), (\d), \d+, \d+(?:, (true|false))?(?:, (true|false))?(?:, (?:true|false))?(?:, \d+)?>", name)
     if m:
         return (f"conv_fwd_kernel<{m.group(1)},k{m.group(3)},s{m.group(4)},NC{m.group(6)}{',split' if m.group(7) == 'true' else ''}>"
                 + ("+gnb" if m.group(8) == "true" else ""))

@@ -12,7 +12,7 @@ rocprofv3 --kernel-trace --stats --output-format csv -d "$out/${tag}_stats" -- p
 f=$(ls "$out/${tag}_stats"/*/*kernel_stats.csv | head -1)
 cp "$f" "$out/${tag}_rocprofv3_kernel_stats_c3.csv"
 rocprofv3 --kernel-trace --output-format csv -d "$out/${tag}_trace" -- python3 bench.py --steps 8 --warmup 2 --no-cpu-baseline --no-kernel-events --sample-steps 0 > /dev/null 2> "$out/${tag}_trace.err"
-python tools/step_timeline.py "$(ls "$out"/${tag}_trace/*/*kernel_trace.csv | head -1)" 2 > "$out/${tag}_step_timeline.txt"
+python tools/step_timeline.py "$(ls "$out"/${tag}_trace/*/*kernel_trace.csv | head -1)" 2 train_scalars_kernel > "$out/${tag}_step_timeline.txt"
 rm -rf "$out/${tag}_trace" "$out/${tag}_stats"
 echo "stats done"
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d "$out/${tag}_pmc_f" -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-kernel-events --sample-steps 0 > /dev/null 2> "$out/${tag}_pmc_f.err"

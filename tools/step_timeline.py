@@ -4,7 +4,8 @@ start offset and duration - the launches of one template instantiation differ a 
 averages hide.
     rocprofv3 --kernel-trace --output-format csv -d out -- python3 bench.py --steps 6 --warmup 2 --no-cpu-baseline --no-kernel-events --sample-steps 0
     python tools/step_timeline.py out/*/*kernel_trace.csv [step_index_from_the_end=2] > profiles/rNN_step_timeline.txt
-A third argument names the kernel a step starts with (default randn_kernel; `pack_input_kernel` for the denoise step of the sampler:
+A third argument names the kernel a step starts with (default randn_kernel; `train_scalars_kernel` since the fused step head of round 4;
+`pack_input_kernel` for the denoise step of the sampler:
     rocprofv3 --kernel-trace ... -- python3 tools/sampler_profile.py --steps 30;  step_timeline.py trace.csv 5 pack_input_kernel)."""
 import csv
 import re

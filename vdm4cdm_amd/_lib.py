@@ -83,6 +83,10 @@ SIGNATURES = {
     "vdm_conv_dgrad_gn_tiles": (_i, [_D]),
     "vdm_conv_dgrad_gn": (_i, [_D, _p, _p, _p, C.POINTER(GnFold), _p]),
     "vdm_conv_kernel_variant": (_i, [_D, _i]),
+    "vdm_conv_dgw_supported": (_i, [_D]),
+    "vdm_conv_dgw_tiles": (_i, [_D]),
+    "vdm_conv_dgw_workspace_bytes": (_sz, [_D]),
+    "vdm_conv_dgrad_gn_wgrad": (_i, [_D, _p, _p, _p, _p, C.POINTER(GnFold), _p, _p, _i, _p, _sz, _p]),
     "vdm_conv_wgrad_workspace_bytes": (_sz, [_D]),
     "vdm_conv_wgrad": (_i, [_D, _p, _p, _p, _p, _i, _p, _sz, _p]),
     "vdm_gn_stats": (_i, [_p, _i, _p, _i, _i, _i64, _i, _i, _p, _p, _p, _i, _p, _i, _p, _p]),

@@ -9,93 +9,6 @@ namespace vdm {
 
 // dOut tile of a wgrad workgroup by LDS-DMA: OVOX voxels x 64 B (one cout block), same x-swizzled voxel-major
 // image as stage_halo_dma (one chunk = one 16-voxel row).
-// (row-wise like stage_halo_dma_rows: the row (oz, oy) is wave-uniform - scalar validity and address; per lane only the x part,
-// computed once per tile.)  sub = 1: the class sub-grid dOut[2c + p] of the up-sampling conv's parity class (pz, py, px).
-template <typename T, typename G>
-__device__ __forceinline__ void stage_dout_dma_gen(char* lds, const T* __restrict__ g, const ConvArgs& a, int n, int oz0, int oy0,
-                                                   int ox0, int cb, int cstride, int sub, int pz, int py, int px, int wave, int lane) {
-    constexpr int EPL = DT<T>::EPL, KB = DT<T>::KB, SH = DT<T>::SHIFT;
-    const int k = lane >> 2, j = lane & 3;
-    const int pc = j ^ ((k >> 1) & 3);
-    const int co = cb * KB + pc * EPL;
-    const int ox = ox0 + k;
-    const int m = sub ? 2 : 1;                                               // fine-grid voxels per tile voxel and dimension
-    const bool okx = co < a.Cout && ox < a.Dx;
-    const unsigned xoff = (__umul24((unsigned)(m * ox + px) & 0xffffffu, (unsigned)cstride) + (unsigned)co) << SH;
-    const char* gn = reinterpret_cast<const char*>(g) + (((size_t)n * (m * a.Dz) * (m * a.Dy) * (m * a.Dx) * cstride) << SH);
-    const char* zp = reinterpret_cast<const char*>(g_zero_page);
-    for (int r = wave; r < G::ROWS; r += 4) {
-        const int oz = oz0 + r / G::TY, oy = oy0 + r % G::TY;
-        const bool okrow = oz < a.Dz && oy < a.Dy;
-        const unsigned fz = okrow ? (unsigned)(m * oz + pz) : 0u, fy = okrow ? (unsigned)(m * oy + py) : 0u;
-        const size_t rowel = (size_t)((fz * (unsigned)(m * a.Dy) + fy) * (unsigned)(m * a.Dx)) * (unsigned)cstride;
-        const char* src = (okrow && okx) ? gn + (rowel << SH) + xoff : zp;
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-                                         (__attribute__((address_space(3))) void*)(lds + r * 1024), 16, 0, 0);
-    }
-}
-
-template <typename T, typename G>
-__device__ __forceinline__ void stage_dout_dma(char* lds, const T* __restrict__ g, const ConvArgs& a, int n, int oz0, int oy0,
-                                               int ox0, int cb, int cstride, int wave, int lane) {
-    stage_dout_dma_gen<T, G>(lds, g, a, n, oz0, oy0, ox0, cb, cstride, 0, 0, 0, 0, wave, lane);
-}
-
-// dOut tile of one parity class of the up-sampling conv: the tile's coarse voxels c map to the fine voxels 2c + p.
-template <typename T, typename G>
-__device__ __forceinline__ void stage_dout_dma_sub(char* lds, const T* __restrict__ g, const ConvArgs& a, int n, int oz0, int oy0,
-                                                   int ox0, int cb, int cstride, int pz, int py, int px, int wave, int lane) {
-    stage_dout_dma_gen<T, G>(lds, g, a, n, oz0, oy0, ox0, cb, cstride, 1, pz, py, px, wave, lane);
-}
-
-// Transposed operand fetch from the x-swizzled voxel-major image: 16 channels (tile ct of the 64-B block) x the
-// k-step's voxels.  address = LDS base + wave-uniform row/tap offset (uni) + per-lane offset(s) (computed once per tap).
-//   bf16: NOFF = 1, two ds_read_b64_tr_b16 (rows r and r+1; the second row is a compile-time byte delta HI);
-//         lane: g = lane>>4 (voxels 4g..4g+3), li = lane&15: voxel-in-quad q' = li>>2, column quad p = li&3.
-//         Voxels x and x+4 of a 32-lane half use opposite piece pairs ((hx>>1)&3 differs by 2): conflict-free.
-//   fp32: NOFF = 4, four ds_read_b32 (MFMA step s reads voxel x = 4*s + (lane>>4), channel lane&15).
-template <typename T> struct TrFetch;
-template <> struct TrFetch<bf16_t> {
-    static constexpr int NOFF = 1;
-    static __device__ __forceinline__ void lane_off(int (&o)[1], int ct, int xs, int dx, int lane) {
-        const int g = lane >> 4, li = lane & 15, qp = li >> 2, p = li & 3;
-        const int hx = (4 * g + qp) * xs + dx;
-        const int slot = (2 * ct + (p >> 1)) ^ ((hx >> 1) & 3);
-        o[0] = hx * 64 + slot * 16 + (p & 1) * 8;
-    }
-    template <int HI>
-    static __device__ __forceinline__ uint4 get(const char* lds, const int (&o)[1], int uni) {
-        typedef __attribute__((address_space(3))) s16x4* lptr;
-        const char* p = lds + uni + o[0];
-        const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lptr)(p));
-        const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lptr)(p + HI));
-        const uint2 l2 = __builtin_bit_cast(uint2, lo), h2 = __builtin_bit_cast(uint2, hi);
-        return make_uint4(l2.x, l2.y, h2.x, h2.y);
-    }
-};
-template <> struct TrFetch<float> {
-    static constexpr int NOFF = 4;
-    static __device__ __forceinline__ void lane_off(int (&o)[4], int ct, int xs, int dx, int lane) {
-        (void)ct;
-        const int m = lane & 15, kq = lane >> 4;
-#pragma unroll
-        for (int st = 0; st < 4; ++st) {
-            const int hx = (4 * st + kq) * xs + dx;
-            o[st] = hx * 64 + (((m >> 2) ^ ((hx >> 1) & 3)) * 16) + (m & 3) * 4;
-        }
-    }
-    template <int HI>
-    static __device__ __forceinline__ uint4 get(const char* lds, const int (&o)[4], int uni) {
-        const char* p = lds + uni;
-        uint4 r;
-        r.x = *reinterpret_cast<const uint32_t*>(p + o[0]);
-        r.y = *reinterpret_cast<const uint32_t*>(p + o[1]);
-        r.z = *reinterpret_cast<const uint32_t*>(p + o[2]);
-        r.w = *reinterpret_cast<const uint32_t*>(p + o[3]);
-        return r;
-    }
-};
-
 // NTA / NTB: 16-channel tiles of the 64-byte cout / cin block that hold real channels (conv_out has 1 output channel, conv_in 2
 // input channels: half of the MFMAs and transposed reads of the block would multiply padding).
 template <typename T, int KS, int STRIDE, int UPS, int TZ, int TY, int NTA = WG<T>::NT, int NTB = WG<T>::NT>
@@ -479,6 +392,21 @@ static int launch_wgrad(const WgradArgs& w, float* dw, float* db, int acc, int c
         if (cout <= 16) return launch_wgrad_cfg<T, 3, 1, 0, 2, 8, 1, 2>(w, dw, db, acc, cout, cin, ws, s);
     }
     return launch_wgrad_cfg<T, 3, 1, 0, 2, 8>(w, dw, db, acc, cout, cin, ws, s);
+}
+
+int launch_dgw_reduce(const float* slabs, const float* bslabs, float* dw, float* dbias, int P, int accumulate, hipStream_t s) {
+    const int total = 27 * 32 * 32;
+    if (ablate_reduce()) return VDM_OK;
+    if (P <= 32)
+        hipLaunchKernelGGL(wgrad_reduce_direct_kernel, dim3(cdiv(total, 256)), dim3(256), 0, s, slabs, dw, 27, 32, 32, 1, 1, 32, P, accumulate);
+    else
+        hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(cdiv(total, WRED_OUT)), dim3(256), 0, s, slabs, dw, 27, 32, 32, 1, 1, 32, P, accumulate);
+    VDM_LAUNCH_CHECK("wgrad_reduce_kernel(dgw)");
+    if (dbias) {
+        hipLaunchKernelGGL(wgrad_bias_reduce_kernel, dim3(2), dim3(256), 0, s, bslabs, dbias, 32, 32, P, accumulate);
+        VDM_LAUNCH_CHECK("wgrad_bias_reduce_kernel(dgw)");
+    }
+    return VDM_OK;
 }
 
 int launch_wgrad_any(const WgradArgs& w, float* dw, float* db, int acc, int cout, int cin, int ks, int stride, int ups, size_t ws,

@@ -323,6 +323,39 @@ class Conv:
             _pe(ev, key + "+gnb", 2.0 * n * od * oh * ow * 27 * self.cin * self.cout, dout.numel() * es + 2 * out.numel() * es)
         return out
 
+    def dgw_ok(self, dout, c1, c2):
+        """Can dgrad_gn_wgrad run this conv's two gradients as one launch (csrc/conv_dgw.hip: bf16, 32 -> 32 channels, large grids)?"""
+        n, od, oh, ow, _ = dout.shape
+        return (dout.dtype == torch.bfloat16 and self.gn_fold_ok(c1, c2, dout.dtype)
+                and bool(_lib.lib().vdm_conv_dgw_supported(self.desc(n, od, oh, ow, dout.dtype))))
+
+    def dgrad_gn_wgrad(self, dout, act, x1, x2, groups, stats, gamma, beta, dw, dbias=None, keep_mask=None, dropout_p=0.0):
+        """dgrad_gn(dout, ...) and wgrad(act, dout, dw, dbias) in ONE launch that stages dout once.  Returns dyh (with `.gnb_partials`)."""
+        L = _lib.lib()
+        _contig(dout, act, x1, x2, stats, gamma, beta, keep_mask, dw, dbias)
+        n, od, oh, ow, c = dout.shape
+        c1, c2 = x1.shape[-1], (0 if x2 is None else x2.shape[-1])
+        assert c == self.cout and act.shape == (n, od, oh, ow, self.cin) and act.dtype == dout.dtype
+        d = self.desc(n, od, oh, ow, dout.dtype)
+        out = torch.empty((n, od, oh, ow, self.cin), dtype=dout.dtype, device=dout.device)
+        part = torch.empty((n, L.vdm_conv_dgw_tiles(d), self.cin, 2), dtype=torch.float32, device=dout.device)
+        need = L.vdm_conv_dgw_workspace_bytes(d)
+        wkey = (dout.device, _s(), "dgw")
+        ws = Conv._ws.get(wkey)
+        if ws is None or ws.numel() < need:
+            ws = Conv._ws[wkey] = torch.empty(need, dtype=torch.uint8, device=dout.device)
+        f = GnFold(x1=_p(x1), x2=_p(x2), c1=c1, c2=c2, groups=groups, stats=_p(stats), gamma=_p(gamma), beta=_p(beta), eps=GN_EPS,
+                   inv_keep=1.0 / (1.0 - dropout_p) if keep_mask is not None else 1.0, keep_mask=_p(keep_mask), partials=_p(part))
+        ev = _pb("conv3")
+        check(L.vdm_conv_dgrad_gn_wgrad(d, _p(dout), _p(self.wd), _p(act), _p(out), C.byref(f), _p(dw), _p(dbias), 0, _p(ws), ws.numel(), _s()),
+              "vdm_conv_dgrad_gn_wgrad")
+        out.gnb_partials = part
+        if ev is not None:
+            es = dout.element_size()
+            _pe(ev, f"conv_dgw_kernel<{_tname(dout.dtype)},k3,s1>(dgrad+gnb+wgrad)", 4.0 * n * od * oh * ow * 27 * self.cin * self.cout,
+                (2 * dout.numel() + 3 * out.numel()) * es)
+        return out
+
     def wgrad(self, x, dout, dw, dbias=None, accumulate=False):
         """dw (fp32 view [taps, cout, cin]) = sum_v dout[v] (x) x[v + tap];  dbias (optional, ksize 3): sum_v dout[v]."""
         L = _lib.lib()

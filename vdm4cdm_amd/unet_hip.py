@@ -22,11 +22,15 @@ FUSED_GNB = FUSED_GN and os.environ.get("VDM4CDM_FUSED_GNB", "1") != "0"
 GNB_MIN_K = int(os.environ.get("VDM4CDM_GNB_MIN_K", "0"))      # fold only into dgrad convs with at least this many reduction channels
 # the 1x1x1 skip conv of a ResNetBlock rides along with norm1's GroupNorm passes where csrc/gn_skip.hip has a kernel (bf16, narrow layers)
 FUSED_SKIP = os.environ.get("VDM4CDM_FUSED_SKIP", "1") != "0"
+# input gradient (+ folded GroupNorm backward) and weight gradient of a 32 -> 32 conv as ONE launch that stages the gradient once
+# (csrc/conv_dgw.hip; the level-0 convs of the 128^3 network).  VDM4CDM_FUSED_DGW=0: the two separate kernels (A/B)
+FUSED_DGW = os.environ.get("VDM4CDM_FUSED_DGW", "1") != "0"
 # inference: norm2's GroupNorm + SiLU applied inside conv2 (to the staged halo image) instead of by a pass of its own.  Measured: the
 # VALU work on the 2.1x halo costs the conv what the 5 TB/s pass cost - off by default
-# "deep" (default): only at the levels of <= 32^3 voxels, whose GroupNorm passes are launch-latency-bound (13 of the 19 passes of a
-# sampling step at 128^3); "1": everywhere; "0": nowhere
-GN_PROLOGUE = os.environ.get("VDM4CDM_GN_PROLOGUE", "deep")
+# "0" (default): nowhere; "deep": only at the levels of <= 32^3 voxels; "1": everywhere.  Round 4, same box, 300 sampling steps at 128^3:
+# 2.42 / 2.43 / 2.46 ms per step for 0 / deep / 1 - the fold does not pay at any level (the level-3 convs run the K-split kernel, which
+# has no prologue: "deep" reaches two launches per step)
+GN_PROLOGUE = os.environ.get("VDM4CDM_GN_PROLOGUE", "0")
 GN_PROLOGUE_MAX_VOXELS = 32 ** 3
 
 class SideStream:
@@ -184,17 +188,27 @@ class _Res:
                 skip_grads.append(self.skip2.dgrad(dout) if self.skip2 is not None else None)
             ss.second.run(side_skip_dgrad, dout)
 
+        dgw2 = fused and FUSED_DGW and self.conv2.dgw_ok(dout, i.cout, 0)      # conv2: both gradients from one staging of dout
+        tcols = dtable[:, i.table_off:i.table_off + i.cout]
+        if dgw2:
+            dyh2 = self.conv2.dgrad_gn_wgrad(dout, a2, h, None, G, st2, P(n + ".norm2.weight"), P(n + ".norm2.bias"), GP(n + ".conv2.weight"),
+                                             GP(n + ".conv2.bias"), keep_mask=mask2, dropout_p=p)
+
         def side_conv2(a2=a2, dout=dout, x1=x1, x2=x2):      # conv2 (+ the 1x1 skip convs share dout); tensors bound now: may run deferred
-            self.conv2.wgrad(a2, dout, GP(n + ".conv2.weight"), GP(n + ".conv2.bias"))      # bias grad fused (column sums of dout)
+            if not dgw2:
+                self.conv2.wgrad(a2, dout, GP(n + ".conv2.weight"), GP(n + ".conv2.bias"))      # bias grad fused (column sums of dout)
             if self.skip1 is not None:
                 GP(n + ".skip.bias").copy_(GP(n + ".conv2.bias"))          # same column sums of dout
                 if not ride:
                     self.skip1.wgrad(x1, dout, GP(n + ".skip.weight"))
                     if self.skip2 is not None:
                         self.skip2.wgrad(x2, dout, GP(n + ".skip2.weight"))
-        ss.run(side_conv2, a2, dout, x1, x2)
-        tcols = dtable[:, i.table_off:i.table_off + i.cout]
-        if fused:      # dgrad epilogue: dyh = da2 * keep * silu'(.) + per-tile sums; then one finalize + one apply pass (no atomics)
+        if not dgw2 or self.skip1 is not None:
+            ss.run(side_conv2, a2, dout, x1, x2)
+        if dgw2:
+            dh, _ = ops.gn_bwd_fused(h, None, G, st2, P(n + ".norm2.weight"), dyh2, GP(n + ".norm2.weight"), GP(n + ".norm2.bias"),
+                                     colsum=tcols)
+        elif fused:      # dgrad epilogue: dyh = da2 * keep * silu'(.) + per-tile sums; then one finalize + one apply pass (no atomics)
             dyh2 = self.conv2.dgrad_gn(dout, h, None, G, st2, P(n + ".norm2.weight"), P(n + ".norm2.bias"), keep_mask=mask2, dropout_p=p)
             dh, _ = ops.gn_bwd_fused(h, None, G, st2, P(n + ".norm2.weight"), dyh2, GP(n + ".norm2.weight"), GP(n + ".norm2.bias"),
                                      colsum=tcols)
@@ -204,11 +218,14 @@ class _Res:
                                     GP(n + ".norm2.weight"), GP(n + ".norm2.bias"), colsum=tcols, dropout_p=p, seed=seed, dx1=da2)
         del a2
         # conv1
-        ss.run(lambda a1=a1, dh=dh: self.conv1.wgrad(a1, dh, GP(n + ".conv1.weight")), a1, dh)
-        if fused:
-            dyh1 = self.conv1.dgrad_gn(dh, x1, x2, G, st1, P(n + ".norm1.weight"), P(n + ".norm1.bias"))
+        if fused and FUSED_DGW and self.conv1.dgw_ok(dh, i.c1, i.c2):
+            dyh1 = self.conv1.dgrad_gn_wgrad(dh, a1, x1, x2, G, st1, P(n + ".norm1.weight"), P(n + ".norm1.bias"), GP(n + ".conv1.weight"))
         else:
-            da1 = self.conv1.dgrad(dh)
+            ss.run(lambda a1=a1, dh=dh: self.conv1.wgrad(a1, dh, GP(n + ".conv1.weight")), a1, dh)
+            if fused:
+                dyh1 = self.conv1.dgrad_gn(dh, x1, x2, G, st1, P(n + ".norm1.weight"), P(n + ".norm1.bias"))
+            else:
+                da1 = self.conv1.dgrad(dh)
         del a1, dh
         # skip path
         add1 = add2 = None
