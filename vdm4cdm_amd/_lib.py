@@ -10,7 +10,9 @@ import subprocess
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 # VDM4CDM_LIB: load another build of the same library (tools/conv_timeline.py uses the stamped diagnostic build)
-LIB_PATH = os.environ.get("VDM4CDM_LIB") or os.path.join(_HERE, "libvdm4cdm_hip.so")
+# VDM4CDM_FP32_EXACT=1: fp32 storage computes with the exact fp32 MFMA (1/16 of the bf16 rate) instead of three bf16 MFMAs per product
+FP32_EXACT = os.environ.get("VDM4CDM_FP32_EXACT", "0") == "1"
+LIB_PATH = os.environ.get("VDM4CDM_LIB") or os.path.join(_HERE, "libvdm4cdm_hip_fp32exact.so" if FP32_EXACT else "libvdm4cdm_hip.so")
 CSRC = os.path.join(_HERE, "csrc")
 
 VDM_F32, VDM_BF16 = 0, 1

@@ -74,6 +74,40 @@ template <typename T> __device__ __forceinline__ void st_elem(T* p, float v);
 template <> __device__ __forceinline__ void st_elem<float>(float* p, float v) { *p = v; }
 template <> __device__ __forceinline__ void st_elem<bf16_t>(bf16_t* p, float v) { p->v = f32_to_bf16(v); }
 
+// ---- fp32 storage on the bf16 matrix pipe (round 4) ------------------------------------------------------------------------
+// v_mfma_f32_16x16x4_f32 runs at 1/16 of the bf16 MFMA rate (exact fp32: 64 FLOP/clk/SIMD).  Default for fp32 storage since round 4:
+// every fp32 operand is split into two bf16 halves, x = hi + lo (hi = bf16(x), lo = bf16(x - hi): |x - hi - lo| <= 2^-17 |x|), and a
+// product is three bf16 MFMAs with fp32 accumulation, a b ~= hi_a lo_b + lo_a hi_b + hi_a hi_b - relative error 2^-16 per product (the
+// dropped lo lo term), tighter than the TF32 (2^-11) path the reference's GPU convolutions take.  v_mfma_f32_16x16x16_bf16 takes the four
+// consecutive channels of an fp32 piece as its four k-values per lane: the LDS image, the staging and the packed-weight SIZE are the
+// fp32 ones (a packed weight fragment is 16 bytes per lane either way: 4 floats, or 4 hi + 4 lo halves).
+// -DVDM_FP32_SPLIT=0 builds the exact variant (libvdm4cdm_hip_fp32exact.so, selected by VDM4CDM_FP32_EXACT=1).
+#ifndef VDM_FP32_SPLIT
+#define VDM_FP32_SPLIT 1
+#endif
+// (hi01, hi23, lo01, lo23) of the four floats of a piece
+__device__ __forceinline__ uint4 split_frag(const uint4& raw) {
+    const float x0 = __builtin_bit_cast(float, raw.x), x1 = __builtin_bit_cast(float, raw.y), x2 = __builtin_bit_cast(float, raw.z),
+                x3 = __builtin_bit_cast(float, raw.w);
+    const uint32_t h01 = pack_bf16x2(x0, x1), h23 = pack_bf16x2(x2, x3);
+    const float r0 = x0 - __builtin_bit_cast(float, h01 << 16), r1 = x1 - __builtin_bit_cast(float, h01 & 0xffff0000u),
+                r2 = x2 - __builtin_bit_cast(float, h23 << 16), r3 = x3 - __builtin_bit_cast(float, h23 & 0xffff0000u);
+    return make_uint4(h01, h23, pack_bf16x2(r0, r1), pack_bf16x2(r2, r3));
+}
+// element i of a packed-weight buffer (fragments of [64 lanes][EPL]): fp32 split mode stores (hi, lo) halves instead of the float
+template <typename T> __device__ __forceinline__ void st_packed_w(T* p, size_t i, float v) { st_elem<T>(p + i, v); }
+template <> __device__ __forceinline__ void st_packed_w<float>(float* p, size_t i, float v) {
+#if VDM_FP32_SPLIT
+    uint16_t* q = reinterpret_cast<uint16_t*>(p) + (i >> 2) * 8;
+    const int j = (int)(i & 3);
+    const uint16_t hi = f32_to_bf16(v);
+    q[j] = hi;
+    q[4 + j] = f32_to_bf16(v - bf16_to_f32(hi));
+#else
+    p[i] = v;
+#endif
+}
+
 // ---- wave / block reductions (wave64) -------------------------------------------------------
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll

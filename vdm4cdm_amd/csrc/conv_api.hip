@@ -27,7 +27,7 @@ __global__ void pack_weights_cls_kernel(const float* __restrict__ w, T* __restri
             for (int t = 0; t < 27; ++t)
                 if ((mask >> t) & 1u) v += transpose ? w[((size_t)t * cout_m + k) * cin_m + o] : w[((size_t)t * cout_m + o) * cin_m + k];
         }
-        st_elem<T>(p + i, v);
+        st_packed_w<T>(p, i, v);
     }
 }
 
@@ -61,7 +61,7 @@ __global__ void pack_weights_kernel(const float* __restrict__ w, T* __restrict__
             else
                 v = w[((size_t)tap * cout_m + o) * cin_m + k];
         }
-        st_elem<T>(p + i, v);
+        st_packed_w<T>(p, i, v);
     }
 }
 
@@ -210,7 +210,7 @@ __global__ void __launch_bounds__(256) pack_many_kernel(const vdm_pack_item* __r
 #pragma unroll
         for (int u = 0; u < FRAG / 256; ++u) {
             const int e = threadIdx.x + u * 256;
-            st_elem<T>(out + f + e, pack_value<T>(it, w, r, e / EPL, j));
+            st_packed_w<T>(out, (size_t)(f + e), pack_value<T>(it, w, r, e / EPL, j));
         }
     }
 }

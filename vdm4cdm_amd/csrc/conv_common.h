@@ -368,12 +368,30 @@ template <typename T> __device__ __forceinline__ void mma16(f32x4& acc, const ui
 template <> __device__ __forceinline__ void mma16<bf16_t>(f32x4& acc, const uint4& a, const uint4& b) {
     acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), acc, 0, 0, 0);
 }
+#if VDM_FP32_SPLIT
+// both operands in split form (hi01, hi23, lo01, lo23): three bf16 MFMAs, small terms first
+__device__ __forceinline__ void mma16_ss(f32x4& acc, const uint4& a, const uint4& b) {
+    const s16x4 ah = __builtin_bit_cast(s16x4, make_uint2(a.x, a.y)), al = __builtin_bit_cast(s16x4, make_uint2(a.z, a.w));
+    const s16x4 bh = __builtin_bit_cast(s16x4, make_uint2(b.x, b.y)), bl = __builtin_bit_cast(s16x4, make_uint2(b.z, b.w));
+    acc = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(ah, bl, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(al, bh, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(ah, bh, acc, 0, 0, 0);
+}
+// A = packed weights (already split), B = raw fp32 piece from LDS
+template <> __device__ __forceinline__ void mma16<float>(f32x4& acc, const uint4& a, const uint4& b) { mma16_ss(acc, a, split_frag(b)); }
+#else
 template <> __device__ __forceinline__ void mma16<float>(f32x4& acc, const uint4& a, const uint4& b) {
     acc = __builtin_amdgcn_mfma_f32_16x16x4f32(__builtin_bit_cast(float, a.x), __builtin_bit_cast(float, b.x), acc, 0, 0, 0);
     acc = __builtin_amdgcn_mfma_f32_16x16x4f32(__builtin_bit_cast(float, a.y), __builtin_bit_cast(float, b.y), acc, 0, 0, 0);
     acc = __builtin_amdgcn_mfma_f32_16x16x4f32(__builtin_bit_cast(float, a.z), __builtin_bit_cast(float, b.z), acc, 0, 0, 0);
     acc = __builtin_amdgcn_mfma_f32_16x16x4f32(__builtin_bit_cast(float, a.w), __builtin_bit_cast(float, b.w), acc, 0, 0, 0);
 }
+#endif
+// both operands are raw activation / gradient fragments (weight gradients)
+template <typename T> __device__ __forceinline__ void mma16_act(f32x4& acc, const uint4& a, const uint4& b) { mma16<T>(acc, a, b); }
+#if VDM_FP32_SPLIT
+template <> __device__ __forceinline__ void mma16_act<float>(f32x4& acc, const uint4& a, const uint4& b) { mma16_ss(acc, split_frag(a), split_frag(b)); }
+#endif
 
 // XCD-aware, bijective block remap: blocks b and b+8 share an XCD (observed round-robin), so give
 // each XCD a contiguous run of spatial tiles (their halos overlap -> hits in that XCD's L2).
@@ -556,6 +574,21 @@ __device__ __forceinline__ void taps_rolled(f32x4 (&acc)[NV][NC], const char* ld
         for (int c = 0; c < NC; ++c) wn[c] = wk[(tn * NC + c) * 64];
 #pragma unroll
         for (int v = 0; v < NV; ++v) af[v] = *reinterpret_cast<const uint4*>(lds + lx0 + v * ROWB + toff);
+#if VDM_FP32_SPLIT
+        uint4 bs[NV];
+#pragma unroll
+        for (int v = 0; v < NV; ++v) bs[v] = split_frag(af[v]);      // once per (tap, row): reused by the NC output tiles
+#pragma unroll
+        for (int m = 0; m < 3; ++m)                                   // term-major over the NV x NC independent accumulators
+#pragma unroll
+            for (int v = 0; v < NV; ++v)
+#pragma unroll
+                for (int c = 0; c < NC; ++c) {
+                    const s16x4 ah = __builtin_bit_cast(s16x4, make_uint2(wf[c].x, wf[c].y)), al = __builtin_bit_cast(s16x4, make_uint2(wf[c].z, wf[c].w));
+                    const s16x4 bh = __builtin_bit_cast(s16x4, make_uint2(bs[v].x, bs[v].y)), bl = __builtin_bit_cast(s16x4, make_uint2(bs[v].z, bs[v].w));
+                    acc[v][c] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(m == 1 ? al : ah, m == 0 ? bl : bh, acc[v][c], 0, 0, 0);
+                }
+#else
 #pragma unroll
         for (int st = 0; st < 4; ++st)
 #pragma unroll
@@ -566,6 +599,7 @@ __device__ __forceinline__ void taps_rolled(f32x4 (&acc)[NV][NC], const char* ld
                     const uint32_t bw = st == 0 ? af[v].x : (st == 1 ? af[v].y : (st == 2 ? af[v].z : af[v].w));
                     acc[v][c] = __builtin_amdgcn_mfma_f32_16x16x4f32(__builtin_bit_cast(float, aw), __builtin_bit_cast(float, bw), acc[v][c], 0, 0, 0);
                 }
+#endif
     }
 }
 

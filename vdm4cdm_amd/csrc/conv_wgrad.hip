@@ -114,7 +114,7 @@ __global__ void __launch_bounds__(256, 2) conv_wgrad_kernel(const WgradArgs w) {
 #pragma unroll
                 for (int i = 0; i < NTA; ++i)
 #pragma unroll
-                    for (int j = 0; j < NTB; ++j) mma16<T>(acc[t][i][j], af[i], cur[j]);
+                    for (int j = 0; j < NTB; ++j) mma16_act<T>(acc[t][i][j], af[i], cur[j]);
                 __builtin_amdgcn_sched_barrier(0);
             }
 #pragma unroll
