@@ -45,6 +45,12 @@ FLOP_PER_VOXEL_FWD = 720.0e3
 BYTES_PER_VOXEL_FWD = {"bf16": 1.53e3, "fp32": 3.05e3}
 HBM_PEAK = 8.0e12
 MFMA_PEAK = {"bf16": 2.5e15, "fp32": 157.3e12}
+# fp32 STORAGE runs on the bf16 matrix pipe by default (three bf16 MFMAs per product, csrc/common.h VDM_FP32_SPLIT): its ceiling is a third
+# of the bf16 peak; VDM4CDM_FP32_EXACT=1 selects the library built on v_mfma_f32_16x16x4_f32 and the fp32 MFMA peak above
+from vdm4cdm_amd import _lib as _vlib
+if not _vlib.FP32_EXACT:
+    MFMA_PEAK["fp32"] = 2.5e15 / 3.0
+DTYPE_LABEL = {"bf16": "bf16", "fp32": "fp32 (exact fp32 MFMA)" if _vlib.FP32_EXACT else "fp32 storage, bf16x3 MFMA"}
 
 
 def build_model(D, chs, precision, device, seed=42):
@@ -303,7 +309,7 @@ def main():
         out = {
             "metric": f"3D voxels/sec UNet fwd+bwd @{D}^3 (VDM training step)", "value": value, "unit": "voxels/s",
             "n_gpus": world, "steps": 0 if args.sample_only else args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": precision, "data": "synthetic",
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": DTYPE_LABEL[precision], "data": "synthetic",
             "config": {"workload": f"{args.config}: {D}^3 conditional VDM (trainVDM3D128_c_c thick_lowbatch), chs {chs}, "
                                    f"batch {B}/GPU, full training step (diffuse + UNet fwd + ELBO + UNet bwd + clip + AdamW), dropout 0.1",
                        "global_batch": world * B, "cube": D, "parallelism": f"dp{world}"},

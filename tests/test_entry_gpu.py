@@ -283,3 +283,16 @@ def test_streams_and_allocator_hazards(mode, precision):
     r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "_stream_hazard_worker.py")], env=env, cwd=ROOT, capture_output=True,
                        text=True, timeout=900)
     assert r.returncode == 0 and "HAZARD_OK" in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]
+
+
+def test_fp32_exact_library_passes_the_fp32_parity_cases():
+    """fp32 storage has two builds of the same C-ABI: the default computes each product as three bf16 MFMAs (hi*hi + hi*lo + lo*hi,
+    csrc/common.h VDM_FP32_SPLIT), VDM4CDM_FP32_EXACT=1 loads libvdm4cdm_hip_fp32exact.so (v_mfma_f32_16x16x4_f32).  The in-process fp32
+    tests cover the default; this child runs the conv / folded-GroupNorm / UNet fp32 cases against the exact library at the SAME
+    tolerances, so the selectable build cannot rot."""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
+    env["VDM4CDM_FP32_EXACT"] = "1"
+    r = subprocess.run([sys.executable, "-m", "pytest", "tests/test_kernels_gpu.py", "tests/test_unet_gpu.py", "-x", "-q", "-m", "gpu", "-k",
+                        "(test_conv_grads and f32) or (test_gn_bwd_folded_into_dgrad and f32) or test_unet_forward_fp32 or test_unet_backward_fp32",
+                        "-p", "no:cacheprovider"], env=env, cwd=ROOT, capture_output=True, text=True, timeout=1200)
+    assert r.returncode == 0 and " passed" in r.stdout, r.stdout[-3000:] + r.stderr[-2000:]

@@ -1351,9 +1351,9 @@ static void fwd_tile_shape(const ConvArgs& a, int dtype, int out_f32, int ks, in
     tz = 4; ty = 8;
     if (stride == 2) { tz = s2_tile_z(); ty = 4; return; }
     if (uses_kpack(dtype, ks, stride, ups, a.Cin, a.Cout, out_f32)) return;
-    if (ks == 3 && dtype == VDM_BF16) {
+    if (ks == 3) {
         small_grid_tile(a, tz, ty);
-        if (stride == 1 && !ups && !out_f32) ksplit_tile(a, tz, ty);
+        if (dtype == VDM_BF16 && stride == 1 && !ups && !out_f32) ksplit_tile(a, tz, ty);
     }
 }
 

@@ -490,10 +490,10 @@ template <typename T, typename TO, int KS, int STRIDE, int UPS, int NC, bool GNB
 static int launch_fwd_geo(const ConvArgs& a, hipStream_t s) {
     if constexpr (STRIDE == 2)
         return s2_tile_z() == 1 ? launch_fwd_cfg<T, TO, KS, STRIDE, UPS, NC, 1, 4>(a, s) : launch_fwd_cfg<T, TO, KS, STRIDE, UPS, NC, 2, 4>(a, s);
-    else if constexpr (KS == 3 && sizeof(T) == 2) {
+    else if constexpr (KS == 3) {      // (fp32 storage too since round 4: on the bf16 pipe it is no longer MFMA-bound, small grids need small tiles)
         int tz, ty;
         small_grid_tile(a, tz, ty);
-        if constexpr (NC == 4 && UPS == 0 && sizeof(TO) == 2) {
+        if constexpr (NC == 4 && UPS == 0 && sizeof(TO) == 2 && sizeof(T) == 2) {
             if (ksplit_tile(a, tz, ty)) {
                 if constexpr (GNP) { set_error("conv_fwd_gn: the K-split kernel has no GroupNorm prologue (vdm_conv_fwd_gn_supported)"); return VDM_ERR_UNSUPPORTED; }
                 else return ty == 4 ? launch_ksplit<T, TO, 4, 4, GNB>(a, s) : launch_ksplit<T, TO, 4, 8, GNB>(a, s);
@@ -505,10 +505,10 @@ static int launch_fwd_geo(const ConvArgs& a, hipStream_t s) {
         }
         if (tz == 1) return ty == 4 ? launch_fwd_cfg<T, TO, KS, STRIDE, UPS, NC, 1, 4, false, GNB, GNP>(a, s) : launch_fwd_cfg<T, TO, KS, STRIDE, UPS, NC, 1, 8, false, GNB, GNP>(a, s);
         if (tz == 2) return launch_fwd_cfg<T, TO, KS, STRIDE, UPS, NC, 2, 8, false, GNB, GNP>(a, s);
-        if constexpr (STRIDE == 1 && UPS == 0 && sizeof(TO) == 2 && NC == 2 && !GNP) {      // one K-block, large grid: persistent walk up z
+        if constexpr (STRIDE == 1 && UPS == 0 && sizeof(TO) == 2 && sizeof(T) == 2 && NC == 2 && !GNP) {      // one K-block, large grid: persistent walk up z
             if (a.nkb == 1 && cdiv(a.Dz, 4) >= 4 && roll_enabled()) return launch_roll<T, NC, GNB>(a, s);
         }
-        if constexpr (STRIDE == 1 && UPS == 0 && sizeof(TO) == 2 && NC == 2 && !GNP) {      // large grids: eight waves share the 4x8x16 tile
+        if constexpr (STRIDE == 1 && UPS == 0 && sizeof(TO) == 2 && sizeof(T) == 2 && NC == 2 && !GNP) {      // large grids: eight waves share the 4x8x16 tile
             // (NC = 4 needs > 128 registers per wave: its accumulators alone are 64)
             if (wg8_enabled(NC, GNB)) return launch_fwd_cfg<T, TO, KS, STRIDE, UPS, NC, 4, 8, false, GNB, GNP, 8>(a, s);
         }

@@ -3,6 +3,32 @@
 
 namespace vdm {
 
+// diagnostic build (make timeline; tools/wgrad_phases.py): per wave the s_memrealtime ticks (100 MHz) of each phase, summed over its tiles
+#ifdef VDM_TIMELINE
+#define WG_TL_DECL unsigned long long tl_acc[6] = {0, 0, 0, 0, 0, 0}, tl_last = __builtin_amdgcn_s_memrealtime(); const unsigned long long tl_first = tl_last
+#define WG_TL(k)                                                          \
+    do {                                                                  \
+        __builtin_amdgcn_sched_barrier(0);                                \
+        const unsigned long long now_ = __builtin_amdgcn_s_memrealtime(); \
+        tl_acc[k] += now_ - tl_last;                                      \
+        tl_last = now_;                                                   \
+        __builtin_amdgcn_sched_barrier(0);                                \
+    } while (0)
+#define WG_TL_WRITE(a_)                                                                                     \
+    do {                                                                                                    \
+        if ((a_).stamps && lane == 0) {                                                                     \
+            unsigned long long* o_ = (a_).stamps + ((size_t)blockIdx.x * 4 + wave) * 8;                      \
+            for (int k_ = 0; k_ < 6; ++k_) o_[k_] = tl_acc[k_];                                             \
+            o_[6] = tl_first;                                                                               \
+            o_[7] = __builtin_amdgcn_s_memrealtime();                                                       \
+        }                                                                                                   \
+    } while (0)
+#else
+#define WG_TL_DECL do { } while (0)
+#define WG_TL(k) do { } while (0)
+#define WG_TL_WRITE(a_) do { } while (0)
+#endif
+
 // ---------------------------------------------------------------------------------------------
 // wgrad kernel
 // ---------------------------------------------------------------------------------------------
@@ -75,18 +101,22 @@ __global__ void __launch_bounds__(256, 2) conv_wgrad_kernel(const WgradArgs w) {
 #pragma unroll
     for (int j = 0; j < DT<T>::EPL; ++j) bsum[j] = 0.f;
     auto in_base = [&](int r) { return (((r / TY) * STRIDE * G::HY + (r % TY) * STRIDE) * G::HX) * 64; };
+    WG_TL_DECL;
 
     for (int tile = pidx; tile < w.ntiles; tile += w.P) {
         int tx, ty, tz, n, rest_;
         decode_tile(a, (uint32_t)tile, tx, ty, tz, n, rest_);      // (tile < ntiles: rest_ == 0)
         const int oz0 = tz * TZ, oy0 = ty * TY, ox0 = tx * 16;
         __syncthreads();                                   // every wave is done reading the previous tile
+        WG_TL(0);
         stage_halo_dma<T, G, CLS ? 0 : UPS>(lds_in, x, a, n, oz0, oy0, ox0, kb, wave, lane);
         if constexpr (CLS)
             stage_dout_dma_sub<T, G>(lds_do, g, a, n, oz0, oy0, ox0, cb, w.dout_stride, pz, py, px, wave, lane);
         else
             stage_dout_dma<T, G>(lds_do, g, a, n, oz0, oy0, ox0, cb, w.dout_stride, wave, lane);
+        WG_TL(1);
         __syncthreads();                                   // (drains the LDS-DMA: vmcnt(0) + barrier)
+        WG_TL(2);
         // Software pipeline: while the MFMAs of tap t run, the transposed fragments of tap t+1 (or of the next
         // row's tap 0 and its dOut fragments) are already in flight; sched_barrier(0) pins that order.
         uint4 af[NTA], afn[NTA], bfA[NTB], bfB[NTB];
@@ -124,6 +154,7 @@ __global__ void __launch_bounds__(256, 2) conv_wgrad_kernel(const WgradArgs w) {
                 for (int j = 0; j < NTB; ++j) bfA[j] = bfB[j];
             }
         }
+        WG_TL(3);
         // bias gradient: column sums of this dOut tile (already in LDS), by the workgroups with cin block 0; every wave
         // takes a quarter of the rows.  Lane l sums the 16-B slot (l & 3) of voxels x = l >> 2: with the x-swizzle that
         // is always the same channel piece, so the sums stay in EPL registers until the kernel ends.
@@ -137,6 +168,7 @@ __global__ void __launch_bounds__(256, 2) conv_wgrad_kernel(const WgradArgs w) {
                 for (int j = 0; j < DT<T>::EPL; ++j) bsum[j] += pz.f[j];
             }
         }
+        WG_TL(4);
     }
 
     constexpr int CL = NT * 16;                               // channels per 64-B block
@@ -175,6 +207,144 @@ __global__ void __launch_bounds__(256, 2) conv_wgrad_kernel(const WgradArgs w) {
                 for (int rg = 0; rg < 4; ++rg)
                     slab[(tap * CL + i * 16 + gq * 4 + rg) * CL + j * 16 + col] = (i < NTA && j < NTB) ? acc[t][i < NTA ? i : 0][j < NTB ? j : 0][rg] : 0.f;
     }
+    WG_TL(5);
+    WG_TL_WRITE(a);
+}
+
+// ---------------------------------------------------------------------------------------------
+// wgrad kernel, halo rows of the shifted operand resident in registers (round 4; bf16, 3^3, stride 1, full 32 x 32 channel blocks)
+// ---------------------------------------------------------------------------------------------
+// conv_wgrad_kernel splits the 27 taps over its waves: per k-step (two 16-voxel rows) a wave reads 2 dOut fragments and, for each of its
+// 7 taps, 2 fragments of the shifted input = 32 transposed LDS reads for 28 MFMAs, and the same halo row is read again for every (dy, k-step)
+// that touches it.  Here a wave owns ONE 16 x 16 tile of the (cout, cin) block and all 27 taps (108 accumulator registers).  With the
+// fragment's K order chosen as (row R: 16 voxels | row R + 1: 16 voxels) one ds_read_b64_tr_b16 is one whole halo row, so for a halo slab hz
+// and a shift dx the TY + 2 rows are read ONCE (10 reads) and serve every (dz, dy, k-step) combination: tap (dz, dy, dx) of output slab
+// oz = hz - dz multiplies the dOut fragment of rows (2j, 2j + 1) with the register pair (row 2j + dy, row 2j + dy + 1).  The dOut fragments
+// of the whole tile stay in registers (TZ * TY / 2 fragments).  Per 2 x 8 x 16 tile and wave: 120 + 16 reads for 216 MFMAs (0.63 reads per MFMA
+// instead of 1.14).  Same slab layout as conv_wgrad_kernel, same reduce kernels; the summation order per output differs (halo-slab-major).
+template <typename T, int TZ, int TY>
+__global__ void __launch_bounds__(256, 2) conv_wgrad_rows_kernel(const WgradArgs w) {
+    using G = Geo<3, 1, TZ, TY>;
+    using TF = TrFetch<T>;
+    static_assert(sizeof(T) == 2 && (TY % 2) == 0, "bf16 only: a fragment = two rows of the same z-slab");
+    constexpr int IN_BYTES = ((G::HVOX + 15) / 16) * 1024;
+    constexpr int NJ = TY / 2, NR = TY + 2, NG = G::HZ * 3, CL = 32;
+    typedef __attribute__((address_space(3))) s16x4* lptr;
+    extern __shared__ __attribute__((aligned(16))) char lds[];
+    char* lds_in = lds;
+    char* lds_do = lds + IN_BYTES;
+    const ConvArgs& a = w.c;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int ia = wave >> 1, jb = wave & 1;               // this wave's cout tile / cin tile of the 32 x 32 block
+    const int pair = blockIdx.x / w.P, pidx = blockIdx.x % w.P;
+    const int cb = pair / w.nkb, kb = pair % w.nkb;
+
+    f32x4 acc[27];
+#pragma unroll
+    for (int t = 0; t < 27; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+    int lo_a[1], lo_b[3][1];
+    TF::lane_off(lo_a, ia, 1, 0, lane);
+#pragma unroll
+    for (int dx = 0; dx < 3; ++dx) TF::lane_off(lo_b[dx], jb, 1, dx, lane);
+
+    const T* x = reinterpret_cast<const T*>(a.x);
+    const T* g = reinterpret_cast<const T*>(w.dout);
+    float bsum[DT<T>::EPL];
+#pragma unroll
+    for (int j = 0; j < DT<T>::EPL; ++j) bsum[j] = 0.f;
+
+    auto rows_of = [&](uint2 (&dst)[NR], int grp) {         // the TY + 2 halo rows of (halo slab, dx) = grp
+        const int hz = grp / 3, dx = grp % 3;
+#pragma unroll
+        for (int r = 0; r < NR; ++r)
+            dst[r] = __builtin_bit_cast(uint2, __builtin_amdgcn_ds_read_tr16_b64_v4i16((lptr)(lds_in + (hz * G::HY + r) * G::HX * 64 + lo_b[dx][0])));
+    };
+
+    WG_TL_DECL;
+    for (int tile = pidx; tile < w.ntiles; tile += w.P) {
+        int tx, ty, tz, n, rest_;
+        decode_tile(a, (uint32_t)tile, tx, ty, tz, n, rest_);
+        const int oz0 = tz * TZ, oy0 = ty * TY, ox0 = tx * 16;
+        __syncthreads();                                   // every wave is done reading the previous tile
+        WG_TL(0);
+        stage_halo_dma<T, G, 0>(lds_in, x, a, n, oz0, oy0, ox0, kb, wave, lane);
+        stage_dout_dma<T, G>(lds_do, g, a, n, oz0, oy0, ox0, cb, w.dout_stride, wave, lane);
+        WG_TL(1);
+        __syncthreads();                                   // (drains the LDS-DMA: vmcnt(0) + barrier)
+        WG_TL(2);
+        uint4 af[TZ][NJ];
+#pragma unroll
+        for (int oz = 0; oz < TZ; ++oz)
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) af[oz][j] = TF::template get<1024>(lds_do, lo_a, (oz * TY + 2 * j) * 1024);
+        uint2 rowsA[NR], rowsB[NR];
+        rows_of(rowsA, 0);
+#pragma unroll
+        for (int grp = 0; grp < NG; ++grp) {
+            uint2 (&cur)[NR] = (grp & 1) ? rowsB : rowsA;
+            uint2 (&nxt)[NR] = (grp & 1) ? rowsA : rowsB;
+            if (grp + 1 < NG) rows_of(nxt, grp + 1);        // in flight behind this group's MFMAs
+            __builtin_amdgcn_sched_barrier(0);
+            const int hz = grp / 3, dx = grp % 3;
+#pragma unroll
+            for (int j = 0; j < NJ; ++j)
+#pragma unroll
+                for (int dz = 0; dz < 3; ++dz) {
+                    const int oz = hz - dz;
+                    if (oz < 0 || oz >= TZ) continue;
+#pragma unroll
+                    for (int dy = 0; dy < 3; ++dy) {
+                        const uint2 r0 = cur[2 * j + dy], r1 = cur[2 * j + dy + 1];
+                        mma16_act<T>(acc[(dz * 3 + dy) * 3 + dx], af[oz][j], make_uint4(r0.x, r0.y, r1.x, r1.y));
+                    }
+                }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        WG_TL(3);
+        // bias gradient: column sums of this dOut tile (see conv_wgrad_kernel)
+        if (w.bslabs != nullptr && kb == 0) {
+            const int vx = lane >> 2, sl = lane & 3;
+#pragma unroll
+            for (int r = wave; r < G::ROWS; r += 4) {
+                Piece<T> pz;
+                pz.load(*reinterpret_cast<const uint4*>(lds_do + r * 1024 + vx * 64 + sl * 16));
+#pragma unroll
+                for (int j = 0; j < DT<T>::EPL; ++j) bsum[j] += pz.f[j];
+            }
+        }
+        WG_TL(4);
+    }
+
+    if (w.bslabs != nullptr && kb == 0) {                  // workgroup-uniform condition
+        float* shb = reinterpret_cast<float*>(lds);
+        constexpr int EPLc = DT<T>::EPL;
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < EPLc; ++j) shb[tid * EPLc + j] = bsum[j];
+        __syncthreads();
+        if (tid < CL) {
+            const int piece = tid / EPLc, j = tid % EPLc;
+            float tot = 0.f;
+            for (int wv = 0; wv < 4; ++wv)
+                for (int vx = 0; vx < 16; ++vx) {
+                    const int ln = vx * 4 + (piece ^ ((vx >> 1) & 3));
+                    tot += shb[(wv * 64 + ln) * EPLc + j];
+                }
+            w.bslabs[((size_t)cb * w.P + pidx) * CL + tid] = tot;
+        }
+    }
+    // ---- this wave's 16 x 16 tile of every tap: slab[tap][co_local][ci_local] ---------------------
+    float* slab = w.slabs + (size_t)(pair * w.P + pidx) * (27 * CL * CL);
+    const int gq = lane >> 4, col = lane & 15;
+#pragma unroll
+    for (int t = 0; t < 27; ++t)
+#pragma unroll
+        for (int rg = 0; rg < 4; ++rg) slab[(t * CL + ia * 16 + gq * 4 + rg) * CL + jb * 16 + col] = acc[t][rg];
+    WG_TL(5);
+    WG_TL_WRITE(a);
 }
 
 // dw[tap][co][ci] (+)= sum over slabs.  Block = 64 outputs x 4 slab groups; each thread sums its slabs with 8
@@ -296,6 +466,12 @@ static bool ablate_reduce() {
     return on;
 }
 
+// VDM4CDM_WGRAD_ROWS=0: the tap-split kernel also for the full bf16 3^3 stride-1 blocks (A/B switch)
+static bool wgrad_rows_enabled() {
+    static const bool on = [] { const char* e = getenv("VDM4CDM_WGRAD_ROWS"); return e == nullptr || atoi(e) != 0; }();
+    return on;
+}
+
 template <typename T, int KS, int STRIDE, int UPS, int TZ, int TY, int NTA = WG<T>::NT, int NTB = WG<T>::NT>
 static int launch_wgrad_cfg(WgradArgs w, float* dw, float* dbias, int accumulate, int cout, int cin, size_t ws_bytes, hipStream_t s) {
     using G = Geo<KS, STRIDE, TZ, TY>;
@@ -304,6 +480,9 @@ static int launch_wgrad_cfg(WgradArgs w, float* dw, float* dbias, int accumulate
     a.ntz = cdiv(a.Dz, TZ); a.nty = cdiv(a.Dy, TY); a.ntx = cdiv(a.Dx, 16);
     set_tile_divs(a);
     w.ntiles = a.N * a.ntz * a.nty * a.ntx;
+#ifdef VDM_TIMELINE
+    a.stamps = g_timeline_stamps;
+#endif
     const int npairs = w.ncb * w.nkb;
     int P = wgrad_wgs() / npairs;             // persistent: ~2 workgroups per CU over all (cout, cin) block pairs
     if (P < 1) P = 1;
@@ -316,13 +495,24 @@ static int launch_wgrad_cfg(WgradArgs w, float* dw, float* dbias, int accumulate
     if (dbias != nullptr && G::TAPS == 1) { set_error("conv_wgrad: fused bias gradient is only built for ksize 3"); return VDM_ERR_UNSUPPORTED; }
     w.bslabs = dbias ? reinterpret_cast<float*>(reinterpret_cast<char*>(w.slabs) + slab_bytes) : nullptr;
     const size_t lds = (size_t)((G::HVOX + 15) / 16) * 1024 + (size_t)G::OVOX * 64;
-    auto kern = conv_wgrad_kernel<T, KS, STRIDE, UPS, TZ, TY, NTA, NTB>;
-    static unsigned long long lds_done = 0;
-    {
+    bool launched = false;
+    if constexpr (sizeof(T) == 2 && KS == 3 && STRIDE == 1 && UPS == 0 && NTA == 2 && NTB == 2) {
+        if (wgrad_rows_enabled()) {
+            auto kern = conv_wgrad_rows_kernel<T, TZ, TY>;
+            static unsigned long long lds_done_rows = 0;
+            int e = set_lds(kern, lds, lds_done_rows);
+            if (e) return e;
+            hipLaunchKernelGGL(kern, dim3(npairs * P), dim3(256), lds, s, w);
+            launched = true;
+        }
+    }
+    if (!launched) {
+        auto kern = conv_wgrad_kernel<T, KS, STRIDE, UPS, TZ, TY, NTA, NTB>;
+        static unsigned long long lds_done = 0;
         int e = set_lds(kern, lds, lds_done);
         if (e) return e;
+        hipLaunchKernelGGL(kern, dim3(npairs * P), dim3(256), lds, s, w);
     }
-    hipLaunchKernelGGL(kern, dim3(npairs * P), dim3(256), lds, s, w);
     VDM_LAUNCH_CHECK("conv_wgrad_kernel");
     if (ablate_reduce()) return VDM_OK;
     const int total = G::TAPS * cout * cin;
@@ -348,6 +538,9 @@ static int launch_wgrad_cls(WgradArgs w, float* dw, float* dbias, int accumulate
     constexpr int CL = WG<T>::NT * 16;
     ConvArgs& a = w.c;
     a.Dz /= 2; a.Dy /= 2; a.Dx /= 2;                       // everything runs on the coarse grid
+#ifdef VDM_TIMELINE
+    a.stamps = g_timeline_stamps;
+#endif
     a.Iz = a.Sz = a.Dz; a.Iy = a.Sy = a.Dy; a.Ix = a.Sx = a.Dx;
     a.ntz = cdiv(a.Dz, G::TZ); a.nty = cdiv(a.Dy, G::TY); a.ntx = cdiv(a.Dx, 16);
     set_tile_divs(a);
