@@ -213,6 +213,10 @@ __device__ __forceinline__ void stage_halo_dma_chunks(char* lds, const T* __rest
 #ifndef VDM_ROWSTAGE
 #define VDM_ROWSTAGE 1
 #endif
+// leftover voxels of a row: 0 = one 4-byte-per-lane LDS-DMA (16 lanes per voxel), 1 = one 16-byte-per-lane LDS-DMA (4 lanes per voxel)
+#ifndef VDM_TAIL16
+#define VDM_TAIL16 0
+#endif
 // per-lane x part (once per tile / per persistent workgroup) + one halo row per call
 template <typename T, typename G, int UPS>
 struct RowStager {
@@ -248,9 +252,13 @@ struct RowStager {
 #pragma unroll
         for (int sgm = 0; sgm < NSEG; ++sgm) okx[sgm] = xpart(16 * sgm + (lane >> 2), lane & 3, xoff[sgm]);
         if constexpr (NTAIL > 0) {
+#if VDM_TAIL16
+            tok = xpart(16 * NSEG + ((lane >> 2) & 3), lane & 3, toff) && lane < 4 * NTAIL;      // 16 B per lane, 4 lanes per leftover voxel
+#else
             const int d = lane & 15;                                          // dword of the tail voxel lane >> 4
             tok = xpart(16 * NSEG + (lane >> 4), d >> 2, toff) && lane < 16 * NTAIL;
             toff += (unsigned)(d & 3) * 4u;
+#endif
         }
     }
     // halo row (hz, hy) of the tile (wave-uniform) -> LDS row `lrow` (HX * 64 bytes): NSEG (+1) LDS-DMAs, scalar address arithmetic
@@ -273,13 +281,23 @@ struct RowStager {
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
                                              (__attribute__((address_space(3))) void*)(lrow + sgm * 1024), 16, 0, 0);
         }
+#ifndef VDM_EXP_NOTAIL                                                        // (timing experiment: rows without their leftover voxels)
         if constexpr (NTAIL > 0) {
+#if VDM_TAIL16
+            if (lane < 4 * NTAIL) {
+                const char* src = (okrow && tok) ? rowp + toff : zp;
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                                 (__attribute__((address_space(3))) void*)(lrow + NSEG * 1024), 16, 0, 0);
+            }
+#else
             if (lane < 16 * NTAIL) {
                 const char* src = (okrow && tok) ? rowp + toff : zp;
                 __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
                                                  (__attribute__((address_space(3))) void*)(lrow + NSEG * 1024), 4, 0, 0);
             }
+#endif
         }
+#endif
     }
 };
 
@@ -1090,6 +1108,35 @@ __device__ __forceinline__ void stage_dout_dma_gen(char* lds, const T* __restric
                                          (__attribute__((address_space(3))) void*)(lds + r * 1024), 16, 0, 0);
     }
 }
+
+// one dOut row per call (a persistent walk issues them between MFMA groups): per-lane x part once per column
+template <typename T, typename G>
+struct DoutRowStager {
+    static constexpr int EPL = DT<T>::EPL, KB = DT<T>::KB, SH = DT<T>::SHIFT;
+    unsigned xoff;
+    bool okx;
+    const char* gn;
+    int cstride;
+    __device__ __forceinline__ DoutRowStager(const T* __restrict__ g, const ConvArgs& a, int n, int ox0, int cb, int cstride_, int lane) : cstride(cstride_) {
+        const int k = lane >> 2, j = lane & 3;
+        const int pc = j ^ ((k >> 1) & 3);
+        const int co = cb * KB + pc * EPL;
+        const int ox = ox0 + k;
+        okx = co < a.Cout && ox < a.Dx;
+        xoff = (__umul24((unsigned)ox & 0xffffffu, (unsigned)cstride) + (unsigned)co) << SH;
+        gn = reinterpret_cast<const char*>(g) + (((size_t)n * a.Dz * a.Dy * a.Dx * cstride) << SH);
+    }
+    // tile row r (of G::ROWS) of the tile at (oz0, oy0) -> lds + r * 1024
+    __device__ __forceinline__ void row(char* lds, const ConvArgs& a, int oz0, int oy0, int r) const {
+        const int oz = oz0 + r / G::TY, oy = oy0 + r % G::TY;
+        const bool okrow = oz < a.Dz && oy < a.Dy;
+        const unsigned fz = okrow ? (unsigned)oz : 0u, fy = okrow ? (unsigned)oy : 0u;
+        const size_t rowel = (size_t)((fz * (unsigned)a.Dy + fy) * (unsigned)a.Dx) * (unsigned)cstride;
+        const char* src = (okrow && okx) ? gn + (rowel << SH) + xoff : reinterpret_cast<const char*>(g_zero_page);
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                         (__attribute__((address_space(3))) void*)(lds + r * 1024), 16, 0, 0);
+    }
+};
 
 template <typename T, typename G>
 __device__ __forceinline__ void stage_dout_dma(char* lds, const T* __restrict__ g, const ConvArgs& a, int n, int oz0, int oy0,

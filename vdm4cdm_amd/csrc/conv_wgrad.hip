@@ -222,14 +222,100 @@ __global__ void __launch_bounds__(256, 2) conv_wgrad_kernel(const WgradArgs w) {
 // oz = hz - dz multiplies the dOut fragment of rows (2j, 2j + 1) with the register pair (row 2j + dy, row 2j + dy + 1).  The dOut fragments
 // of the whole tile stay in registers (TZ * TY / 2 fragments).  Per 2 x 8 x 16 tile and wave: 120 + 16 reads for 216 MFMAs (0.63 reads per MFMA
 // instead of 1.14).  Same slab layout as conv_wgrad_kernel, same reduce kernels; the summation order per output differs (halo-slab-major).
-template <typename T, int TZ, int TY>
+// ROLL (rolling z window): a persistent workgroup walks up a column of tiles (fixed n, y, x; z ascending) and the input image is a ring of
+// HZ = TZ + 2 slice slots: a step stages only its TZ NEW slices (the top two of the previous step are the bottom two of this one) - 39 KB and
+// 56 LDS-DMA instructions per 2 x 8 x 16 step instead of 62 KB and 96 (the phase stamps of tools/wgrad_phases.py: issuing the DMAs of a tile
+// takes as long as its 216 MFMAs per wave, and a leftover-voxel DMA of 128 B costs a wave as much as a 1-KiB one).  Halo slab hz of step r
+// lives in slot (TZ r + hz) mod HZ: with TZ = 2 the mapping has period two, so the step body exists twice (PAR = r & 1), all LDS addresses
+// still immediates.
+template <int V> struct IntC { static constexpr int value = V; };
+// Register tuples.  An MFMA operand is four CONSECUTIVE registers = two rows.  Pairing the output rows as (2j, 2j + 1) for every dy makes the
+// B operand of dy = 1 the rows (2j + 1, 2j + 2) - overlapping the tuples of dy = 0 / 2, and the compiler assembles overlapping tuples with
+// copies (measured: ~1.5 v_mov per MFMA, issued right in front of the MFMA that reads them; one wave per SIMD then needs 2.4 us for its
+// 216 MFMAs instead of 1.65).  So dy = 1 pairs the OUTPUT rows as (2m + 1, 2m + 2), m = 0 .. TY/2 - 2: their halo rows (2m + 2, 2m + 3) are
+// again an even pair, and the two left-over output rows (0, TY - 1) form one more k-step whose halo rows (1, TY) get a tuple of their own
+// (read a second time).  All B tuples are then the disjoint even pairs P_p = rows (2p, 2p + 1), p = 0 .. TY/2, used by (dy 0, j = p),
+// (dy 2, j = p - 1), (dy 1, m = p - 1) - and a pair is refilled for the next group right behind its last MFMA (no double buffer).  The dOut
+// fragments exist in the three pairings (TZ x (TY/2 + TY/2 - 1 + 1) fragments, resident).  Per tile and wave: 144 + 32 transposed reads for
+// 216 MFMAs (0.81 per MFMA; conv_wgrad_kernel: 1.14).
+template <typename T, int TZ, int TY, int PAR>
+__device__ __forceinline__ void wgrad_rows_step(f32x4 (&acc)[27], f32x4& accb, bool bias, const char* lds_in, const char* lds_do,
+                                                const int (&lo_a)[1], const int (&lo_b)[3][1]) {
+    using G = Geo<3, 1, TZ, TY>;
+    using TF = TrFetch<T>;
+    constexpr int NJ = TY / 2, NP = NJ + 1, NG = G::HZ * 3, R = G::HZ, ROWB = G::HX * 64;
+    auto pair_of = [&](int grp, int p) {                    // halo rows (2p, 2p + 1) of (halo slab, dx) = grp
+        const int hz = grp / 3, dx = grp % 3;
+        return TF::template get<ROWB>(lds_in, lo_b[dx], (((TZ * PAR + hz) % R) * G::HY + 2 * p) * ROWB);
+    };
+    // (the wrap rows are also halves of P_0 and P_NJ: through laundered copies of the lane offsets the compiler cannot merge the reads -
+    //  it would replace the second read by register copies into the wrap tuple)
+    int lo_w[3][1];
+#pragma unroll
+    for (int dx = 0; dx < 3; ++dx) {
+        lo_w[dx][0] = lo_b[dx][0];
+        asm volatile("" : "+v"(lo_w[dx][0]));
+    }
+    auto wrap_of = [&](int grp) {                           // halo rows (1, TY)
+        const int hz = grp / 3, dx = grp % 3;
+        return TF::template get<(TY - 1) * ROWB>(lds_in, lo_w[dx], (((TZ * PAR + hz) % R) * G::HY + 1) * ROWB);
+    };
+    uint4 ae[TZ][NJ], ao[TZ][NJ - 1], aw[TZ];              // dOut rows (2j, 2j + 1) | (2m + 1, 2m + 2) | (0, TY - 1)
+#pragma unroll
+    for (int oz = 0; oz < TZ; ++oz) {
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) ae[oz][j] = TF::template get<1024>(lds_do, lo_a, (oz * TY + 2 * j) * 1024);
+#pragma unroll
+        for (int m = 0; m < NJ - 1; ++m) ao[oz][m] = TF::template get<1024>(lds_do, lo_a, (oz * TY + 2 * m + 1) * 1024);
+        aw[oz] = TF::template get<(TY - 1) * 1024>(lds_do, lo_a, oz * TY * 1024);
+    }
+    uint4 bp[NP], bw;
+#pragma unroll
+    for (int p = 0; p < NP; ++p) bp[p] = pair_of(0, p);
+    bw = wrap_of(0);
+    if (bias) {          // bias gradient = column sums of the dOut tile: dOut^T x ones on the matrix pipe (every result column holds the sum)
+        const uint4 ones = make_uint4(0x3f803f80u, 0x3f803f80u, 0x3f803f80u, 0x3f803f80u);      // bf16 1.0 pairs
+#pragma unroll
+        for (int oz = 0; oz < TZ; ++oz)
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) mma16_act<T>(accb, ae[oz][j], ones);
+    }
+#pragma unroll
+    for (int grp = 0; grp < NG; ++grp) {
+        const int hz = grp / 3, dx = grp % 3;
+#pragma unroll
+        for (int p = 0; p <= NP; ++p) {                     // p == NP: the wrap k-step
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int dz = 0; dz < 3; ++dz) {
+                const int oz = hz - dz;
+                if (oz < 0 || oz >= TZ) continue;
+                const int t = dz * 9 + dx;                  // tap index = (dz * 3 + dy) * 3 + dx
+                if (p == NP) {
+                    mma16_act<T>(acc[t + 3], aw[oz], bw);
+                } else {
+                    if (p < NJ) mma16_act<T>(acc[t], ae[oz][p], bp[p]);                         // dy = 0, j = p
+                    if (p >= 1 && p <= NJ - 1) mma16_act<T>(acc[t + 3], ao[oz][p - 1], bp[p]);  // dy = 1, m = p - 1
+                    if (p >= 1) mma16_act<T>(acc[t + 6], ae[oz][p - 1], bp[p]);                 // dy = 2, j = p - 1
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            if (grp + 1 < NG) {                             // the tuple is dead: the next group's rows take its place
+                if (p == NP) bw = wrap_of(grp + 1);
+                else bp[p] = pair_of(grp + 1, p);
+            }
+        }
+    }
+}
+
+template <typename T, int TZ, int TY, bool ROLL>
 __global__ void __launch_bounds__(256, 2) conv_wgrad_rows_kernel(const WgradArgs w) {
     using G = Geo<3, 1, TZ, TY>;
     using TF = TrFetch<T>;
     static_assert(sizeof(T) == 2 && (TY % 2) == 0, "bf16 only: a fragment = two rows of the same z-slab");
+    static_assert(!ROLL || TZ == 2, "the ring mapping has period two for TZ = 2");
     constexpr int IN_BYTES = ((G::HVOX + 15) / 16) * 1024;
-    constexpr int NJ = TY / 2, NR = TY + 2, NG = G::HZ * 3, CL = 32;
-    typedef __attribute__((address_space(3))) s16x4* lptr;
+    constexpr int CL = 32, R = G::HZ;
     extern __shared__ __attribute__((aligned(16))) char lds[];
     char* lds_in = lds;
     char* lds_do = lds + IN_BYTES;
@@ -252,89 +338,68 @@ __global__ void __launch_bounds__(256, 2) conv_wgrad_rows_kernel(const WgradArgs
 
     const T* x = reinterpret_cast<const T*>(a.x);
     const T* g = reinterpret_cast<const T*>(w.dout);
-    float bsum[DT<T>::EPL];
-#pragma unroll
-    for (int j = 0; j < DT<T>::EPL; ++j) bsum[j] = 0.f;
-
-    auto rows_of = [&](uint2 (&dst)[NR], int grp) {         // the TY + 2 halo rows of (halo slab, dx) = grp
-        const int hz = grp / 3, dx = grp % 3;
-#pragma unroll
-        for (int r = 0; r < NR; ++r)
-            dst[r] = __builtin_bit_cast(uint2, __builtin_amdgcn_ds_read_tr16_b64_v4i16((lptr)(lds_in + (hz * G::HY + r) * G::HX * 64 + lo_b[dx][0])));
-    };
-
+    f32x4 accb = f32x4{0.f, 0.f, 0.f, 0.f};                 // bias gradient of this wave's 16 couts (waves with cin tile 0 of cin block 0)
+    const bool bias = w.bslabs != nullptr && kb == 0 && jb == 0;
     WG_TL_DECL;
-    for (int tile = pidx; tile < w.ntiles; tile += w.P) {
-        int tx, ty, tz, n, rest_;
-        decode_tile(a, (uint32_t)tile, tx, ty, tz, n, rest_);
-        const int oz0 = tz * TZ, oy0 = ty * TY, ox0 = tx * 16;
-        __syncthreads();                                   // every wave is done reading the previous tile
-        WG_TL(0);
-        stage_halo_dma<T, G, 0>(lds_in, x, a, n, oz0, oy0, ox0, kb, wave, lane);
-        stage_dout_dma<T, G>(lds_do, g, a, n, oz0, oy0, ox0, cb, w.dout_stride, wave, lane);
-        WG_TL(1);
-        __syncthreads();                                   // (drains the LDS-DMA: vmcnt(0) + barrier)
-        WG_TL(2);
-        uint4 af[TZ][NJ];
-#pragma unroll
-        for (int oz = 0; oz < TZ; ++oz)
-#pragma unroll
-            for (int j = 0; j < NJ; ++j) af[oz][j] = TF::template get<1024>(lds_do, lo_a, (oz * TY + 2 * j) * 1024);
-        uint2 rowsA[NR], rowsB[NR];
-        rows_of(rowsA, 0);
-#pragma unroll
-        for (int grp = 0; grp < NG; ++grp) {
-            uint2 (&cur)[NR] = (grp & 1) ? rowsB : rowsA;
-            uint2 (&nxt)[NR] = (grp & 1) ? rowsA : rowsB;
-            if (grp + 1 < NG) rows_of(nxt, grp + 1);        // in flight behind this group's MFMAs
-            __builtin_amdgcn_sched_barrier(0);
-            const int hz = grp / 3, dx = grp % 3;
-#pragma unroll
-            for (int j = 0; j < NJ; ++j)
-#pragma unroll
-                for (int dz = 0; dz < 3; ++dz) {
-                    const int oz = hz - dz;
-                    if (oz < 0 || oz >= TZ) continue;
-#pragma unroll
-                    for (int dy = 0; dy < 3; ++dy) {
-                        const uint2 r0 = cur[2 * j + dy], r1 = cur[2 * j + dy + 1];
-                        mma16_act<T>(acc[(dz * 3 + dy) * 3 + dx], af[oz][j], make_uint4(r0.x, r0.y, r1.x, r1.y));
-                    }
+    if constexpr (ROLL) {
+        // w.ntiles = column segments (n, ty, tx, seg); a.fdz divides by a.nseg
+        for (int cs = pidx; cs < w.ntiles; cs += w.P) {
+            uint32_t b = (uint32_t)cs;
+            uint32_t q = fdiv(b, a.fdx);
+            const int tx = (int)(b - q * (uint32_t)a.ntx); b = q;
+            q = fdiv(b, a.fdy);
+            const int ty = (int)(b - q * (uint32_t)a.nty); b = q;
+            q = fdiv(b, a.fdz);
+            const int seg = (int)(b - q * (uint32_t)a.nseg);
+            const int n = (int)q;
+            const int zs0 = seg * a.zsteps, zs1 = min(a.ntz, zs0 + a.zsteps);
+            const int oy0 = ty * TY, ox0 = tx * 16;
+            const RowStager<T, G, 0> st(x, a, n, 0, oy0, ox0, kb, lane, 1, 0, 0, 0, a.Sz, a.Sy, a.Sx);      // (iz0 = -1; x part once per column)
+            // slices are addressed by their position p = iz + 1 - TZ zs0 >= 0 in the walk; slot = p mod R
+            auto step = [&](int s, auto parc) {
+                const int rel = s - zs0;
+                const int p0 = rel == 0 ? 0 : TZ * rel + (R - TZ), cnt = rel == 0 ? R : TZ;
+                __syncthreads();                           // every wave is done reading the previous step
+                WG_TL(0);
+                for (int r = wave; r < cnt * G::HY; r += 4) {
+                    const int sl = r / G::HY, hy = r % G::HY, p = p0 + sl;
+                    st.row(lds_in + ((p % R) * G::HY + hy) * (G::HX * 64), a, TZ * zs0 + p, hy);
                 }
-            __builtin_amdgcn_sched_barrier(0);
-        }
-        WG_TL(3);
-        // bias gradient: column sums of this dOut tile (see conv_wgrad_kernel)
-        if (w.bslabs != nullptr && kb == 0) {
-            const int vx = lane >> 2, sl = lane & 3;
-#pragma unroll
-            for (int r = wave; r < G::ROWS; r += 4) {
-                Piece<T> pz;
-                pz.load(*reinterpret_cast<const uint4*>(lds_do + r * 1024 + vx * 64 + sl * 16));
-#pragma unroll
-                for (int j = 0; j < DT<T>::EPL; ++j) bsum[j] += pz.f[j];
+                stage_dout_dma<T, G>(lds_do, g, a, n, s * TZ, oy0, ox0, cb, w.dout_stride, wave, lane);
+                WG_TL(1);
+                __syncthreads();                           // (drains the LDS-DMA: vmcnt(0) + barrier)
+                WG_TL(2);
+                wgrad_rows_step<T, TZ, TY, decltype(parc)::value>(acc, accb, bias, lds_in, lds_do, lo_a, lo_b);
+                WG_TL(3);
+            };
+            // (two steps per iteration: the slot mapping has period two.  Staging step s + 1 from inside step s - its new slices go to slots
+            //  that are free after the first half of the groups - was built and measured: the DMAs issued between the MFMA groups block the
+            //  wave for ~0.28 us each, the step got longer: 6.7 us against 1.7 + 0.6 + 3.3 us)
+            for (int s = zs0; s < zs1; s += 2) {
+                step(s, IntC<0>());
+                if (s + 1 < zs1) step(s + 1, IntC<1>());
             }
         }
-        WG_TL(4);
+    } else {
+        for (int tile = pidx; tile < w.ntiles; tile += w.P) {
+            int tx, ty, tz, n, rest_;
+            decode_tile(a, (uint32_t)tile, tx, ty, tz, n, rest_);
+            const int oz0 = tz * TZ, oy0 = ty * TY, ox0 = tx * 16;
+            __syncthreads();                               // every wave is done reading the previous tile
+            WG_TL(0);
+            stage_halo_dma<T, G, 0>(lds_in, x, a, n, oz0, oy0, ox0, kb, wave, lane);
+            stage_dout_dma<T, G>(lds_do, g, a, n, oz0, oy0, ox0, cb, w.dout_stride, wave, lane);
+            WG_TL(1);
+            __syncthreads();                               // (drains the LDS-DMA: vmcnt(0) + barrier)
+            WG_TL(2);
+            wgrad_rows_step<T, TZ, TY, 0>(acc, accb, bias, lds_in, lds_do, lo_a, lo_b);
+            WG_TL(3);
+        }
     }
 
-    if (w.bslabs != nullptr && kb == 0) {                  // workgroup-uniform condition
-        float* shb = reinterpret_cast<float*>(lds);
-        constexpr int EPLc = DT<T>::EPL;
-        __syncthreads();
+    if (bias && (lane & 15) == 0) {                         // (result column 0: rows = couts ia * 16 + 4 (lane >> 4) ...)
 #pragma unroll
-        for (int j = 0; j < EPLc; ++j) shb[tid * EPLc + j] = bsum[j];
-        __syncthreads();
-        if (tid < CL) {
-            const int piece = tid / EPLc, j = tid % EPLc;
-            float tot = 0.f;
-            for (int wv = 0; wv < 4; ++wv)
-                for (int vx = 0; vx < 16; ++vx) {
-                    const int ln = vx * 4 + (piece ^ ((vx >> 1) & 3));
-                    tot += shb[(wv * 64 + ln) * EPLc + j];
-                }
-            w.bslabs[((size_t)cb * w.P + pidx) * CL + tid] = tot;
-        }
+        for (int rg = 0; rg < 4; ++rg) w.bslabs[((size_t)cb * w.P + pidx) * CL + ia * 16 + (lane >> 4) * 4 + rg] = accb[rg];
     }
     // ---- this wave's 16 x 16 tile of every tap: slab[tap][co_local][ci_local] ---------------------
     float* slab = w.slabs + (size_t)(pair * w.P + pidx) * (27 * CL * CL);
@@ -498,11 +563,31 @@ static int launch_wgrad_cfg(WgradArgs w, float* dw, float* dbias, int accumulate
     bool launched = false;
     if constexpr (sizeof(T) == 2 && KS == 3 && STRIDE == 1 && UPS == 0 && NTA == 2 && NTB == 2) {
         if (wgrad_rows_enabled()) {
-            auto kern = conv_wgrad_rows_kernel<T, TZ, TY>;
-            static unsigned long long lds_done_rows = 0;
-            int e = set_lds(kern, lds, lds_done_rows);
-            if (e) return e;
-            hipLaunchKernelGGL(kern, dim3(npairs * P), dim3(256), lds, s, w);
+            // rolling z window (VDM4CDM_WGRAD_ROLL=0: off): the persistent workgroups walk column segments instead of scattered tiles
+            static const bool roll_on = [] { const char* e = getenv("VDM4CDM_WGRAD_ROLL"); return e == nullptr || atoi(e) != 0; }();
+            const int ncols = a.N * a.nty * a.ntx;
+            int nseg = roll_on && TZ == 2 ? P / ncols : 0;               // P = the workgroups this pair may use (slab space is sized for it)
+            if (nseg > a.ntz / 2) nseg = a.ntz / 2;                      // >= 2 steps per segment, or the walk saves nothing
+            if (nseg >= 1 || (roll_on && TZ == 2 && a.ntz >= 4)) {
+                if (nseg < 1) nseg = 1;                                  // more columns than workgroups: a workgroup walks several
+                a.zsteps = cdiv(a.ntz, nseg);
+                a.nseg = cdiv(a.ntz, a.zsteps);
+                a.fdz = make_fastdiv((uint32_t)a.nseg);
+                w.ntiles = ncols * a.nseg;
+                if (P > w.ntiles) P = w.ntiles;
+                w.P = P;
+                auto kern = conv_wgrad_rows_kernel<T, TZ, TY, (TZ == 2)>;
+                static unsigned long long lds_done_roll = 0;
+                int e = set_lds(kern, lds, lds_done_roll);
+                if (e) return e;
+                hipLaunchKernelGGL(kern, dim3(npairs * P), dim3(256), lds, s, w);
+            } else {
+                auto kern = conv_wgrad_rows_kernel<T, TZ, TY, false>;
+                static unsigned long long lds_done_rows = 0;
+                int e = set_lds(kern, lds, lds_done_rows);
+                if (e) return e;
+                hipLaunchKernelGGL(kern, dim3(npairs * P), dim3(256), lds, s, w);
+            }
             launched = true;
         }
     }
@@ -578,7 +663,14 @@ template <typename T>
 static int launch_wgrad(const WgradArgs& w, float* dw, float* db, int acc, int cout, int cin, int ks, int stride, int ups, size_t ws,
                         hipStream_t s) {
     if (ks == 1) return launch_wgrad_cfg<T, 1, 1, 0, 4, 8>(w, dw, db, acc, cout, cin, ws, s);
-    if (stride == 2) return launch_wgrad_cfg<T, 3, 2, 0, 2, 4>(w, dw, db, acc, cout, cin, ws, s);
+    if (stride == 2) {
+        // 1x4x16 output tiles (57-KB halo, two workgroups per CU; default since round 4: alone 0.100 -> 0.091 / 0.060 -> 0.048 / 0.038 ->
+        // 0.034 ms at levels 0 / 1 / 2, step unchanged).  VDM4CDM_S2W_TZ=2: 2x4x16 tiles (95-KB halo, -17 % staged bytes, one workgroup per
+        // CU - and none next to a main-stream kernel that holds 2 x 70 KB of the CU's LDS)
+        static const int tz = [] { const char* e = getenv("VDM4CDM_S2W_TZ"); return e ? atoi(e) : 1; }();
+        if (tz == 1) return launch_wgrad_cfg<T, 3, 2, 0, 1, 4>(w, dw, db, acc, cout, cin, ws, s);
+        return launch_wgrad_cfg<T, 3, 2, 0, 2, 4>(w, dw, db, acc, cout, cin, ws, s);
+    }
     if (ups) return launch_wgrad_cls<T, 2, 8, 512>(w, dw, db, acc, cout, cin, ws, s);      // (2x4x16 tiles with 1024 workgroups: same time)
     if constexpr (sizeof(T) == 2) {                          // 64-byte blocks with a single real 16-channel tile
         if (cin <= 16) return launch_wgrad_cfg<T, 3, 1, 0, 2, 8, 2, 1>(w, dw, db, acc, cout, cin, ws, s);

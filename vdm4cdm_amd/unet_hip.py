@@ -23,8 +23,10 @@ GNB_MIN_K = int(os.environ.get("VDM4CDM_GNB_MIN_K", "0"))      # fold only into 
 # the 1x1x1 skip conv of a ResNetBlock rides along with norm1's GroupNorm passes where csrc/gn_skip.hip has a kernel (bf16, narrow layers)
 FUSED_SKIP = os.environ.get("VDM4CDM_FUSED_SKIP", "1") != "0"
 # input gradient (+ folded GroupNorm backward) and weight gradient of a 32 -> 32 conv as ONE launch that stages the gradient once
-# (csrc/conv_dgw.hip; the level-0 convs of the 128^3 network).  VDM4CDM_FUSED_DGW=0: the two separate kernels (A/B)
-FUSED_DGW = os.environ.get("VDM4CDM_FUSED_DGW", "1") != "0"
+# (csrc/conv_dgw.hip; the level-0 convs of the 128^3 network).  Opt-in (VDM4CDM_FUSED_DGW=1) since the stand-alone weight-gradient kernel
+# got its rolling z window and copy-free operand tuples: alone 0.55 ms fused against 0.345 + 0.213 ms separately, training step 12.23 fused
+# against 12.02 ms separate (same box, alternating)
+FUSED_DGW = os.environ.get("VDM4CDM_FUSED_DGW", "0") == "1"
 # inference: norm2's GroupNorm + SiLU applied inside conv2 (to the staged halo image) instead of by a pass of its own.  Measured: the
 # VALU work on the 2.1x halo costs the conv what the 5 TB/s pass cost - off by default
 # "0" (default): nowhere; "deep": only at the levels of <= 32^3 voxels; "1": everywhere.  Round 4, same box, 300 sampling steps at 128^3:
