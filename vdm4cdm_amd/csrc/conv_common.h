@@ -894,6 +894,10 @@ __device__ __forceinline__ void st_sub(T* p, const float (&f)[SUB]) {
 // after it (NC = 4: the operand registers of the tap loop are free by then).
 // The second sum is taken against the RAW x (S2raw = sum dyh * x); vdm_gn_bwd_finalize converts the tile totals,
 // sum dyh * xhat = rstd * (S2raw - mean * S1), so the inner loop needs neither xhat nor the per-group constants.
+#ifndef VDM_GNB_PACKED
+#define VDM_GNB_PACKED 1
+#endif
+typedef float f32x2 __attribute__((ext_vector_type(2)));
 template <typename T, int NC, int NV>
 struct GnbRegs {
     static constexpr int EPL = DT<T>::EPL;
@@ -967,15 +971,49 @@ __device__ __forceinline__ void gnb_issue_consts(GnbRegs<T, NC, NV>& r, const Gn
     }
 }
 
-// everything up front (NC <= 2, before the tap loop)
-template <typename T, typename G, int NC, int NV>
+// The same constants ONCE per workgroup: thread t < 64 evaluates channel cout0 + t into an LDS table (the lanes of a workgroup cover at most
+// 64 channels: index q * qstride + j), the lanes read their NC * 4 pairs back behind the workgroup's next barrier.  gnb_issue_consts costs
+// every lane ~40 instructions per channel (two exact divisions, the group index by integer division, rsqrt): 640 per lane at NC = 4 - as
+// many as the element-wise epilogue itself.  (Same arithmetic: bit-identical constants.)
+constexpr int GNB_TABLE_BYTES = 64 * 2 * 4;
+__device__ __forceinline__ void gnb_consts_table(float* tab, const ConvArgs& a, int n, int cout0, int tid) {
+    if (tid < 64) {
+        const int c = cout0 + tid;
+        float A2 = 0.f, B2 = 0.f;
+        if (c < a.Cout) {
+            const int gs = a.Cout / a.gG;
+            const int g = c / gs;
+            const float sum = a.gstats[((size_t)n * a.gG + g) * 2], sq = a.gstats[((size_t)n * a.gG + g) * 2 + 1];
+            const float mean = sum / a.gcnt;
+            const float var = fmaxf(sq / a.gcnt - mean * mean, 0.f);
+            const float rstd = rsqrtf(var + a.geps);
+            const float A = rstd * a.ggamma[c];
+            A2 = -1.44269504089f * A;
+            B2 = -1.44269504089f * (a.gbeta[c] - mean * A);
+        }
+        tab[2 * tid] = A2;
+        tab[2 * tid + 1] = B2;
+    }
+}
+template <typename T, int NC, int NV>
+__device__ __forceinline__ void gnb_consts_read(GnbRegs<T, NC, NV>& r, const float* tab, int lane, int qstride) {
+    const float* t = tab + 2 * ((lane >> 4) * qstride);
+#pragma unroll
+    for (int j = 0; j < NC * 4; j += 2) {
+        const float4 v = *reinterpret_cast<const float4*>(t + 2 * j);
+        r.A[j] = v.x; r.B[j] = v.y; r.A[j + 1] = v.z; r.B[j + 1] = v.w;
+    }
+}
+
+// everything up front (NC <= 2, before the tap loop); ctab != nullptr: the constants come from the workgroup's table (gnb_consts_read, later)
+template <typename T, typename G, int NC, int NV, bool TABLED = false>
 __device__ __forceinline__ void gnb_issue(GnbRegs<T, NC, NV>& r, const ConvArgs& a, int n, int oz0, int oy0, int ox0, int cwave, int lane,
                                           int cout0, int qstride) {
     const GnbLane<T, NC, NV> L(a, n, lane, cout0, qstride);
     const RowMap<G, NV> rm(a, oz0, oy0, ox0, cwave, lane);
 #pragma unroll
     for (int v = 0; v < NV; ++v) gnb_issue_row<T, G, NC, NV>(r, L, rm, a, n, v);
-    gnb_issue_consts<T, NC, NV>(r, L, a, n);
+    if constexpr (!TABLED) gnb_issue_consts<T, NC, NV>(r, L, a, n);
 }
 
 template <typename T, int SUB, int XQ>
@@ -998,10 +1036,10 @@ __device__ __forceinline__ void raw_unpack(const uint4 (&q)[XQ], float (&f)[SUB]
 
 // PREFETCHED: gnb_issue() already ran (before the tap loop).  Otherwise the rows are fetched here through a rolling window of PD
 // rows (the lane's accumulators die row by row, which makes room for the x pieces still in flight).
-template <typename T, typename G, int NC, int NV, bool PREFETCHED>
+template <typename T, typename G, int NC, int NV, bool PREFETCHED, bool TABLED = false>
 __device__ __forceinline__ void conv_epilogue_gnb(const f32x4 (&acc)[NV][NC], const ConvArgs& a, GnbRegs<T, NC, NV>& r, int n,
                                                   int oz0, int oy0, int ox0, int cwave, int lane, float* gn_sm, int tile, int cout0,
-                                                  int qstride) {
+                                                  int qstride, const float* ctab = nullptr) {
     using R = GnbRegs<T, NC, NV>;
     constexpr int EPL = R::EPL, CH = R::CH, SUB = R::SUB, NSUB = R::NSUB;
     constexpr int PD = NV < 3 ? NV : 3;                    // (4 rows in flight spill the NC = 4, 4x8x16 kernel)
@@ -1013,11 +1051,15 @@ __device__ __forceinline__ void conv_epilogue_gnb(const f32x4 (&acc)[NV][NC], co
     if constexpr (!PREFETCHED) {
 #pragma unroll
         for (int v = 0; v < PD; ++v) gnb_issue_row<T, G, NC, NV>(r, L, rm, a, n, v);
-        gnb_issue_consts<T, NC, NV>(r, L, a, n);
+        if constexpr (!TABLED) gnb_issue_consts<T, NC, NV>(r, L, a, n);
     }
+    if constexpr (TABLED) gnb_consts_read<T, NC, NV>(r, ctab, lane, qstride);
     float gsum[CH], gsq[CH];                               // S1 = sum dyh, S2raw = sum dyh * x
 #pragma unroll
     for (int j = 0; j < CH; ++j) gsum[j] = gsq[j] = 0.f;
+    f32x2 gs2[CH / 2], gq2[CH / 2];                        // (the same sums as channel pairs: bf16 path)
+#pragma unroll
+    for (int j = 0; j < CH / 2; ++j) gs2[j] = gq2[j] = f32x2{0.f, 0.f};
     const bool lane_ok = cbase + CH <= C;                  // (host: C % (NC*4) == 0 and no lane straddles c1)
     T* out = reinterpret_cast<T*>(a.out) + (size_t)n * ((size_t)a.Dz * a.Dy * a.Dx * C);
 #pragma unroll
@@ -1028,6 +1070,41 @@ __device__ __forceinline__ void conv_epilogue_gnb(const f32x4 (&acc)[NV][NC], co
         if (!rm.ok(a, v) || !lane_ok) continue;
         const unsigned vox = rm.vox(a, v);
         const uint32_t mb = r.mb[v];
+        if constexpr (sizeof(T) == 2 && VDM_GNB_PACKED) {
+            // bf16 storage: explicit channel PAIRS (2i, 2i + 1) - one dword of x, two adjacent accumulator registers, one dword of dyh - so that
+            // every arithmetic step is one packed instruction on registers that are already adjacent (the auto-vectorised scalar form paired
+            // channels (0, 2), (1, 3) of the unpacked words and re-paired them with ~6 v_mov per pair: 5.2 k instructions per tile at NC = 4,
+            // as many issue cycles as the 864 MFMAs); keep factor as sign-extended bit AND 1/(1-p): 2 instead of 3 instructions
+            const uint32_t ikb = __builtin_bit_cast(uint32_t, a.ginv_keep);
+            const uint32_t mbs = CH >= EPL ? mb : (mb >> ((unsigned)cbase % EPL));
+#pragma unroll
+            for (int sc = 0; sc < NSUB; ++sc) {
+                const uint32_t w[4] = {r.x[v][sc][0].x, r.x[v][sc][0].y, r.x[v][sc][0].z, r.x[v][sc][0].w};
+                uint32_t ow[SUB / 2];
+#pragma unroll
+                for (int i = 0; i < SUB / 2; ++i) {
+                    const int jj = sc * SUB + 2 * i;        // channels jj, jj + 1 of the lane: accumulator (jj / 4, jj % 4), (jj / 4, jj % 4 + 1)
+                    const f32x2 xv = {__builtin_bit_cast(float, w[i] << 16), __builtin_bit_cast(float, w[i] & 0xffff0000u)};
+                    const f32x2 A2 = {r.A[jj], r.A[jj + 1]}, B2 = {r.B[jj], r.B[jj + 1]};
+                    const f32x2 yl = xv * A2 + B2;
+                    const f32x2 e1 = f32x2{__builtin_amdgcn_exp2f(yl.x), __builtin_amdgcn_exp2f(yl.y)} + 1.0f;
+                    const f32x2 sg = {__builtin_amdgcn_rcpf(e1.x), __builtin_amdgcn_rcpf(e1.y)};
+                    const f32x2 ds = sg * ((yl * -0.69314718056f) * (1.0f - sg) + 1.0f);      // silu'(y) = s (1 + y (1 - s))
+                    const int bit = CH >= EPL ? (jj / EPL) * 8 + jj % EPL : jj;
+                    const f32x2 keep = {__builtin_bit_cast(float, (uint32_t)__builtin_amdgcn_sbfe((int)mbs, bit, 1) & ikb),
+                                        __builtin_bit_cast(float, (uint32_t)__builtin_amdgcn_sbfe((int)mbs, bit + 1, 1) & ikb)};
+                    const f32x2 ac = {acc[v][jj >> 2][jj & 3], acc[v][jj >> 2][(jj & 3) + 1]};
+                    const f32x2 dd = ac * (ds * keep);
+                    gs2[jj / 2] += dd;
+                    gq2[jj / 2] = dd * xv + gq2[jj / 2];
+                    ow[i] = pack_bf16x2(dd.x, dd.y);
+                }
+                T* po = out + (vox * (unsigned)C + (unsigned)(cbase + sc * SUB));
+                if constexpr (SUB == 8) *reinterpret_cast<uint4*>(po) = make_uint4(ow[0], ow[1], ow[2], ow[3]);
+                else *reinterpret_cast<uint2*>(po) = make_uint2(ow[0], ow[1]);
+            }
+            continue;
+        }
 #pragma unroll
         for (int sc = 0; sc < NSUB; ++sc) {
             float xv[SUB], d[SUB];
@@ -1046,6 +1123,13 @@ __device__ __forceinline__ void conv_epilogue_gnb(const f32x4 (&acc)[NV][NC], co
                 gsq[jj] = fmaf(dd, xv[j], gsq[jj]);
             }
             st_sub<T, SUB>(out + (vox * (unsigned)C + (unsigned)(cbase + sc * SUB)), d);
+        }
+    }
+    if constexpr (sizeof(T) == 2 && VDM_GNB_PACKED) {
+#pragma unroll
+        for (int j = 0; j < CH / 2; ++j) {
+            gsum[2 * j] = gs2[j].x; gsum[2 * j + 1] = gs2[j].y;
+            gsq[2 * j] = gq2[j].x; gsq[2 * j + 1] = gq2[j].y;
         }
     }
     gn_partials_reduce<NC, G::NW>(gsum, gsq, gn_sm, a.gnp + ((size_t)n * (a.ntz * a.nty * a.ntx) + tile) * a.Cout * 2, cout0, a.Cout, cwave,

@@ -60,7 +60,9 @@ __global__ void __launch_bounds__(64 * NW, NW == 8 ? 4 : ((TZ * TY <= 16 && NC <
     const int e_cout0 = SPLIT ? (chunk >> 1) * 64 + (chunk & 1) * 8 : chunk * NC * 16, e_qstride = SPLIT ? 16 : NC * 4;
     GnbRegs<T, NC, GNB ? NV : 1> gr;
     constexpr bool GNB_PRE = GNB && NC <= 2 && NW == 4;      // (eight-wave workgroups: 128 registers per wave, the rolling window instead)
-    if constexpr (GNB_PRE) gnb_issue<T, G, NC, NV>(gr, a, n, oz0, oy0, ox0, wave, lane, e_cout0, e_qstride);
+    float* gnb_tab = reinterpret_cast<float*>(lds + ((G::HVOX + 15) / 16) * 1024 + GN_SCRATCH_BYTES);      // (behind the GN scratch; read after the first barrier)
+    if constexpr (GNB) gnb_consts_table(gnb_tab, a, n, e_cout0, tid);
+    if constexpr (GNB_PRE) gnb_issue<T, G, NC, NV, true>(gr, a, n, oz0, oy0, ox0, wave, lane, e_cout0, e_qstride);
     float badd[NC * 4];                                      // bias + conditioning bias of the lane's channels (latency hidden behind the taps)
     if constexpr (!GNB) load_badd<NC>(badd, a, n, e_cout0 + (lane >> 4) * e_qstride);
 
@@ -110,7 +112,7 @@ __global__ void __launch_bounds__(64 * NW, NW == 8 ? 4 : ((TZ * TY <= 16 && NC <
     const int tile = (tz * a.nty + ty) * a.ntx + tx;
     if constexpr (GNB) {
         static_assert(sizeof(T) == sizeof(TO), "the folded GroupNorm backward stores dyh in the activation dtype");
-        conv_epilogue_gnb<T, G, NC, NV, GNB_PRE>(acc, a, gr, n, oz0, oy0, ox0, wave, lane, gn_sm, tile, e_cout0, e_qstride);
+        conv_epilogue_gnb<T, G, NC, NV, GNB_PRE, true>(acc, a, gr, n, oz0, oy0, ox0, wave, lane, gn_sm, tile, e_cout0, e_qstride, gnb_tab);
     } else
         conv_epilogue<T, TO, G, NC, NV>(acc, a, badd, n, oz0, oy0, ox0, wave, lane, gn_sm, tile, e_cout0, e_qstride);
 #ifdef VDM_TIMELINE
@@ -171,6 +173,8 @@ __global__ void __launch_bounds__(256, 2) conv_roll_kernel(const ConvArgs a) {
     // the per-lane x part of the staging is the same for every step of the column
     const RowStager<T, G, 0> st(x, a, n, 0, oy0, ox0, 0, lane, 1, 0, 0, 0, a.Sz, a.Sy, a.Sx);
     float* gn_sm = reinterpret_cast<float*>(lds + R * SLICE);
+    float* gnb_tab = reinterpret_cast<float*>(lds + R * SLICE + GN_SCRATCH_BYTES);
+    if constexpr (GNB) gnb_consts_table(gnb_tab, a, n, e_cout0, tid);     // (one sample, one chunk per column: once; read behind the first barrier)
     constexpr int WPD = WPipe<NC>::WPD;
 
     // slices are addressed by their position p = iz + 1 - 4 zs0 >= 0 in the column walk; slot = p mod 6
@@ -207,7 +211,7 @@ __global__ void __launch_bounds__(256, 2) conv_roll_kernel(const ConvArgs a) {
         }
         const int tile = (s * a.nty + ty) * a.ntx + tx;
         if constexpr (GNB)
-            conv_epilogue_gnb<T, G, NC, NV, false>(acc, a, gr, n, oz0, oy0, ox0, wave, lane, gn_sm, tile, e_cout0, e_qstride);
+            conv_epilogue_gnb<T, G, NC, NV, false, true>(acc, a, gr, n, oz0, oy0, ox0, wave, lane, gn_sm, tile, e_cout0, e_qstride, gnb_tab);
         else
             conv_epilogue<T, T, G, NC, NV>(acc, a, badd, n, oz0, oy0, ox0, wave, lane, gn_sm, tile, e_cout0, e_qstride);
     }
@@ -411,7 +415,7 @@ static int launch_fwd_cfg(const ConvArgs& a0, hipStream_t s) {
     a.ntz = cdiv(a.Dz, TZ); a.nty = cdiv(a.Dy, TY); a.ntx = cdiv(a.Dx, 16);
     set_tile_divs(a);
     static const int lds_pad = getenv("VDM4CDM_LDS_PAD") ? atoi(getenv("VDM4CDM_LDS_PAD")) : 0;      // experiments: fewer workgroups per CU
-    const size_t lds = (size_t)((G::HVOX + 15) / 16) * 1024 + GN_SCRATCH_BYTES + (GNP ? GNP_TABLE_BYTES : 0) + (size_t)(lds_pad > 0 ? lds_pad : 0);
+    const size_t lds = (size_t)((G::HVOX + 15) / 16) * 1024 + GN_SCRATCH_BYTES + (GNP ? GNP_TABLE_BYTES : 0) + (GNB ? GNB_TABLE_BYTES : 0) + (size_t)(lds_pad > 0 ? lds_pad : 0);
     auto kern = conv_fwd_kernel<T, TO, KS, STRIDE, UPS, NC, TZ, TY, SPLIT, GNB, GNP, NW>;
     static unsigned long long lds_done = 0;
     {
@@ -452,7 +456,7 @@ static int launch_roll(const ConvArgs& a0, hipStream_t s) {
     a.nseg = cdiv(a.ntz, a.zsteps);
     a.fdx = make_fastdiv((uint32_t)a.ntx); a.fdy = make_fastdiv((uint32_t)a.nty); a.fdz = make_fastdiv((uint32_t)a.nseg);
     a.fdn = make_fastdiv((uint32_t)a.N);
-    const size_t lds = (size_t)6 * G::HY * G::HX * 64 + GN_SCRATCH_BYTES;
+    const size_t lds = (size_t)6 * G::HY * G::HX * 64 + GN_SCRATCH_BYTES + (GNB ? GNB_TABLE_BYTES : 0);
     auto kern = conv_roll_kernel<T, NC, GNB>;
     static unsigned long long lds_done = 0;
     {
