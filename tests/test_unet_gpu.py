@@ -528,7 +528,7 @@ def test_c4_192_training_step_properties():
     b = SyntheticAstroDataModule(cropsize=192, batch_size=2, seed=1000)._make_batch(1000, 2)
     batch = {"x": b["x"].to(DEV), "conditioning": b["conditioning"].to(DEV), "conditioning_values": [b["conditioning_values"][0].to(DEV)]}
     outs = []
-    for rep in range(2):
+    for rep in range(5):          # (five repetitions: a round-4 regression showed up in 3 of 5 identical steps, never in the first pair alone)
         torch.manual_seed(11)
         import vdm4cdm_amd.unet_hip as uh
         uh._seed_counter[0] = 0
@@ -542,9 +542,10 @@ def test_c4_192_training_step_properties():
     assert torch.isfinite(loss) and torch.isfinite(g).all()
     for name in net.spec.items:
         assert net.view(name, g).abs().max().item() > 0, f"no gradient reached {name}"
-    assert torch.equal(outs[0][0], outs[1][0]), "loss differs between two identical steps"
-    diff = [name for name in net.spec.items if not torch.equal(net.view(name, outs[0][1]), net.view(name, outs[1][1]))]
-    assert not diff, f"gradient not bit-reproducible in {len(diff)} tensors: {diff[:12]}"
+    for k in range(1, len(outs)):
+        assert torch.equal(outs[0][0], outs[k][0]), f"loss differs between identical steps 0 and {k}"
+        diff = [name for name in net.spec.items if not torch.equal(net.view(name, outs[0][1]), net.view(name, outs[k][1]))]
+        assert not diff, f"gradient not bit-reproducible (step {k} vs 0) in {len(diff)} tensors: {diff[:12]}"
 
 
 def test_full_size_128_cfg_sfm_attention_properties():

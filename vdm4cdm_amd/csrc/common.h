@@ -22,8 +22,22 @@ __device__ __forceinline__ float bf16_to_f32(uint16_t h) {
 __device__ __forceinline__ uint16_t f32_to_bf16(float f) {      // RNE, NaN-preserving (plain cast)
     return __builtin_bit_cast(uint16_t, (__bf16)f);
 }
+// (Round 4: the one-instruction form `__builtin_convertvector(f32x2 -> bf16x2)` = v_cvt_pk_bf16_f32 saves an sdwa-or per pair, but with it
+//  the training step stopped being bit-reproducible run to run (62 gradient tensors of the down path at 128^3 differ by ~1e-4 relative in
+//  3 of 5 repetitions; same sources with this scalar form: 0 of 5, `tools/repro_bits.py`).  A vector with one undefined lane bit-cast to a
+//  dword is undefined as a whole, and some callers pack pieces whose upper channels are padding - the scalar form keeps the halves
+//  independent.  VDM_PACK_CVT=1 re-enables the vector form for experiments.)
+#ifndef VDM_PACK_CVT
+#define VDM_PACK_CVT 0
+#endif
 __device__ __forceinline__ uint32_t pack_bf16x2(float lo, float hi) {
+#if VDM_PACK_CVT
+    typedef float f32x2_ __attribute__((ext_vector_type(2)));
+    typedef __bf16 bf16x2_ __attribute__((ext_vector_type(2)));
+    return __builtin_bit_cast(uint32_t, __builtin_convertvector(f32x2_{lo, hi}, bf16x2_));
+#else
     return (uint32_t)f32_to_bf16(lo) | ((uint32_t)f32_to_bf16(hi) << 16);
+#endif
 }
 
 // Per-dtype constants.  A "piece" is 16 bytes of consecutive channels of one voxel

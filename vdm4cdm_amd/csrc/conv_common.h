@@ -897,6 +897,9 @@ __device__ __forceinline__ void st_sub(T* p, const float (&f)[SUB]) {
 #ifndef VDM_GNB_PACKED
 #define VDM_GNB_PACKED 1
 #endif
+#ifndef VDM_GNB_TABLE
+#define VDM_GNB_TABLE 1
+#endif
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 template <typename T, int NC, int NV>
 struct GnbRegs {

@@ -61,8 +61,8 @@ __global__ void __launch_bounds__(64 * NW, NW == 8 ? 4 : ((TZ * TY <= 16 && NC <
     GnbRegs<T, NC, GNB ? NV : 1> gr;
     constexpr bool GNB_PRE = GNB && NC <= 2 && NW == 4;      // (eight-wave workgroups: 128 registers per wave, the rolling window instead)
     float* gnb_tab = reinterpret_cast<float*>(lds + ((G::HVOX + 15) / 16) * 1024 + GN_SCRATCH_BYTES);      // (behind the GN scratch; read after the first barrier)
-    if constexpr (GNB) gnb_consts_table(gnb_tab, a, n, e_cout0, tid);
-    if constexpr (GNB_PRE) gnb_issue<T, G, NC, NV, true>(gr, a, n, oz0, oy0, ox0, wave, lane, e_cout0, e_qstride);
+    if constexpr (GNB && VDM_GNB_TABLE) gnb_consts_table(gnb_tab, a, n, e_cout0, tid);
+    if constexpr (GNB_PRE) gnb_issue<T, G, NC, NV, VDM_GNB_TABLE != 0>(gr, a, n, oz0, oy0, ox0, wave, lane, e_cout0, e_qstride);
     float badd[NC * 4];                                      // bias + conditioning bias of the lane's channels (latency hidden behind the taps)
     if constexpr (!GNB) load_badd<NC>(badd, a, n, e_cout0 + (lane >> 4) * e_qstride);
 
@@ -112,7 +112,7 @@ __global__ void __launch_bounds__(64 * NW, NW == 8 ? 4 : ((TZ * TY <= 16 && NC <
     const int tile = (tz * a.nty + ty) * a.ntx + tx;
     if constexpr (GNB) {
         static_assert(sizeof(T) == sizeof(TO), "the folded GroupNorm backward stores dyh in the activation dtype");
-        conv_epilogue_gnb<T, G, NC, NV, GNB_PRE, true>(acc, a, gr, n, oz0, oy0, ox0, wave, lane, gn_sm, tile, e_cout0, e_qstride, gnb_tab);
+        conv_epilogue_gnb<T, G, NC, NV, GNB_PRE, VDM_GNB_TABLE != 0>(acc, a, gr, n, oz0, oy0, ox0, wave, lane, gn_sm, tile, e_cout0, e_qstride, gnb_tab);
     } else
         conv_epilogue<T, TO, G, NC, NV>(acc, a, badd, n, oz0, oy0, ox0, wave, lane, gn_sm, tile, e_cout0, e_qstride);
 #ifdef VDM_TIMELINE
@@ -174,7 +174,7 @@ __global__ void __launch_bounds__(256, 2) conv_roll_kernel(const ConvArgs a) {
     const RowStager<T, G, 0> st(x, a, n, 0, oy0, ox0, 0, lane, 1, 0, 0, 0, a.Sz, a.Sy, a.Sx);
     float* gn_sm = reinterpret_cast<float*>(lds + R * SLICE);
     float* gnb_tab = reinterpret_cast<float*>(lds + R * SLICE + GN_SCRATCH_BYTES);
-    if constexpr (GNB) gnb_consts_table(gnb_tab, a, n, e_cout0, tid);     // (one sample, one chunk per column: once; read behind the first barrier)
+    if constexpr (GNB && VDM_GNB_TABLE) gnb_consts_table(gnb_tab, a, n, e_cout0, tid);     // (one sample, one chunk per column: once; read behind the first barrier)
     constexpr int WPD = WPipe<NC>::WPD;
 
     // slices are addressed by their position p = iz + 1 - 4 zs0 >= 0 in the column walk; slot = p mod 6
@@ -211,7 +211,7 @@ __global__ void __launch_bounds__(256, 2) conv_roll_kernel(const ConvArgs a) {
         }
         const int tile = (s * a.nty + ty) * a.ntx + tx;
         if constexpr (GNB)
-            conv_epilogue_gnb<T, G, NC, NV, false, true>(acc, a, gr, n, oz0, oy0, ox0, wave, lane, gn_sm, tile, e_cout0, e_qstride, gnb_tab);
+            conv_epilogue_gnb<T, G, NC, NV, false, VDM_GNB_TABLE != 0>(acc, a, gr, n, oz0, oy0, ox0, wave, lane, gn_sm, tile, e_cout0, e_qstride, gnb_tab);
         else
             conv_epilogue<T, T, G, NC, NV>(acc, a, badd, n, oz0, oy0, ox0, wave, lane, gn_sm, tile, e_cout0, e_qstride);
     }
