@@ -324,7 +324,8 @@ def test_cabi_argument_errors_do_not_need_a_gpu(hip_lib):
     d.ksize = 3
     assert hip_lib.vdm_conv_packed_bytes(d, 0) == 27 * 2 * 64 * 16 * 2     # 2 K-blocks (fp32: 16 ch) x 27 taps x NC=2 x 1 KiB
     assert hip_lib.vdm_conv_fwd(d, None, None, None, None, 0, None, None, None, None) == -1   # VDM_ERR_ARG, no launch
-    assert hip_lib.vdm_conv_gn_tiles(d) == 1 and hip_lib.vdm_conv_kernel_variant(d, 0) == 0     # host-side planning only
+    # host-side planning only (4 tiles: since round 4 fp32 storage takes the small-grid tiles too - a 4^3 volume runs as four 1x4x16 tiles)
+    assert hip_lib.vdm_conv_gn_tiles(d) == 4 and hip_lib.vdm_conv_kernel_variant(d, 0) == 0
 
 
 def test_synthetic_datamodule_contract():
