@@ -34,6 +34,10 @@ def simplify(name):
     m = re.search(r"conv_cls_kernel<vdm::(\w+), (\d), (\d)>", name)
     if m:
         return f"conv_cls_kernel<{m.group(1)},NC{m.group(2)},{'B' if m.group(3) == '1' else 'F'}>"
+    # conv_wgrad_rows_kernel<T, TZ, TY, ROLL>: the row-resident / rolling form of conv_wgrad_kernel<T, 3, 1, 0, ...> - same family key
+    m = re.search(r"conv_wgrad_rows_kernel<vdm::(\w+), \d+, \d+, (?:true|false)>", name)
+    if m:
+        return f"conv_wgrad_kernel<{m.group(1)},k3,s1,u0>"
     # conv_wgrad_kernel<T, KS, STRIDE, UPS, TZ, TY, NTA, NTB>
     m = re.search(r"conv_wgrad_kernel<vdm::(\w+), (\d), (\d), (\d), \d+, \d+(?:, (\d), (\d))?>", name)
     if m:

@@ -5,8 +5,6 @@ set -e
 tag=${1:-r04}
 out=$PWD/gpurun_out
 mkdir -p "$out"
-python bench.py > "$out/${tag}_bench_c3.json" 2> "$out/${tag}_bench_c3.err"
-echo "bench done"
 export TMPDIR=/tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d "$out/${tag}_stats" -- python3 bench.py --steps 10 --warmup 3 --no-cpu-baseline --all-kernel-events --sample-steps 0 > "$out/${tag}_bench_c3_all_kernel_events_under_rocprof.json" 2> "$out/${tag}_stats.err"
 f=$(ls "$out/${tag}_stats"/*/*kernel_stats.csv | head -1)
@@ -37,4 +35,15 @@ python tools/step_timeline.py "$(ls "$out"/${tag}_samp_tr/*/*kernel_trace.csv | 
 rm -rf "$out/${tag}_samp_tr"
 python tools/sampler_profile.py --steps 200 > "$out/${tag}_sampler_plain.json" 2>/dev/null
 cat "$out/${tag}_sampler_plain.json"
+# phase stamps of the weight-gradient kernels (diagnostic build), tap-split kernel next to the row-resident rolling kernel
+if [ -f vdm4cdm_amd/libvdm4cdm_hip_timeline.so ]; then
+  ( for v in 0 1; do VDM4CDM_WGRAD_ROWS=$v VDM4CDM_LIB=$PWD/vdm4cdm_amd/libvdm4cdm_hip_timeline.so python tools/wgrad_phases.py --shape L0_32_32; done
+    VDM4CDM_WGRAD_WGS=256 VDM4CDM_LIB=$PWD/vdm4cdm_amd/libvdm4cdm_hip_timeline.so python tools/wgrad_phases.py --shape L0_32_32
+    VDM4CDM_LIB=$PWD/vdm4cdm_amd/libvdm4cdm_hip_timeline.so python tools/wgrad_phases.py --shape L0_64_32 ) 2>&1 | grep -v amdgpu.ids > "$out/${tag}_wgrad_phases.txt"
+fi
+python bench.py --config c2 --steps 40 --warmup 5 --no-cpu-baseline --sample-steps 0 > "$out/${tag}_bench_c2.json" 2>/dev/null
+# the default bench line LAST: its roofline object reads the counter tables of THIS profile (static files under profiles/)
+cp "$out/${tag}_pmc_bench_traffic.json" "$out/${tag}_pmc_mfma_util.json" profiles/ 2>/dev/null || true
+python bench.py > "$out/${tag}_bench_c3.json" 2> "$out/${tag}_bench_c3.err"
+echo "bench done"
 echo done
