@@ -24,9 +24,10 @@ __device__ __forceinline__ uint16_t f32_to_bf16(float f) {      // RNE, NaN-pres
 }
 // (Round 4: the one-instruction form `__builtin_convertvector(f32x2 -> bf16x2)` = v_cvt_pk_bf16_f32 saves an sdwa-or per pair, but with it
 //  the training step stopped being bit-reproducible run to run (62 gradient tensors of the down path at 128^3 differ by ~1e-4 relative in
-//  3 of 5 repetitions; same sources with this scalar form: 0 of 5, `tools/repro_bits.py`).  A vector with one undefined lane bit-cast to a
-//  dword is undefined as a whole, and some callers pack pieces whose upper channels are padding - the scalar form keeps the halves
-//  independent.  VDM_PACK_CVT=1 re-enables the vector form for experiments.)
+//  3 of 5 repetitions; same sources with this scalar form: 0 of 5 at 128^3 and 192^3, `tools/repro_bits.py`).  Cause not established - a
+//  vector with one undefined lane bit-cast to a dword is undefined as a whole (pieces with padding channels), or a hazard the compiler
+//  misses between the quarter-rate instructions that feed the conversion and the new instruction.  VDM_PACK_CVT=1 re-enables the vector
+//  form for experiments.)
 #ifndef VDM_PACK_CVT
 #define VDM_PACK_CVT 0
 #endif
