@@ -257,6 +257,26 @@ __device__ __forceinline__ uint64_t mix_seed(uint64_t seed, const int32_t* step)
     return step ? seed + (uint64_t)(uint32_t)(*step) * 0x9E3779B97F4A7C15ull : seed;
 }
 
+// Dropout keep bits of one 16-byte piece (EPL elements) from ONE Philox4x32-10 block keyed by (seed, global piece index): fp32 storage
+// (4 elements) takes 32 bits per element, bf16 storage (8 elements) 16 bits per element - keep iff the field exceeds p scaled to the
+// field (|rate - p| < 8e-6 at 16 bits).  Round 4: was one Philox block per FOUR elements, i.e. two per bf16 piece - the generator was a
+// third of the level-0 pass (153 vs 110 us with / without dropout).
+template <int EPL>
+__device__ __forceinline__ unsigned keep_bits_of_piece(uint64_t seed, uint64_t piece, float p) {
+    uint32_t rnd[4];
+    Philox::gen((uint32_t)piece, (uint32_t)(piece >> 32), 0x5eedu, 0u, (uint32_t)seed, (uint32_t)(seed >> 32), rnd);
+    unsigned bits = 0;
+    if constexpr (EPL == 4) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) bits |= (u32_to_unit(rnd[j]) > p ? 1u : 0u) << j;
+    } else {
+        const uint32_t thr = (uint32_t)(p * 65536.0f + 0.5f);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) bits |= ((((rnd[j >> 1] >> (16 * (j & 1))) & 0xffffu) >= thr) ? 1u : 0u) << j;
+    }
+    return bits;
+}
+
 template <typename T>
 __global__ void __launch_bounds__(256) gn_silu_fwd_kernel(const GnArgs a) {
     constexpr int EPL = DT<T>::EPL;
@@ -280,27 +300,20 @@ __global__ void __launch_bounds__(256) gn_silu_fwd_kernel(const GnArgs a) {
         float mean, rstd;
         gn_affine(a.stats, n, a.G, c / gs, cnt, a.eps, a.gamma[c], a.beta[c], A[j], B[j], mean, rstd);
     }
-    for (int64_t i = start; i < npieces; i += stride) {
-        const int64_t v = i / PPV;
+    // (the voxel of piece i advances by a constant per iteration: stride % PPV == 0 - no 64-bit division inside the loop)
+    int64_t v = start / PPV;
+    const int64_t dv = stride / PPV;
+    for (int64_t i = start; i < npieces; i += stride, v += dv) {
         const uint4 raw = pc < P1 ? *reinterpret_cast<const uint4*>(x1 + v * a.c1 + pc * EPL)
                                   : *reinterpret_cast<const uint4*>(x2 + v * a.c2 + (pc - P1) * EPL);
         Piece<T> p;
         p.load(raw);
-        uint32_t rnd[4];
-        unsigned keepbits = 0;
+        const unsigned keepbits = drop ? keep_bits_of_piece<EPL>(seed, (uint64_t)n * npieces + (uint64_t)i, a.p) : 0xffu;
 #pragma unroll
         for (int j = 0; j < EPL; ++j) {
             float o = p.f[j] * A[j] + B[j];
             if (!a.linear) o = silu_f(o);
-            if (drop) {
-                if ((j & 3) == 0) {
-                    const uint64_t e4 = ((uint64_t)n * a.V * C + (uint64_t)i * EPL + j) >> 2;
-                    Philox::gen((uint32_t)e4, (uint32_t)(e4 >> 32), 0x5eedu, 0u, (uint32_t)seed, (uint32_t)(seed >> 32), rnd);
-                }
-                const bool keep = u32_to_unit(rnd[j & 3]) > a.p;
-                keepbits |= (keep ? 1u : 0u) << j;
-                o *= keep ? inv_keep : 0.f;
-            }
+            if (drop) o *= ((keepbits >> j) & 1u) ? inv_keep : 0.f;
             p.f[j] = o;
         }
         *reinterpret_cast<uint4*>(y + i * EPL) = p.store();
@@ -342,24 +355,19 @@ __global__ void __launch_bounds__(256) gn_dyh_kernel(const GnArgs a) {
         float mean, rstd;
         gn_affine(a.stats, n, a.G, c / gs, cnt, a.eps, a.gamma[c], a.beta[c], A[j], B[j], mean, rstd);
     }
-    for (int64_t i = start; i < npieces; i += stride) {
-        const int64_t v = i / PPV;
+    int64_t v = start / PPV;
+    const int64_t dv = stride / PPV;
+    for (int64_t i = start; i < npieces; i += stride, v += dv) {
         const uint4 raw = pc < P1 ? *reinterpret_cast<const uint4*>(x1 + v * a.c1 + pc * EPL)
                                   : *reinterpret_cast<const uint4*>(x2 + v * a.c2 + (pc - P1) * EPL);
         Piece<T> px, pd;
         px.load(raw);
         pd.load(*reinterpret_cast<const uint4*>(dy + i * EPL));
-        uint32_t rnd[4];
+        const unsigned keepbits = drop ? keep_bits_of_piece<EPL>(seed, (uint64_t)n * npieces + (uint64_t)i, a.p) : 0xffu;      // (the forward's bits)
 #pragma unroll
         for (int j = 0; j < EPL; ++j) {
             float d = a.linear ? pd.f[j] : pd.f[j] * dsilu(px.f[j] * A[j] + B[j]);
-            if (drop) {
-                if ((j & 3) == 0) {
-                    const uint64_t e4 = ((uint64_t)n * a.V * C + (uint64_t)i * EPL + j) >> 2;
-                    Philox::gen((uint32_t)e4, (uint32_t)(e4 >> 32), 0x5eedu, 0u, (uint32_t)seed, (uint32_t)(seed >> 32), rnd);
-                }
-                d *= u32_to_unit(rnd[j & 3]) > a.p ? inv_keep : 0.f;
-            }
+            if (drop) d *= ((keepbits >> j) & 1u) ? inv_keep : 0.f;
             pd.f[j] = d;
         }
         *reinterpret_cast<uint4*>(dyh + i * EPL) = pd.store();
@@ -462,8 +470,9 @@ __global__ void __launch_bounds__(256) gn_bwd_apply_kernel(const GnArgs a) {
         Qc[j] = -rstd * rstd * m2;
         Rc[j] = rstd * (mean * rstd * m2 - m1);
     }
-    for (int64_t i = start; i < npieces; i += stride) {
-        const int64_t v = i / PPV;
+    int64_t v = start / PPV;
+    const int64_t dv = stride / PPV;
+    for (int64_t i = start; i < npieces; i += stride, v += dv) {
         const uint4 raw = pc < P1 ? *reinterpret_cast<const uint4*>(x1 + v * a.c1 + pc * EPL)
                                   : *reinterpret_cast<const uint4*>(x2 + v * a.c2 + (pc - P1) * EPL);
         Piece<T> px, pd, pa;
