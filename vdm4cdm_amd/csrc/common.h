@@ -157,6 +157,24 @@ struct Philox {
         out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
     }
 };
+// Division of a block / tile index by a launch constant as multiply-high + shifts (Granlund-Montgomery round-up form, exact for all
+// 32-bit n): on wave-uniform operands it is three SCALAR instructions - `b % a.ntx; b /= a.ntx` on runtime divisors compiled to a
+// float-reciprocal sequence on the vector unit (~20 vector instructions per division, eight divisions per workgroup).
+struct FastDiv { uint32_t m, s1, s2; };
+static inline FastDiv make_fastdiv(uint32_t d) {
+    FastDiv f;
+    uint32_t l = 0;
+    while ((1ull << l) < d) ++l;                          // ceil(log2 d)
+    f.m = (uint32_t)(((1ull << 32) * ((1ull << l) - d)) / d + 1);
+    f.s1 = l < 1 ? l : 1;
+    f.s2 = l > 0 ? l - 1 : 0;
+    return f;
+}
+__device__ __forceinline__ uint32_t fdiv(uint32_t n, const FastDiv& f) {
+    const uint32_t t = __umulhi(n, f.m);
+    return (t + ((n - t) >> f.s1)) >> f.s2;
+}
+
 __host__ __device__ inline float u32_to_unit(uint32_t u) {          // (0,1]
     return ((float)(u >> 8) + 1.0f) * (1.0f / 16777216.0f);
 }

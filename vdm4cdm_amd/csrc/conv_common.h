@@ -46,24 +46,6 @@ struct Geo {
     static_assert(ROWS % NW == 0, "rows must split over the waves");
 };
 
-// Division of a block / tile index by a launch constant as multiply-high + shifts (Granlund-Montgomery round-up form, exact for all
-// 32-bit n): on wave-uniform operands it is three SCALAR instructions - `b % a.ntx; b /= a.ntx` on runtime divisors compiled to a
-// float-reciprocal sequence on the vector unit (~20 vector instructions per division, eight divisions per workgroup).
-struct FastDiv { uint32_t m, s1, s2; };
-static inline FastDiv make_fastdiv(uint32_t d) {
-    FastDiv f;
-    uint32_t l = 0;
-    while ((1ull << l) < d) ++l;                          // ceil(log2 d)
-    f.m = (uint32_t)(((1ull << 32) * ((1ull << l) - d)) / d + 1);
-    f.s1 = l < 1 ? l : 1;
-    f.s2 = l > 0 ? l - 1 : 0;
-    return f;
-}
-__device__ __forceinline__ uint32_t fdiv(uint32_t n, const FastDiv& f) {
-    const uint32_t t = __umulhi(n, f.m);
-    return (t + ((n - t) >> f.s1)) >> f.s2;
-}
-
 struct ConvArgs {
     const void* x;       // staged operand (input for fwd/wgrad, dOut for dgrad)
     const void* w;       // packed weights

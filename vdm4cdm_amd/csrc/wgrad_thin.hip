@@ -27,6 +27,7 @@ struct ThinArgs {
     const float* gstats; const float* ggamma; const float* gred; const float* gchan;
     float* gdgamma; float* gdbeta;
     int gG; float geps;
+    FastDiv fdx, fdy, fdz;   // divisions of the chunk index by the x chunks per row, Dy, Dz (scalar multiply-high: the index is wave-uniform)
 };
 
 constexpr int THIN_COLS = 80;                               // 9 rows x 8 + the ones row (72..79)
@@ -121,17 +122,21 @@ __global__ void __launch_bounds__(256) wgrad_thin_kernel(const ThinArgs a) {
         uint4 d[2][KP];                                     // the dense chunk (GNA: x)
         uint4 y[GNA ? 2 : 1][GNA ? KP : 1], ad[GNA ? 2 : 1][GNA ? KP : 1];      // GNA: dyh, residual-path gradient
         uint32_t t[6];
-        int n;
+        int n, x0;
     };
     auto fetch = [&](unsigned ch, Regs& R) {                // (32-bit index arithmetic: the loop is issue-bound)
         const bool live = ch < (unsigned)nchunks;
         unsigned r = live ? ch : 0u;
-        const int xc = (int)(r % uxch); r /= uxch;
-        const int y = (int)(r % uDy); r /= uDy;
-        const int z = (int)(r % uDz);
-        const int n = (int)(r / uDz);
+        unsigned qd = fdiv(r, a.fdx);                      // (three float-reciprocal division sequences per chunk before: ~80 of its ~280 instructions)
+        const int xc = (int)(r - qd * uxch); r = qd;
+        qd = fdiv(r, a.fdy);
+        const int y = (int)(r - qd * uDy); r = qd;
+        qd = fdiv(r, a.fdz);
+        const int z = (int)(r - qd * uDz);
+        const int n = (int)qd;
         const int x0 = xc * 32;
         R.n = n;
+        R.x0 = x0;
         // dense chunk: lane (v16, q) of half h -> voxel x0 + 16 h + v16, pieces q, q + 4, ...
         const size_t rowo = ((((size_t)n * a.Dz + z) * a.Dy + y) * a.Dx) * C;
 #pragma unroll
@@ -186,7 +191,7 @@ __global__ void __launch_bounds__(256) wgrad_thin_kernel(const ThinArgs a) {
                 const int pc = k * 4 + q;
                 uint4 val = cur.d[h][k];
                 if constexpr (GNA) {                        // dx = dyh * P + x * Q + R (+ add), rounded to bf16 like the tensor it replaces
-                    const int xv = (int)((ch % uxch) * 32) + 16 * h + v16;
+                    const int xv = cur.x0 + 16 * h + v16;
                     const bool inside = xv < a.Dx && pc < 2 * MT;
                     Piece<bf16_t> px, pd, pa;
                     px.load(val);
@@ -281,9 +286,11 @@ __global__ void __launch_bounds__(256) wgrad_thin_reduce_kernel(const float* __r
     }
 }
 
+// persistent workgroups (4 waves each, one chunk per wave in flight ahead of the one it consumes).  VDM4CDM_THIN_WGS: A/B
 static int thin_grid(long long nchunks) {
+    static const int cap = [] { const char* e = getenv("VDM4CDM_THIN_WGS"); const int v = e ? atoi(e) : 512; return v > 0 ? v : 512; }();
     long long want = (nchunks + 3) / 4;
-    if (want > 512) want = 512;
+    if (want > cap) want = cap;
     return (int)(want < 1 ? 1 : want);
 }
 
@@ -318,7 +325,8 @@ int launch_wgrad_thin(int mode, const void* x, const void* dout, int n, int od, 
         return VDM_ERR_ARG;
     }
     const long long nchunks = (long long)n * od * oh * ((ow + 31) / 32);
-    if (nchunks + 4 * 512 >= 0x7fffffffLL || nvox >= 0x7fffffffLL) { set_error("conv_wgrad: tensor too large for the thin-side kernel"); return VDM_ERR_ARG; }
+    if (nchunks + 4 * 4096 >= 0x7fffffffLL || nvox >= 0x7fffffffLL) { set_error("conv_wgrad: tensor too large for the thin-side kernel"); return VDM_ERR_ARG; }
+    a.fdx = make_fastdiv((uint32_t)((ow + 31) / 32)); a.fdy = make_fastdiv((uint32_t)oh); a.fdz = make_fastdiv((uint32_t)od);
     const int grid = thin_grid(nchunks);
     const long long cb = (nvox + 256 * 8 - 1) / (256 * 8);
     hipLaunchKernelGGL(thin_compact_kernel, dim3((unsigned)(cb > 4096 ? 4096 : cb)), dim3(256), 0, s, (const bf16_t*)(mode == 0 ? x : dout), nvox, compact);
@@ -351,7 +359,8 @@ int launch_wgrad_thin_gna(const ThinArgs& g, const void* thin_x, int cin, float*
     }
     const long long nvox = (long long)a.N * a.Dz * a.Dy * a.Dx;
     const long long nchunks = (long long)a.N * a.Dz * a.Dy * ((a.Dx + 31) / 32);
-    if (nchunks + 4 * 512 >= 0x7fffffffLL || nvox >= 0x7fffffffLL) { set_error("gn_bwd_apply_wgrad_thin: tensor too large"); return VDM_ERR_ARG; }
+    if (nchunks + 4 * 4096 >= 0x7fffffffLL || nvox >= 0x7fffffffLL) { set_error("gn_bwd_apply_wgrad_thin: tensor too large"); return VDM_ERR_ARG; }
+    a.fdx = make_fastdiv((uint32_t)((a.Dx + 31) / 32)); a.fdy = make_fastdiv((uint32_t)a.Dy); a.fdz = make_fastdiv((uint32_t)a.Dz);
     uint32_t* compact = reinterpret_cast<uint32_t*>((char*)workspace + thin_slab_bytes(a.N, a.Dz, a.Dy, a.Dx, a.C));
     a.slabs = (float*)workspace;
     a.thin = compact;
