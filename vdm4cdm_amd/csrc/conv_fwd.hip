@@ -137,16 +137,11 @@ __global__ void __launch_bounds__(64 * NW, NW == 8 ? 4 : ((TZ * TY <= 16 && NC <
 // right behind the tap loop of step s (the slots it overwrites are free once every wave has left the taps) and lands under the
 // epilogue's stores.
 // ---------------------------------------------------------------------------------------------
-// STG (stager waves): the stamps say a workgroup that stages its own slices spends stage 4.0 + taps 3.97 + epilogue 1.0 us per tile when it
-// has the CU to itself, and two of them per CU reach 7.4 us per tile - an LDS-DMA blocks the wave that issues it until the memory pipeline
-// takes it.  Here ONE workgroup per CU has four MFMA waves (one per SIMD, never issuing a DMA) and two stager waves that do nothing else:
-// ring of 10 slice slots (115 KB), the stagers load the four new slices of step s + 1 while the MFMA waves run the taps and the epilogue
-// of step s; one rendezvous per step (+ the epilogue's own barrier, which the stagers join).
-template <typename T, int NC, bool GNB, bool STG = false>
-__global__ void __launch_bounds__(STG ? 384 : 256, STG ? 1 : 2) conv_roll_kernel(const ConvArgs a) {
+template <typename T, int NC, bool GNB>
+__global__ void __launch_bounds__(256, 2) conv_roll_kernel(const ConvArgs a) {
     static_assert(sizeof(T) == 2, "bf16 storage");
     using G = Geo<3, 1, 4, 8>;
-    constexpr int NV = G::NV, TAPS = G::TAPS, NCW = NC, R = STG ? 10 : 6;
+    constexpr int NV = G::NV, TAPS = G::TAPS, NCW = NC, R = 6;
     constexpr int SLICE = G::HY * G::HX * 64;
     static_assert(NV == G::TY, "a wave owns one z slab of the step");
     extern __shared__ __attribute__((aligned(16))) char lds[];
@@ -184,27 +179,13 @@ __global__ void __launch_bounds__(STG ? 384 : 256, STG ? 1 : 2) conv_roll_kernel
 
     // slices are addressed by their position p = iz + 1 - 4 zs0 >= 0 in the column walk; slot = p mod 6
     auto stage = [&](int p0, int cnt) {                      // positions p0 .. p0 + cnt - 1
-        for (int r = STG ? wave - 4 : wave; r < cnt * G::HY; r += STG ? 2 : 4) {
+        for (int r = wave; r < cnt * G::HY; r += 4) {
             const int sl = r / G::HY, hy = r % G::HY;
             const int p = p0 + sl;
             st.row(lds + (p % R) * SLICE + hy * (G::HX * 64), a, 4 * zs0 + p, hy);      // (RowStager: iz = iz0 + hz with iz0 = -1)
         }
     };
-    if constexpr (STG) {
-        if (wave >= 4) {                                    // ---- stager waves ----
-            const bool ep_barrier = GNB || a.gnp != nullptr; // (the epilogue's GroupNorm partial fold has one workgroup barrier)
-            stage(0, 6);
-            for (int s = zs0; s < zs1; ++s) {
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                __builtin_amdgcn_s_barrier();               // B(s): the slices of step s have landed; the MFMA waves are done with step s - 1
-                if (s + 1 < zs1) stage(4 * (s - zs0) + 6, 4);      // positions of step s + 1 that step s does not read: the slots of step s - 1
-                if (ep_barrier) __builtin_amdgcn_s_barrier();
-            }
-            return;
-        }
-    } else {
-        stage(0, R);
-    }
+    stage(0, R);
     for (int s = zs0; s < zs1; ++s) {
         const int oz0 = s * G::TZ, p0 = 4 * (s - zs0);      // this step reads positions p0 .. p0 + 5
         f32x4 acc[NV][NC];
@@ -220,20 +201,13 @@ __global__ void __launch_bounds__(STG ? 384 : 256, STG ? 1 : 2) conv_roll_kernel
         asm volatile("" : "+v"(wks));
         uint4 wf[WPD + 1][NC];
         rr_prefetch_weights<NC, WPD, NCW>(wf, wks);
-        if constexpr (STG) {
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            __builtin_amdgcn_s_barrier();                   // B(s) (raw: the previous step's stores keep draining)
-        } else {
-            __syncthreads();                                // (vmcnt(0) + barrier: the slices of this step have landed)
-        }
+        __syncthreads();                                    // (vmcnt(0) + barrier: the slices of this step have landed)
         const int zoff[3] = {((p0 + wave) % R) * SLICE, ((p0 + wave + 1) % R) * SLICE, ((p0 + wave + 2) % R) * SLICE};
         taps_rowreuse_z<T, G, NC, NV, WPD, NCW>(acc, lds, wks, wf, lanex, zoff);
-        if constexpr (!STG) {
-            if (s + 1 < zs1) {                              // next step's four new slices, behind this step's taps
-                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-                __builtin_amdgcn_s_barrier();               // every wave has read its operands: positions p0 .. p0 + 3 are free
-                stage(p0 + R, 4);
-            }
+        if (s + 1 < zs1) {                                  // next step's four new slices, behind this step's taps
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();                   // every wave has read its operands: positions p0 .. p0 + 3 are free
+            stage(p0 + R, 4);
         }
         const int tile = (s * a.nty + ty) * a.ntx + tx;
         if constexpr (GNB)
@@ -469,29 +443,21 @@ static bool roll_enabled() {
     static const bool on = getenv("VDM4CDM_ROLL") ? atoi(getenv("VDM4CDM_ROLL")) != 0 : true;
     return on;
 }
-// VDM4CDM_ROLL_STG: bit 0 - the plain kernel, bit 1 - the folded-GroupNorm kernel run with stager waves (one 6-wave workgroup per CU)
-static int roll_stg_mask() {
-    static const int m = getenv("VDM4CDM_ROLL_STG") ? atoi(getenv("VDM4CDM_ROLL_STG")) : 0;
-    return m;
-}
-template <typename T, int NC, bool GNB, bool STG = false>
+template <typename T, int NC, bool GNB>
 static int launch_roll(const ConvArgs& a0, hipStream_t s) {
     using G = Geo<3, 1, 4, 8>;
-    if constexpr (!STG) {
-        if ((roll_stg_mask() >> (GNB ? 1 : 0)) & 1) return launch_roll<T, NC, GNB, true>(a0, s);
-    }
     ConvArgs a = a0;
     a.ntz = cdiv(a.Dz, G::TZ); a.nty = cdiv(a.Dy, G::TY); a.ntx = cdiv(a.Dx, 16);
     const long long ncols = (long long)a.N * a.nty * a.ntx * a.nchunks;
-    int nseg = (int)(((STG ? 1LL : 2LL) * cu_count() + ncols - 1) / ncols);          // ~2 persistent workgroups per CU (STG: one)
+    int nseg = (int)((2LL * cu_count() + ncols - 1) / ncols);          // ~2 persistent workgroups per CU
     if (nseg > a.ntz / 2) nseg = a.ntz / 2;                             // >= 2 steps per segment, or the walk saves nothing
     if (nseg < 1) nseg = 1;
     a.zsteps = cdiv(a.ntz, nseg);
     a.nseg = cdiv(a.ntz, a.zsteps);
     a.fdx = make_fastdiv((uint32_t)a.ntx); a.fdy = make_fastdiv((uint32_t)a.nty); a.fdz = make_fastdiv((uint32_t)a.nseg);
     a.fdn = make_fastdiv((uint32_t)a.N);
-    const size_t lds = (size_t)(STG ? 10 : 6) * G::HY * G::HX * 64 + GN_SCRATCH_BYTES + (GNB ? GNB_TABLE_BYTES : 0);
-    auto kern = conv_roll_kernel<T, NC, GNB, STG>;
+    const size_t lds = (size_t)6 * G::HY * G::HX * 64 + GN_SCRATCH_BYTES + (GNB ? GNB_TABLE_BYTES : 0);
+    auto kern = conv_roll_kernel<T, NC, GNB>;
     static unsigned long long lds_done = 0;
     {
         int e = set_lds(kern, lds, lds_done);
@@ -499,7 +465,7 @@ static int launch_roll(const ConvArgs& a0, hipStream_t s) {
     }
     const long long nwg = ncols * a.nseg;
     if (nwg > 0x7fffffffLL) { set_error("conv: grid too large"); return VDM_ERR_ARG; }
-    hipLaunchKernelGGL(kern, dim3((unsigned)nwg), dim3(STG ? 384 : 256), lds, s, a);
+    hipLaunchKernelGGL(kern, dim3((unsigned)nwg), dim3(256), lds, s, a);
     VDM_LAUNCH_CHECK("conv_roll_kernel");
     return VDM_OK;
 }
