@@ -48,3 +48,26 @@ def _quiesce_gpu_before_freeing():
         yield
     finally:
         torch.cuda.empty_cache = orig
+
+
+@pytest.fixture(autouse=True)
+def _release_gpu_state_between_tests():
+    """After every GPU test: drain the device, drop the library's per-stream scratch caches and return the cached blocks to the driver, so
+    that no test inherits device memory (or a graph-pool remnant) of the ~360 tests that ran before it in the same process.  The round-4
+    full-suite runs died twice (of seven) inside the hipGraph sampler tests at the end of test_unet_gpu.py - a segfault in hipFree and an
+    abort at a device-to-host copy - and never in a test file run on its own."""
+    yield
+    try:
+        import torch
+    except Exception:
+        return
+    if not torch.cuda.is_available():
+        return
+    import gc
+    from vdm4cdm_amd import hip_ops as ops
+    torch.cuda.synchronize()
+    for cache in (ops.Conv._ws, ops._gn_ws, ops._skip_ws, ops._red_ws):
+        cache.clear()
+    gc.collect()
+    torch.cuda.synchronize()
+    torch.cuda.empty_cache()

@@ -106,6 +106,19 @@ def _s():
     return torch.cuda.current_stream().cuda_stream
 
 
+def _scratch(cache, key, numel, dtype, device, floor=0):
+    """Per-(device, stream) scratch tensors are cached in module-level dicts - EXCEPT while the current stream is being captured into a
+    hipGraph: an allocation made during capture comes out of that graph's private memory pool, the pool keeps the block for the replays
+    whether or not the tensor object survives, and a module-level reference would pin memory of a pool whose graph is long gone (and
+    hand it to later captures / eager launches on a stream that happens to reuse the handle).  Under capture: a fresh tensor, not cached."""
+    if torch.cuda.is_current_stream_capturing():
+        return torch.empty(max(numel, floor), dtype=dtype, device=device)
+    ws = cache.get(key)
+    if ws is None or ws.numel() < numel:
+        ws = cache[key] = torch.empty(max(numel, floor), dtype=dtype, device=device)
+    return ws
+
+
 # The side stream a launch is being issued on (set by unet_hip.SideStream.run around its body), else None.  Every tensor whose pointer
 # goes to a kernel while it is set is recorded on that stream HERE - one choke point instead of a record_stream per call site: memory
 # that was allocated on the main stream and is still referenced by a queued side-stream kernel (weight gradients run up to a whole
@@ -340,10 +353,7 @@ class Conv:
         out = torch.empty((n, od, oh, ow, self.cin), dtype=dout.dtype, device=dout.device)
         part = torch.empty((n, L.vdm_conv_dgw_tiles(d), self.cin, 2), dtype=torch.float32, device=dout.device)
         need = L.vdm_conv_dgw_workspace_bytes(d)
-        wkey = (dout.device, _s(), "dgw")
-        ws = Conv._ws.get(wkey)
-        if ws is None or ws.numel() < need:
-            ws = Conv._ws[wkey] = torch.empty(need, dtype=torch.uint8, device=dout.device)
+        ws = _scratch(Conv._ws, (dout.device, _s(), "dgw"), need, torch.uint8, dout.device)
         f = GnFold(x1=_p(x1), x2=_p(x2), c1=c1, c2=c2, groups=groups, stats=_p(stats), gamma=_p(gamma), beta=_p(beta), eps=GN_EPS,
                    inv_keep=1.0 / (1.0 - dropout_p) if keep_mask is not None else 1.0, keep_mask=_p(keep_mask), partials=_p(part))
         ev = _pb("conv3")
@@ -364,11 +374,7 @@ class Conv:
         assert c == cpad(self.cout, dout.dtype) and x.shape[-1] == cpad(self.cin, x.dtype)
         d = self.desc(n, od, oh, ow, x.dtype)
         need = L.vdm_conv_wgrad_workspace_bytes(d)
-        wkey = (x.device, _s())
-        ws = Conv._ws.get(wkey)
-        if ws is None or ws.numel() < need:
-            ws = torch.empty(max(need, 32 << 20), dtype=torch.uint8, device=x.device)
-            Conv._ws[wkey] = ws
+        ws = _scratch(Conv._ws, (x.device, _s()), need, torch.uint8, x.device, floor=32 << 20)
         if "wgrad" in ABLATE or ("wgrad1" in ABLATE and self.ksize == 1):
             return dw
         ev = _pb("wgrad" if self.ksize == 3 else "other")
@@ -397,9 +403,7 @@ def gn_stats(x1, x2, groups, out=None, chsum=False):
     n, v = _nv(x1)
     if out is None:
         out = torch.empty((n, groups, 2), dtype=torch.float32, device=x1.device)
-    ws = _gn_ws.get((x1.device, _s()))
-    if ws is None:
-        ws = _gn_ws[(x1.device, _s())] = torch.empty(_lib.GN_STATS_WS_BYTES // 4, dtype=torch.float32, device=x1.device)
+    ws = _scratch(_gn_ws, (x1.device, _s()), _lib.GN_STATS_WS_BYTES // 4, torch.float32, x1.device)
     c2 = 0 if x2 is None else x2.shape[-1]
     p1 = getattr(x1, "gn_partials", None)       # set by Conv.fwd(..., gn=True): that source needs no pass over the tensor
     p2 = getattr(x2, "gn_partials", None) if x2 is not None else None
@@ -545,11 +549,7 @@ def gn_bwd_fused(x1, x2, groups, stats, gamma, dyh, dgamma, dbeta, add1=None, ad
         n_, od, oh, ow, _ = x1.shape
         d = conv_in.desc(n_, od, oh, ow, x1.dtype)
         need = L.vdm_conv_wgrad_workspace_bytes(d)
-        wkey = (x1.device, _s())
-        ws = Conv._ws.get(wkey)
-        if ws is None or ws.numel() < need:
-            ws = torch.empty(max(need, 32 << 20), dtype=torch.uint8, device=x1.device)
-            Conv._ws[wkey] = ws
+        ws = _scratch(Conv._ws, (x1.device, _s()), need, torch.uint8, x1.device, floor=32 << 20)
         if "gn_apply" not in ABLATE and "wgrad" not in ABLATE:
             check(L.vdm_gn_bwd_apply_wgrad_thin(_p(x1), c1, n, od, oh, ow, groups, _p(stats), _p(gamma), GN_EPS, _p(dyh), _p(red), _p(chan), _p(add1),
                                                 _p(xin), conv_in.cin, 1 if conv_in.circular else 0, _p(dgamma), _p(dbeta), _p(dw), _p(dbias), _p(ws),
@@ -562,9 +562,7 @@ def gn_bwd_fused(x1, x2, groups, stats, gamma, dyh, dgamma, dbeta, add1=None, ad
         _contig(dout, w1, w2, dw1, dw2)
         cout = w1.shape[0]
         nws = L.vdm_gn_skip_ws_floats(c1, c2, cout, n, v)
-        ws = _skip_ws.get((x1.device, _s()))
-        if ws is None or ws.numel() < nws:
-            ws = _skip_ws[(x1.device, _s())] = torch.empty(nws, dtype=torch.float32, device=x1.device)
+        ws = _scratch(_skip_ws, (x1.device, _s()), nws, torch.float32, x1.device)
         if "gn_apply" not in ABLATE:
             check(L.vdm_gn_bwd_apply_skip(_p(x1), c1, _p(x2), c2, n, v, groups, dt_id(x1.dtype), _p(stats), _p(gamma), GN_EPS, _p(dyh), _p(red),
                                           _p(chan), _p(dout), _p(w1), _p(w2), cout, _p(dx1), _p(dx2), _p(dgamma), _p(dbeta), _p(dw1), _p(dw2),
@@ -759,11 +757,7 @@ _red_ws = {}
 
 def _reduce_ws(device):
     """per-(device, stream) scratch of the fixed-order two-stage reductions (loss terms, gradient norm)"""
-    key = (device, _s())
-    ws = _red_ws.get(key)
-    if ws is None:
-        ws = _red_ws[key] = torch.empty(2048 * 3, dtype=torch.float32, device=device)
-    return ws
+    return _scratch(_red_ws, (device, _s()), 2048 * 3, torch.float32, device)
 
 
 def loss_terms(x, eps, eps_hat, eps0, sigma0_over_alpha0, coef, sums, d_eps_hat, rng=None):

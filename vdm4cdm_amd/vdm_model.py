@@ -409,9 +409,17 @@ def hip_graph_sampler(net, z, coef, noises, seed, verbose, use_graph, s_cond, v_
         z.copy_(z_keep)             # capture does not execute, but keep the state explicit
         step.zero_()
     zs = torch.empty((n,) + tuple(z.shape), dtype=z.dtype, device=dev) if return_all else None
+    # supplied noise fields (tests / oracle comparisons; the product path draws them in-kernel): uploaded in blocks of <= 256 MB and copied
+    # device-to-device per step - one pageable host-to-device copy between every two graph replays was the only thing the tests that
+    # intermittently took the process down (round 4) did differently from the product's sampling loop
+    blk, dev_block = 1, None
+    if noise_buf is not None:
+        blk = max(1, min(n, (256 << 20) // max(1, z.numel() * z.element_size())))
     for i in range(n):
         if noise_buf is not None:
-            noise_buf.copy_(noises[i].to(z))
+            if i % blk == 0:
+                dev_block = torch.stack([noises[k].to(dtype=z.dtype) for k in range(i, min(n, i + blk))]).to(dev)
+            noise_buf.copy_(dev_block[i % blk])
         if graph is not None:
             graph.replay()
         else:
